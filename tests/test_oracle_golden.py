@@ -1,0 +1,125 @@
+"""Pin the CPU oracle (oracle/mmsbm_oracle.py) against vectors produced by the real
+reference (tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, rel_err
+from oracle import mmsbm_oracle as orc
+
+
+def test_g0_reference_backend_test_inputs():
+    g = load_golden("g0_backend_tests")
+    for tag in "ab":
+        args = (g["data"], g[f"{tag}_theta"], g[f"{tag}_eta"], g[f"{tag}_pr"])
+        # the reference's own tolerance for this case is atol=1e-8 (tests/test_backends.py:35,60)
+        assert np.array_equal(orc.compute_omegas(*args), g[f"{tag}_omegas"])
+        assert np.allclose(orc.prod_dist(*args), g[f"{tag}_prod_dist"], rtol=0, atol=1e-15)
+        nt, ne, npr = orc.update_coefficients(*args)
+        assert np.array_equal(nt, g[f"{tag}_n_theta"])
+        assert np.array_equal(ne, g[f"{tag}_n_eta"])
+        assert np.array_equal(npr, g[f"{tag}_n_pr"])
+
+
+def test_g1_c1_loop_bit_exact():
+    g = load_golden("g1_c1_mock")
+    train = g["train"]
+    d_u, d_i = orc.degrees(train)
+    assert np.array_equal(d_u, g["d_u"]) and np.array_equal(d_i, g["d_i"])
+    seeds = orc.child_seeds(1, 1)
+    out = orc.run_one_sampling(train, seeds[0], 2, 4, 500, snapshots=(0, 1, 10, 500))
+    for it in (0, 1, 10, 500):
+        t, e, p = out["snapshots"][it]
+        assert np.array_equal(t, g[f"c1_theta_{it}"]), it
+        assert np.array_equal(e, g[f"c1_eta_{it}"]), it
+        assert np.array_equal(p, g[f"c1_pr_{it}"]), it
+    assert out["likelihood"] == g["c1_likelihood_500"]
+    assert out["likelihood"] == pytest.approx(-9.470339454833308, rel=1e-14)
+    nt, ne, npr = orc.update_coefficients(train, *out["snapshots"][0])
+    assert np.array_equal(nt, g["c1_n_theta_1"])
+    assert np.array_equal(ne, g["c1_n_eta_1"])
+    assert np.array_equal(npr, g["c1_n_pr_1"])
+    assert np.array_equal(orc.compute_omegas(train, *out["snapshots"][0]), g["c1_omegas_0"])
+    lik = [orc.compute_likelihood(train, *out["snapshots"][it]) for it in (0, 1, 10, 500)]
+    assert np.array_equal(np.array(lik), g["c1_likelihood_at"])
+
+
+def test_g1_reference_end_to_end_case_and_encoding():
+    g = load_golden("g1_c1_mock")
+    train, dicts = orc.encode_train(g["train_raw_users"], g["train_raw_items"], g["train_raw_ratings"])
+    assert np.array_equal(train, g["train"])
+    assert list(dicts[0].keys()) == list(g["dict_users_keys"])
+    assert list(dicts[2].keys()) == list(g["dict_ratings_keys"])
+    test = orc.encode_test(g["test_raw_users"], g["test_raw_items"], g["test_raw_ratings"], dicts)
+    assert np.array_equal(test, g["test"])
+    res = orc.fit(train, 2, 2, iterations=10, sampling=1, seed=1)[0]
+    assert np.array_equal(res["theta"], g["t_theta"])
+    assert np.array_equal(res["pr"], g["t_pr"])
+    assert res["likelihood"] == g["t_likelihood"] == pytest.approx(-13.773187406968459, rel=1e-14)
+    pdist = orc.prod_dist(test, res["theta"], res["eta"], res["pr"])
+    assert np.allclose(pdist, g["t_prod_dist"], rtol=0, atol=1e-15)
+    assert np.array_equal(np.argmax(pdist, 1), g["t_argmax"])
+    stats = orc.score_stats(pdist, test[:, 2], sorted(set(train[:, 2].tolist())))
+    want = dict(zip(g["t_stats_keys"].tolist(), g["t_stats_vals"].tolist()))
+    for key in ("accuracy", "one_off_accuracy", "mae", "s2", "s2pond"):
+        assert float(stats[key]) == pytest.approx(want[key], rel=1e-12), key
+    # the numbers the reference's own tests assert (tests/test_mmsbm.py:65-81)
+    assert stats["accuracy"] == pytest.approx(0.13, 0.01)
+    assert stats["one_off_accuracy"] == pytest.approx(0.55, 0.01)
+    assert stats["mae"] == pytest.approx(0.78, 0.01)
+
+
+def test_g2_restarts_independent_of_sampling():
+    g = load_golden("g2_c1_sampling3")
+    res = orc.fit(g["train"], 2, 2, iterations=10, sampling=3, seed=1)
+    assert np.array_equal(np.array([r["likelihood"] for r in res]), g["likelihoods"])
+    for s in range(3):
+        assert np.array_equal(res[s]["theta"], g[f"theta_{s}"])
+        assert np.array_equal(res[s]["eta"], g[f"eta_{s}"])
+    one = orc.fit(g["train"], 2, 2, iterations=10, sampling=1, seed=1)[0]
+    assert np.array_equal(one["theta"], res[0]["theta"])
+    mean_pd = np.mean([orc.prod_dist(g["test"], r["theta"], r["eta"], r["pr"]) for r in res], axis=0)
+    assert np.allclose(mean_pd, g["prediction_matrix"], rtol=0, atol=1e-15)
+
+
+def test_g4_mid_size():
+    g = load_golden("g4_2k_k10")
+    train = g["train"]
+    out = orc.run_one_sampling(train, orc.child_seeds(0, 1)[0], 10, 10, 50, snapshots=(0, 1, 50))
+    nt, ne, npr = orc.update_coefficients(train, *out["snapshots"][0])
+    assert np.array_equal(nt, g["n_theta_1"]) and np.array_equal(ne, g["n_eta_1"])
+    assert np.array_equal(npr, g["n_pr_1"])
+    for it in (1, 50):
+        for j, nm in enumerate(("theta", "eta", "pr")):
+            assert np.array_equal(out["snapshots"][it][j], g[f"{nm}_{it}"]), (it, nm)
+    assert out["likelihood"] == g["likelihood_50"]
+
+
+def test_edge_cases():
+    g = load_golden("edge_cases")
+    for tag in ("zero", "dup", "tiny", "mix"):
+        args = (g[f"{tag}_data"], g[f"{tag}_theta"], g[f"{tag}_eta"], g[f"{tag}_pr"])
+        nt, ne, npr = orc.update_coefficients(*args)
+        assert np.array_equal(nt, g[f"{tag}_n_theta"]), tag
+        assert np.array_equal(ne, g[f"{tag}_n_eta"]), tag
+        assert np.array_equal(npr, g[f"{tag}_n_pr"]), tag
+    assert np.array_equal(orc.normalize_with_self(g["zero_n_pr"]), g["zero_pr_norm"])
+    assert np.all(g["zero_pr_norm"][1] == 0)  # the zero-row guard really fired
+    for tag in ("tiny", "mix"):
+        args = (g[f"{tag}_data"], g[f"{tag}_theta"], g[f"{tag}_eta"], g[f"{tag}_pr"])
+        assert orc.compute_likelihood(*args) == g[f"{tag}_likelihood"]
+    assert np.array_equal(orc.prod_dist(g["dup_data"], g["dup_theta"], g["dup_eta"], g["dup_pr"]),
+                          g["dup_prod_dist"])
+
+
+@pytest.mark.slow
+def test_g5_c2_sampled_entries():
+    g = load_golden("g5_c2_sampled")
+    train = orc.synthetic_triples(int(g["n"]), int(g["u"]), int(g["i"]), int(g["r"]), int(g["gen_seed"]))
+    assert np.array_equal(train[:64], g["train_head"]) and np.array_equal(train.sum(0), g["train_sum"])
+    out = orc.run_one_sampling(train, orc.child_seeds(int(g["model_seed"]), 1)[0], 10, 10, 10,
+                               snapshots=(1, 10))
+    for it in (1, 10):
+        t, e, p = out["snapshots"][it]
+        assert rel_err(t[g["ut"], g["kt"]], g[f"theta_s_{it}"]) < 1e-13
+        assert rel_err(e[g["ie"], g["le"]], g[f"eta_s_{it}"]) < 1e-13
+        assert rel_err(p, g[f"pr_{it}"]) < 1e-13
