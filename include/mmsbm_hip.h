@@ -1,0 +1,143 @@
+/*
+ * mmsbm_hip.h -- C ABI of the MI355X-native (gfx950) EM core for the Mixed-Membership
+ * Stochastic Block Model.
+ *
+ * This is the drop-in boundary for the hot path of eudald-seeslab/mmsbm (paths below
+ * are relative to the reference checkout):
+ *
+ *   src/backend.py:16-22              load_backend(name) -> (compute_omegas,
+ *                                     update_coefficients, prod_dist, name)
+ *   src/kernels_numpy.py:21-36        compute_omegas(data, theta, eta, pr)
+ *   src/kernels_numpy.py:43-79        update_coefficients(data, theta, eta, pr)
+ *   src/kernels_numpy.py:86-96        prod_dist(data, theta, eta, pr)
+ *   src/expectation_maximization.py:118-120,152-155,157-167
+ *                                     normalize_with_d / normalize_with_self / compute_likelihood
+ *   src/mmsbm.py:243-256              the per-restart EM loop
+ *
+ * The reference has no native layer; a Python module `kernels_hip` binds these entry
+ * points with ctypes.  Conventions:
+ *
+ *   - plain C types only; every host buffer is owned by the caller, C-contiguous,
+ *     float64 / int32, and is never retained after the call returns;
+ *   - host-side parameter layouts are the reference's: theta (U,K), eta (I,L),
+ *     pr (K,L,R), row-major;
+ *   - every function returns 0 on success or an MMSBM_E_* code; the message for the
+ *     calling thread's last failure is mmsbm_hip_last_error();
+ *   - a context is bound to one device and one stream and must be driven by one host
+ *     thread at a time; distinct contexts (e.g. one per GPU) are independent;
+ *   - there is no CPU fallback: without a usable HIP device every call fails.
+ */
+#ifndef MMSBM_HIP_H
+#define MMSBM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMSBM_HIP_ABI_VERSION 1
+
+enum {
+  MMSBM_OK = 0,
+  MMSBM_E_INVALID = 1,     /* bad argument (null pointer, index out of range, size) */
+  MMSBM_E_HIP = 2,         /* a HIP runtime call failed                              */
+  MMSBM_E_NODEVICE = 3,    /* no usable gfx950 device                                */
+  MMSBM_E_UNSUPPORTED = 4, /* shape outside what the kernels are instantiated for    */
+  MMSBM_E_TOOLARGE = 5,    /* output would exceed the caller's capacity / byte cap   */
+  MMSBM_E_INTERNAL = 6
+};
+
+typedef struct mmsbm_hip_ctx mmsbm_hip_ctx;
+
+/* ---- library / device ---------------------------------------------------------- */
+int mmsbm_hip_abi_version(void);
+const char *mmsbm_hip_last_error(void);
+int mmsbm_hip_device_count(int *count);
+/* name: caller buffer of name_len bytes; arch e.g. "gfx950:sramecc+:xnack-". */
+int mmsbm_hip_device_info(int device, char *name, int name_len, int *compute_units,
+                          int64_t *global_mem_bytes);
+
+/* ---- context = (device, encoded training triples) -------------------------------- */
+/* Replaces the per-call re-gathering of `data` in src/kernels_numpy.py:26-28 and the
+ * degree pre-computation of src/mmsbm.py:100-111.  user/item/rating: n_obs int32 ids in
+ * [0,U) / [0,I) / [0,R).  Uploads, sorts (rating,item)-major and user-major, builds the
+ * CSR offsets and degrees once.  swap_sides != 0 lets the library pair ratings with the
+ * users instead of the items when that is the smaller table (results are identical up
+ * to summation order); pass 0 for the default, -1 for "choose automatically". */
+int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items,
+                     int32_t n_ratings, int32_t k_groups, int32_t l_groups,
+                     const int32_t *user, const int32_t *item, const int32_t *rating,
+                     int swap_sides, mmsbm_hip_ctx **out);
+int mmsbm_hip_destroy(mmsbm_hip_ctx *ctx);
+/* dims[0..7] = n_obs, U, I, R, K, L, n_pairs (distinct (item,rating) pairs), swapped */
+int mmsbm_hip_dims(const mmsbm_hip_ctx *ctx, int64_t dims[8]);
+/* d_u (U) and d_i (I): rows per user / item, floored at 1 (src/mmsbm.py:106-111). */
+int mmsbm_hip_degrees(const mmsbm_hip_ctx *ctx, int64_t *d_user, int64_t *d_item);
+
+/* ---- parameters (device resident between calls) ---------------------------------- */
+int mmsbm_hip_set_params(mmsbm_hip_ctx *ctx, const double *theta, const double *eta,
+                         const double *pr);
+int mmsbm_hip_get_params(mmsbm_hip_ctx *ctx, double *theta, double *eta, double *pr);
+
+/* ---- the hot loop: src/mmsbm.py:243-250 ------------------------------------------- */
+/* n_iters x { update_coefficients; theta = n_theta/d_u; eta = n_eta/d_i;
+ * pr = normalize_with_self(n_pr) } entirely on the device; enqueues on the context's
+ * stream and returns without synchronising. */
+int mmsbm_hip_em_iterate(mmsbm_hip_ctx *ctx, int n_iters);
+int mmsbm_hip_synchronize(mmsbm_hip_ctx *ctx);
+
+/* One un-normalised M-step from the current parameters (src/kernels_numpy.py:43-79).
+ * Outputs in host layout; the context's parameters are left unchanged.  Any output
+ * pointer may be NULL. */
+int mmsbm_hip_update_coefficients(mmsbm_hip_ctx *ctx, double *n_theta, double *n_eta,
+                                  double *n_pr);
+
+/* src/expectation_maximization.py:157-167 on the current parameters. */
+int mmsbm_hip_likelihood(mmsbm_hip_ctx *ctx, double *out);
+
+/* src/kernels_numpy.py:21-36: (N,K,L) tensor in the ORIGINAL row order of the triples
+ * given to create().  Contract / test use only: refuses if N*K*L > capacity_elems. */
+int mmsbm_hip_compute_omegas(mmsbm_hip_ctx *ctx, double *out, int64_t capacity_elems);
+
+/* src/kernels_numpy.py:86-96 for n_pairs (user,item) pairs; out is (n_pairs, R). */
+int mmsbm_hip_prod_dist(mmsbm_hip_ctx *ctx, int64_t n_pairs, const int32_t *user,
+                        const int32_t *item, double *out);
+
+/* ---- measurement ------------------------------------------------------------------ */
+/* Runs n_iters EM iterations bracketed by HIP events on the context's stream; returns
+ * the elapsed device time of the whole region in milliseconds (synchronises). */
+int mmsbm_hip_time_iterations(mmsbm_hip_ctx *ctx, int n_iters, float *elapsed_ms);
+/* Number of distinct kernels in one EM iteration and their names. */
+int mmsbm_hip_kernel_count(void);
+const char *mmsbm_hip_kernel_name(int index);
+/* Runs n_iters iterations with a HIP event pair around EVERY kernel launch (on the
+ * context's stream) and returns the mean duration per launch, in microseconds, for each
+ * of the mmsbm_hip_kernel_count() kernels, plus launches per iteration. */
+int mmsbm_hip_profile_iterations(mmsbm_hip_ctx *ctx, int n_iters, float *mean_us,
+                                 int *launches_per_iter);
+/* Algorithmic bytes (read, written) of kernel `index` for this context's shapes; the
+ * accounting is stated in DESIGN.md. */
+int mmsbm_hip_kernel_bytes(const mmsbm_hip_ctx *ctx, int index, int64_t *bytes_read,
+                           int64_t *bytes_written);
+/* 0 = eager launches, 1 = replay a captured hipGraph of two iterations (default). */
+int mmsbm_hip_set_graph_mode(mmsbm_hip_ctx *ctx, int enabled);
+
+/* ---- host-only helpers (no device needed) ------------------------------------------- */
+/* The sorted CSR-style layout create() uploads, exposed so it can be checked on a
+ * machine without a GPU.  which: 0 pair_off, 1 pair_user, 2 pair_item, 3 rating_off,
+ * 4 user_off, 5 user_pair, 6 item_off, 7 item_pairs, 8 item_deg, 9 chunk_off,
+ * 10 chunks (rating, q_begin, q_end, 0 per chunk).  Pass out == NULL to query count. */
+typedef struct mmsbm_hip_layout mmsbm_hip_layout;
+int mmsbm_hip_layout_build(int64_t n_obs, int32_t n_users, int32_t n_items,
+                           int32_t n_ratings, const int32_t *user, const int32_t *item,
+                           const int32_t *rating, int32_t target_chunks,
+                           mmsbm_hip_layout **out);
+int mmsbm_hip_layout_array(const mmsbm_hip_layout *layout, int which, int32_t *out,
+                           int64_t capacity, int64_t *count);
+int mmsbm_hip_layout_free(mmsbm_hip_layout *layout);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMSBM_HIP_H */

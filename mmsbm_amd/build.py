@@ -1,0 +1,45 @@
+"""Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(PKG_DIR, "csrc", "mmsbm_hip.hip")
+DEPS = [SRC, os.path.join(PKG_DIR, "csrc", "layout.hpp"),
+        os.path.join(os.path.dirname(PKG_DIR), "include", "mmsbm_hip.h")]
+LIB = os.path.join(PKG_DIR, "libmmsbm_hip.so")
+ARCH = "gfx950"
+
+
+def hipcc_path() -> str:
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (set HIPCC or install ROCm under /opt/rocm)")
+
+
+def is_stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    built = os.path.getmtime(LIB)
+    return any(os.path.getmtime(d) > built for d in DEPS)
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 -shared -> mmsbm_amd/libmmsbm_hip.so; returns its path."""
+    if not force and not is_stale():
+        return LIB
+    cmd = [hipcc_path(), "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-shared",
+           "-Wall", "-Wno-unused-function", "-Wl,-rpath,/opt/rocm/lib", "-o", LIB, SRC]
+    if verbose:
+        print(" ".join(cmd))
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_library(force=True, verbose=True))

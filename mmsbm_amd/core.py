@@ -1,0 +1,184 @@
+"""Thin Python handle over the resident C-ABI context (include/mmsbm_hip.h, "level 2").
+
+One ``HipEM`` = one GPU + one encoded training set.  Parameters stay on the device
+between calls; the EM loop of src/mmsbm.py:243-250 runs there without host round trips.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _p(a, ctype):
+    return a.ctypes.data_as(C.POINTER(ctype))
+
+
+def split_triples(data):
+    """(N,3) integer array (any int dtype, any strides) -> three contiguous int32 columns."""
+    d = np.asarray(data)
+    if d.ndim != 2 or d.shape[1] < 3:
+        raise ValueError("data must have shape (N, 3): [user_idx, item_idx, rating_idx]")
+    if d.shape[0] and not np.issubdtype(d.dtype, np.integer):
+        raise TypeError("data must hold integer ids")
+    if d.size and (d.min() < 0 or d.max() >= 2**31):
+        raise ValueError("ids must be in [0, 2^31)")
+    return _i32(d[:, 0]), _i32(d[:, 1]), _i32(d[:, 2])
+
+
+class HipEM:
+    """Device-resident EM state for one (GPU, training set, K, L)."""
+
+    def __init__(self, data, k_groups, l_groups, n_users=None, n_items=None, n_ratings=None,
+                 device=0, swap_sides=-1):
+        u, i, r = split_triples(data)
+        n = len(u)
+        self.n_obs = n
+        self.n_users = int(n_users) if n_users is not None else (int(u.max()) + 1 if n else 1)
+        self.n_items = int(n_items) if n_items is not None else (int(i.max()) + 1 if n else 1)
+        self.n_ratings = int(n_ratings) if n_ratings is not None else (int(r.max()) + 1 if n else 1)
+        self.k, self.l = int(k_groups), int(l_groups)
+        self.device = int(device)
+        self._h = C.c_void_p()
+        _lib.call("mmsbm_hip_create", self.device, n, self.n_users, self.n_items, self.n_ratings,
+                  self.k, self.l, _p(u, C.c_int32), _p(i, C.c_int32), _p(r, C.c_int32),
+                  int(swap_sides), C.byref(self._h))
+        dims = (C.c_int64 * 8)()
+        _lib.call("mmsbm_hip_dims", self._h, dims)
+        self.n_pairs, self.swapped = int(dims[6]), bool(dims[7])
+
+    # -- lifetime ------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            _lib.call("mmsbm_hip_destroy", self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- parameters ----------------------------------------------------------------------
+    def _shapes(self):
+        return ((self.n_users, self.k), (self.n_items, self.l), (self.k, self.l, self.n_ratings))
+
+    def set_params(self, theta, eta, pr):
+        theta, eta, pr = _f64(theta), _f64(eta), _f64(pr)
+        for arr, shp, nm in zip((theta, eta, pr), self._shapes(), ("theta", "eta", "pr")):
+            if arr.shape != shp:
+                raise ValueError(f"{nm} has shape {arr.shape}, expected {shp}")
+        _lib.call("mmsbm_hip_set_params", self._h, _p(theta, C.c_double), _p(eta, C.c_double),
+                  _p(pr, C.c_double))
+
+    def get_params(self):
+        theta, eta, pr = (np.empty(s, dtype=np.float64) for s in self._shapes())
+        _lib.call("mmsbm_hip_get_params", self._h, _p(theta, C.c_double), _p(eta, C.c_double),
+                  _p(pr, C.c_double))
+        return theta, eta, pr
+
+    def degrees(self):
+        d_u = np.empty(self.n_users, dtype=np.int64)
+        d_i = np.empty(self.n_items, dtype=np.int64)
+        _lib.call("mmsbm_hip_degrees", self._h, _p(d_u, C.c_int64), _p(d_i, C.c_int64))
+        return d_u, d_i
+
+    # -- the hot path ----------------------------------------------------------------------
+    def iterate(self, n_iters, sync=True):
+        _lib.call("mmsbm_hip_em_iterate", self._h, int(n_iters))
+        if sync:
+            self.synchronize()
+
+    def synchronize(self):
+        _lib.call("mmsbm_hip_synchronize", self._h)
+
+    def update_coefficients(self):
+        n_theta, n_eta, n_pr = (np.empty(s, dtype=np.float64) for s in self._shapes())
+        _lib.call("mmsbm_hip_update_coefficients", self._h, _p(n_theta, C.c_double),
+                  _p(n_eta, C.c_double), _p(n_pr, C.c_double))
+        return n_theta, n_eta, n_pr
+
+    def likelihood(self):
+        out = C.c_double(0.0)
+        _lib.call("mmsbm_hip_likelihood", self._h, C.byref(out))
+        return np.float64(out.value)
+
+    def compute_omegas(self):
+        out = np.empty((self.n_obs, self.k, self.l), dtype=np.float64)
+        _lib.call("mmsbm_hip_compute_omegas", self._h, _p(out, C.c_double), out.size)
+        return out
+
+    def prod_dist(self, pairs):
+        d = np.asarray(pairs)
+        if d.ndim != 2 or d.shape[1] < 2:
+            raise ValueError("pairs must have shape (M, >=2): [user_idx, item_idx, ...]")
+        u, i = _i32(d[:, 0]), _i32(d[:, 1])
+        out = np.empty((len(u), self.n_ratings), dtype=np.float64)
+        _lib.call("mmsbm_hip_prod_dist", self._h, len(u), _p(u, C.c_int32), _p(i, C.c_int32),
+                  _p(out, C.c_double))
+        return out
+
+    # -- measurement -------------------------------------------------------------------------
+    def time_iterations(self, n_iters):
+        """Device milliseconds for n_iters EM iterations (HIP events on the context stream)."""
+        ms = C.c_float(0.0)
+        _lib.call("mmsbm_hip_time_iterations", self._h, int(n_iters), C.byref(ms))
+        return float(ms.value)
+
+    def profile_iterations(self, n_iters):
+        """{kernel name: (mean microseconds per launch, launches per iteration, bytes read,
+        bytes written)} from a HIP event pair around every launch."""
+        lib = _lib.load()
+        nk = lib.mmsbm_hip_kernel_count()
+        us = (C.c_float * nk)()
+        cnt = (C.c_int * nk)()
+        _lib.call("mmsbm_hip_profile_iterations", self._h, int(n_iters), us, cnt)
+        out = {}
+        for j in range(nk):
+            rd, wr = C.c_int64(0), C.c_int64(0)
+            _lib.call("mmsbm_hip_kernel_bytes", self._h, j, C.byref(rd), C.byref(wr))
+            out[lib.mmsbm_hip_kernel_name(j).decode()] = (float(us[j]), int(cnt[j]),
+                                                         int(rd.value), int(wr.value))
+        return out
+
+    def set_graph_mode(self, enabled):
+        _lib.call("mmsbm_hip_set_graph_mode", self._h, int(bool(enabled)))
+
+
+def build_layout(data, n_users, n_items, n_ratings, target_chunks=1024):
+    """Host-only: the sorted CSR layout the library uploads (dict of int32 arrays)."""
+    u, i, r = split_triples(data)
+    h = C.c_void_p()
+    _lib.call("mmsbm_hip_layout_build", len(u), int(n_users), int(n_items), int(n_ratings),
+              _p(u, C.c_int32), _p(i, C.c_int32), _p(r, C.c_int32), int(target_chunks), C.byref(h))
+    names = ["pair_off", "pair_user", "pair_item", "rating_off", "user_off", "user_pair",
+             "item_off", "item_pairs", "item_deg", "chunk_off", "chunks"]
+    out = {}
+    try:
+        for which, nm in enumerate(names):
+            cnt = C.c_int64(0)
+            _lib.call("mmsbm_hip_layout_array", h, which, None, 0, C.byref(cnt))
+            arr = np.empty(cnt.value, dtype=np.int32)
+            if cnt.value:
+                _lib.call("mmsbm_hip_layout_array", h, which, _p(arr, C.c_int32), arr.size,
+                          C.byref(cnt))
+            out[nm] = arr.reshape(-1, 4) if nm == "chunks" else arr
+    finally:
+        _lib.call("mmsbm_hip_layout_free", h)
+    return out

@@ -1,0 +1,133 @@
+// layout.hpp -- host-side construction of the device data layout for the MMSBM EM core.
+//
+// The reference re-gathers `data[:,0..2]` on every call (src/kernels_numpy.py:26-28) and
+// pre-computes degrees with O(U*N) scans (src/mmsbm.py:100-111).  Here the triples are
+// sorted ONCE into two CSR-style orders:
+//
+//   pair order : triples sorted by (rating, item, user).  A "pair" is a distinct
+//                (item, rating) combination; pairs are numbered rating-major so that any
+//                contiguous run of pairs inside one rating shares one K x L tile p[:,:,r].
+//   user order : triples sorted by (user, pair).
+//
+// plus a CSR of pairs per item and a table of rating-homogeneous pair chunks.
+// Pure host code (no HIP): usable and testable without a GPU.
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace mmsbm {
+
+struct Chunk {  // one workgroup's share of the pairs of ONE rating
+  int32_t rating, q_begin, q_end, pad;
+};
+
+struct Layout {
+  int64_t n_obs = 0;
+  int32_t n_users = 0, n_items = 0, n_ratings = 0, n_pairs = 0;
+  // pair order
+  std::vector<int32_t> pair_off;     // n_pairs+1 : triple range of each pair
+  std::vector<int32_t> pair_user;    // n_obs     : user of each triple (pair order)
+  std::vector<int32_t> pair_item;    // n_pairs   : item of each pair
+  std::vector<int32_t> rating_off;   // n_ratings+1 : pair range of each rating
+  // user order
+  std::vector<int32_t> user_off;     // n_users+1
+  std::vector<int32_t> user_pair;    // n_obs : pair id of each triple (user order)
+  // pairs of each item (ascending rating)
+  std::vector<int32_t> item_off;     // n_items+1
+  std::vector<int32_t> item_pairs;   // n_pairs
+  std::vector<int32_t> item_deg;     // n_items : triples per item (NOT floored)
+  // rating-homogeneous chunks of pairs
+  std::vector<Chunk> chunks;
+  std::vector<int32_t> chunk_off;    // n_ratings+1 : chunk range of each rating
+  int32_t chunk_pairs = 0;           // max pairs per chunk
+};
+
+inline void build_layout(int64_t n_obs, int32_t n_users, int32_t n_items, int32_t n_ratings,
+                         const int32_t *user, const int32_t *item, const int32_t *rating,
+                         int32_t target_chunks, Layout &out) {
+  if (n_obs < 0 || n_obs >= (int64_t(1) << 31) - 64)
+    throw std::invalid_argument("n_obs must be in [0, 2^31)");
+  if (n_users <= 0 || n_items <= 0 || n_ratings <= 0)
+    throw std::invalid_argument("n_users, n_items and n_ratings must be positive");
+  if (n_obs > 0 && (!user || !item || !rating))
+    throw std::invalid_argument("null triple array");
+  for (int64_t n = 0; n < n_obs; ++n) {
+    if (user[n] < 0 || user[n] >= n_users || item[n] < 0 || item[n] >= n_items ||
+        rating[n] < 0 || rating[n] >= n_ratings)
+      throw std::invalid_argument("triple " + std::to_string(n) + " has an id out of range");
+  }
+  Layout &L = out;
+  L = Layout();
+  L.n_obs = n_obs; L.n_users = n_users; L.n_items = n_items; L.n_ratings = n_ratings;
+
+  // ---- sort by (rating, item, user) -------------------------------------------------
+  struct Key { uint64_t pk; uint32_t u; };
+  std::vector<Key> keys(static_cast<size_t>(n_obs));
+  for (int64_t n = 0; n < n_obs; ++n)
+    keys[n] = Key{uint64_t(rating[n]) * uint64_t(n_items) + uint64_t(item[n]), uint32_t(user[n])};
+  std::sort(keys.begin(), keys.end(), [](const Key &a, const Key &b) {
+    return a.pk != b.pk ? a.pk < b.pk : a.u < b.u;
+  });
+
+  L.pair_user.resize(n_obs);
+  L.pair_off.clear(); L.pair_item.clear();
+  L.rating_off.assign(size_t(n_ratings) + 1, 0);
+  std::vector<int32_t> triple_pair(static_cast<size_t>(n_obs));  // pair id per sorted triple
+  std::vector<int32_t> pairs_per_rating(n_ratings, 0);
+  uint64_t prev = ~uint64_t(0);
+  for (int64_t n = 0; n < n_obs; ++n) {
+    if (keys[n].pk != prev) {
+      prev = keys[n].pk;
+      L.pair_off.push_back(int32_t(n));
+      L.pair_item.push_back(int32_t(prev % uint64_t(n_items)));
+      pairs_per_rating[size_t(prev / uint64_t(n_items))]++;
+    }
+    triple_pair[n] = int32_t(L.pair_off.size()) - 1;
+    L.pair_user[n] = int32_t(keys[n].u);
+  }
+  L.n_pairs = int32_t(L.pair_off.size());
+  L.pair_off.push_back(int32_t(n_obs));
+  for (int r = 0; r < n_ratings; ++r) L.rating_off[r + 1] = L.rating_off[r] + pairs_per_rating[r];
+
+  // ---- user order: stable counting sort of the pair-ordered triples by user ---------
+  L.user_off.assign(size_t(n_users) + 1, 0);
+  for (int64_t n = 0; n < n_obs; ++n) L.user_off[size_t(L.pair_user[n]) + 1]++;
+  for (int u = 0; u < n_users; ++u) L.user_off[u + 1] += L.user_off[u];
+  L.user_pair.resize(n_obs);
+  {
+    std::vector<int32_t> cur(L.user_off.begin(), L.user_off.end() - 1);
+    for (int64_t n = 0; n < n_obs; ++n) L.user_pair[cur[L.pair_user[n]]++] = triple_pair[n];
+  }
+
+  // ---- pairs of each item + item degrees ----------------------------------------------
+  L.item_off.assign(size_t(n_items) + 1, 0);
+  L.item_deg.assign(n_items, 0);
+  for (int q = 0; q < L.n_pairs; ++q) {
+    L.item_off[size_t(L.pair_item[q]) + 1]++;
+    L.item_deg[L.pair_item[q]] += L.pair_off[q + 1] - L.pair_off[q];
+  }
+  for (int i = 0; i < n_items; ++i) L.item_off[i + 1] += L.item_off[i];
+  L.item_pairs.resize(L.n_pairs);
+  {
+    std::vector<int32_t> cur(L.item_off.begin(), L.item_off.end() - 1);
+    for (int q = 0; q < L.n_pairs; ++q) L.item_pairs[cur[L.pair_item[q]]++] = q;
+  }
+
+  // ---- rating-homogeneous chunks --------------------------------------------------------
+  if (target_chunks < 1) target_chunks = 1;
+  int32_t cp = int32_t((int64_t(L.n_pairs) + target_chunks - 1) / target_chunks);
+  cp = std::max<int32_t>(cp, 64);
+  cp = (cp + 15) / 16 * 16;
+  L.chunk_pairs = cp;
+  L.chunk_off.assign(size_t(n_ratings) + 1, 0);
+  for (int r = 0; r < n_ratings; ++r) {
+    for (int32_t q = L.rating_off[r]; q < L.rating_off[r + 1]; q += cp)
+      L.chunks.push_back(Chunk{r, q, std::min<int32_t>(q + cp, L.rating_off[r + 1]), 0});
+    L.chunk_off[r + 1] = int32_t(L.chunks.size());
+  }
+}
+
+}  // namespace mmsbm

@@ -1,0 +1,1254 @@
+// mmsbm_hip.hip -- MI355X (gfx950 / CDNA4) EM core for the Mixed-Membership Stochastic
+// Block Model, behind the C ABI of include/mmsbm_hip.h.
+//
+// What the reference computes per EM iteration (src/kernels_numpy.py:43-79 followed by
+// src/mmsbm.py:248-250), for every observed triple n = (u, i, r):
+//
+//   omega[n,k,l] = theta[u,k] eta[i,l] p[k,l,r]        s_n = sum_kl omega[n,k,l]
+//   n_theta[u,k] = sum_{n: u_n=u} sum_l omega/max(s_n,eps)      (and the same for eta, p)
+//
+// materialising the (N,K,L) tensor several times.  This file never builds omega.  With
+// a "pair" q = a distinct (item, rating) combination and
+//
+//   A[q,k]   = sum_l p[k,l,r_q] eta[i_q,l]                       (pair_matvec, K-side)
+//   w_n      = 1 / max(theta[u_n,:] . A[q_n,:], eps)
+//   n_theta[u,k] = theta[u,k] * sum_{n in user u} A[q_n,k] w_n   (seg_pass, user segments)
+//   C[q,k]   = sum_{n in pair q} theta[u_n,k] w_n                (seg_pass, pair segments)
+//   T[q,l]   = sum_k p[k,l,r_q] C[q,k]                           (pair_matvec, L-side)
+//   n_eta[i,l] = eta[i,l] * sum_{q in item i} T[q,l]             (item_sum)
+//   n_p[k,l,r] = p[k,l,r] * sum_{q: r_q=r} C[q,k] eta[i_q,l]     (p_partial + p_finalize)
+//
+// which is the same sum re-associated: O(N K + Q K L) flops instead of O(N K L), two
+// row-gather passes over the triples (sorted user-major and (rating,item)-major), every
+// reduction a segmented reduction in registers (no atomics: results are bitwise
+// reproducible), all arithmetic float64 on the vector ALU (no MFMA).
+//
+// Written for gfx950 only: 64-wide wavefronts, DPP cross-lane reductions, LDS-staged
+// rating tiles.
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/mmsbm_hip.h"
+#include "layout.hpp"
+
+namespace {
+
+// ======================================================================================
+// errors
+// ======================================================================================
+thread_local std::string g_last_error;
+
+struct ApiError : std::runtime_error {
+  int code;
+  ApiError(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+
+#define HIP_CHECK(expr)                                                                 \
+  do {                                                                                  \
+    hipError_t e_ = (expr);                                                             \
+    if (e_ != hipSuccess)                                                               \
+      throw ApiError(MMSBM_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));   \
+  } while (0)
+
+template <class F>
+int guarded(F &&f) {
+  try {
+    f();
+    return MMSBM_OK;
+  } catch (const ApiError &e) {
+    g_last_error = e.what();
+    return e.code;
+  } catch (const std::invalid_argument &e) {
+    g_last_error = e.what();
+    return MMSBM_E_INVALID;
+  } catch (const std::bad_alloc &) {
+    g_last_error = "host allocation failed";
+    return MMSBM_E_INTERNAL;
+  } catch (const std::exception &e) {
+    g_last_error = e.what();
+    return MMSBM_E_INTERNAL;
+  }
+}
+
+constexpr double kEps = 2.220446049250313e-16;  // np.finfo(float).eps, src/kernels_numpy.py:51
+constexpr int kBlock = 256;
+
+// ======================================================================================
+// device helpers
+// ======================================================================================
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+
+// Sum over the G consecutive lanes of a group (G a power of two, groups aligned to G).
+// Every step adds a value to its mirror image, so all lanes of a group end with the
+// bitwise-identical sum.  Up to 16 lanes stay inside one DPP row (no LDS traffic).
+template <int G>
+__device__ __forceinline__ double group_sum(double x) {
+  if (G >= 2) x += dpp_move<0xB1>(x);    // quad_perm [1,0,3,2]
+  if (G >= 4) x += dpp_move<0x4E>(x);    // quad_perm [2,3,0,1]
+  if (G >= 8) x += dpp_move<0x141>(x);   // row_half_mirror
+  if (G >= 16) x += dpp_move<0x140>(x);  // row_mirror
+  if (G >= 32) x += __shfl_xor(x, 16, 64);
+  if (G >= 64) x += __shfl_xor(x, 32, 64);
+  return x;
+}
+
+template <int VEC>
+__device__ __forceinline__ void load_vec(const double *__restrict__ p, double (&v)[VEC]) {
+#pragma unroll
+  for (int j = 0; j < VEC; j += 2) {
+    const double2 t = *reinterpret_cast<const double2 *>(p + j);
+    v[j] = t.x;
+    v[j + 1] = t.y;
+  }
+}
+
+template <int VEC>
+__device__ __forceinline__ void store_vec(double *__restrict__ p, const double (&v)[VEC]) {
+#pragma unroll
+  for (int j = 0; j < VEC; j += 2) {
+    double2 t;
+    t.x = v[j];
+    t.y = v[j + 1];
+    *reinterpret_cast<double2 *>(p + j) = t;
+  }
+}
+
+// ======================================================================================
+// kernel 0: seg_pass -- the two triple passes (user segments and pair segments), fused
+// into one launch.  One group of G lanes per segment; lane gl owns VEC consecutive
+// entries of the K-vector.
+//
+//   acc[:] = sum_{n in segment} gath[idx[n], :] / max(fixed[seg, :] . gath[idx[n], :], eps)
+//
+//   user segments: fixed = theta, gath = A, out = theta * acc / d_u   (src/mmsbm.py:248)
+//   pair segments: fixed = A,     gath = theta, out = C = acc
+// ======================================================================================
+struct SegArgs {
+  const double *fixed;
+  const double *gath;
+  const int32_t *off;
+  const int32_t *idx;
+  double *out;
+  int32_t nseg;
+  int32_t mode;  // 0: out = acc   1: out = fixed*acc/max(len,1)   2: out = fixed*acc
+};
+
+template <int G, int VEC, int B>
+__global__ __launch_bounds__(kBlock) void seg_pass_kernel(SegArgs sa, SegArgs sb,
+                                                          int blocks_a, int dp) {
+  const bool first = static_cast<int>(blockIdx.x) < blocks_a;
+  const SegArgs a = first ? sa : sb;
+  const int blk = first ? blockIdx.x : blockIdx.x - blocks_a;
+  const int seg = blk * (kBlock / G) + threadIdx.x / G;
+  const int gl = threadIdx.x % G;
+  if (seg >= a.nseg) return;  // whole groups leave together
+  const bool act = gl * VEC < dp;
+  const int lane_off = act ? gl * VEC : 0;
+
+  double f[VEC], acc[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) acc[v] = 0.0;
+  load_vec<VEC>(a.fixed + static_cast<size_t>(seg) * dp + lane_off, f);
+  if (!act) {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) f[v] = 0.0;
+  }
+
+  const int beg = a.off[seg], end = a.off[seg + 1];
+  for (int n = beg; n < end; n += B) {
+    int id[B];
+#pragma unroll
+    for (int b = 0; b < B; ++b) id[b] = a.idx[min(n + b, end - 1)];
+    double g[B][VEC];
+#pragma unroll
+    for (int b = 0; b < B; ++b)
+      load_vec<VEC>(a.gath + static_cast<size_t>(id[b]) * dp + lane_off, g[b]);
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+      if (n + b < end) {
+        double part = 0.0;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) part = fma(g[b][v], f[v], part);
+        const double s = group_sum<G>(part);
+        const double w = 1.0 / fmax(s, kEps);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] = fma(g[b][v], w, acc[v]);
+      }
+    }
+  }
+
+  if (!act) return;
+  double o[VEC];
+  if (a.mode == 0) {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) o[v] = acc[v];
+  } else if (a.mode == 1) {
+    const double d = static_cast<double>(max(end - beg, 1));
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) o[v] = (f[v] * acc[v]) / d;
+  } else {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) o[v] = f[v] * acc[v];
+  }
+  store_vec<VEC>(a.out + static_cast<size_t>(seg) * dp + lane_off, o);
+}
+
+// ======================================================================================
+// kernels 1 and 5: pair_matvec -- out[q, :] = sum_d M_r[d, :] * in[row(q), d] for every
+// pair q of a rating-homogeneous chunk; the Din x Dout tile M_r lives in LDS.
+//   T = P_r^T-contract:  M = p[r] as [K][Lp],  in = C[q, :K],            out = T[q, :Lp]
+//   A = P_r-contract:    M = pT[r] as [L][Kp], in = eta[item(q), :L],    out = A[q, :Kp]
+// One group of G lanes per pair, lanes over the output dimension.
+// ======================================================================================
+template <int G, int VEC>
+__global__ __launch_bounds__(kBlock) void pair_matvec_kernel(
+    const double *__restrict__ tiles, const double *__restrict__ in_tab,
+    const int32_t *__restrict__ gather, const mmsbm::Chunk *__restrict__ chunks,
+    double *__restrict__ out, int din, int dinp, int doutp, int gpb) {
+  extern __shared__ double lds[];  // gpb <= kBlock / G groups work per batch (LDS budget)
+  double *tile = lds;                                   // [dinp][doutp]
+  double *rows = lds + static_cast<size_t>(dinp) * doutp;  // [gpb][dinp]
+  const mmsbm::Chunk ch = chunks[blockIdx.x];
+  const int tile_elems = dinp * doutp;
+  const double *src = tiles + static_cast<size_t>(ch.rating) * tile_elems;
+  for (int t = threadIdx.x * 2; t < tile_elems; t += kBlock * 2)
+    *reinterpret_cast<double2 *>(tile + t) = *reinterpret_cast<const double2 *>(src + t);
+
+  const int grp = threadIdx.x / G, gl = threadIdx.x % G;
+  const bool act = gl * VEC < doutp;
+  const int lane_off = act ? gl * VEC : 0;
+  double *myrow = rows + static_cast<size_t>(min(grp, gpb - 1)) * dinp;
+
+  for (int q0 = ch.q_begin; q0 < ch.q_end; q0 += gpb) {
+    const int q = q0 + grp;
+    const bool have = grp < gpb && q < ch.q_end;
+    __syncthreads();  // tile staged (first trip) / previous rows consumed
+    if (have) {
+      const size_t r = gather ? static_cast<size_t>(gather[q]) : static_cast<size_t>(q);
+      for (int d = gl * 2; d < dinp; d += G * 2)
+        *reinterpret_cast<double2 *>(myrow + d) =
+            *reinterpret_cast<const double2 *>(in_tab + r * dinp + d);
+    }
+    __syncthreads();
+    if (have) {
+      double acc[VEC];
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) acc[v] = 0.0;
+      for (int d = 0; d < din; ++d) {
+        const double x = myrow[d];
+        double m[VEC];
+        load_vec<VEC>(tile + static_cast<size_t>(d) * doutp + lane_off, m);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] = fma(m[v], x, acc[v]);
+      }
+      if (act) store_vec<VEC>(out + static_cast<size_t>(q) * doutp + lane_off, acc);
+    }
+  }
+}
+
+// ======================================================================================
+// kernel 2: p_partial -- per chunk of pairs of one rating, the K x L partial sum
+//   S[k,l] = sum_{q in chunk} C[q,k] * eta[item(q), l]
+// C rows and gathered eta rows are staged in LDS in batches; each thread owns NACC
+// (k, l-pair) accumulators in registers.  One slab per chunk, combined by p_finalize in
+// a fixed order (deterministic, no atomics).
+// ======================================================================================
+constexpr int kPBatchMax = 32;
+
+template <int NACC>
+__global__ __launch_bounds__(kBlock) void p_partial_kernel(
+    const double *__restrict__ ctab, const double *__restrict__ eta,
+    const int32_t *__restrict__ pair_item, const mmsbm::Chunk *__restrict__ chunks,
+    double *__restrict__ partial, int kp, int lp, int batch) {
+  extern __shared__ double lds[];
+  double *cs = lds;                                   // [batch][kp]
+  double *es = lds + static_cast<size_t>(batch) * kp;  // [batch][lp]
+  const mmsbm::Chunk ch = chunks[blockIdx.x];
+  const int lh = lp / 2, nout = kp * lh;
+  int coff[NACC], eoff[NACC];
+  double2 acc[NACC];
+#pragma unroll
+  for (int a = 0; a < NACC; ++a) {
+    const int o = min(static_cast<int>(threadIdx.x) + a * kBlock, nout - 1);
+    coff[a] = o / lh;
+    eoff[a] = (o % lh) * 2;
+    acc[a].x = 0.0;
+    acc[a].y = 0.0;
+  }
+  for (int q0 = ch.q_begin; q0 < ch.q_end; q0 += batch) {
+    const int nb = min(batch, ch.q_end - q0);
+    __syncthreads();
+    for (int t = threadIdx.x * 2; t < nb * kp; t += kBlock * 2)
+      *reinterpret_cast<double2 *>(cs + t) =
+          *reinterpret_cast<const double2 *>(ctab + static_cast<size_t>(q0) * kp + t);
+    for (int t = threadIdx.x * 2; t < nb * lp; t += kBlock * 2) {
+      const int j = t / lp, l = t % lp;
+      *reinterpret_cast<double2 *>(es + t) = *reinterpret_cast<const double2 *>(
+          eta + static_cast<size_t>(pair_item[q0 + j]) * lp + l);
+    }
+    __syncthreads();
+    for (int j = 0; j < nb; ++j) {
+#pragma unroll
+      for (int a = 0; a < NACC; ++a) {
+        const double c = cs[j * kp + coff[a]];
+        const double2 e = *reinterpret_cast<const double2 *>(es + j * lp + eoff[a]);
+        acc[a].x = fma(c, e.x, acc[a].x);
+        acc[a].y = fma(c, e.y, acc[a].y);
+      }
+    }
+  }
+  double *dst = partial + static_cast<size_t>(blockIdx.x) * kp * lp;
+#pragma unroll
+  for (int a = 0; a < NACC; ++a) {
+    const int o = static_cast<int>(threadIdx.x) + a * kBlock;
+    if (o < nout) *reinterpret_cast<double2 *>(dst + coff[a] * lp + eoff[a]) = acc[a];
+  }
+}
+
+// ======================================================================================
+// kernel 4: p_finalize -- n_p[r][k][l] = p[r][k][l] * sum_{chunks of r} S_chunk[k][l], then
+// normalize_with_self over r (src/expectation_maximization.py:152-155, zero rows kept).
+// Block = 64 (k,l) columns x 16 chunk-rows.  Writes p_new both as [R][Kp][Lp] and
+// transposed [R][Lp][Kp] (the tile shape pair_matvec wants for A).
+// ======================================================================================
+constexpr int kFinCols = 64, kFinRows = 16;
+
+__global__ __launch_bounds__(kFinCols *kFinRows) void p_finalize_kernel(
+    const double *__restrict__ partial, const int32_t *__restrict__ chunk_off,
+    const double *__restrict__ p_old, double *__restrict__ p_new, double *__restrict__ pt_new,
+    double *__restrict__ n_p_out, int n_ratings, int kp, int lp, int normalize) {
+  extern __shared__ double lds[];
+  double *red = lds;                          // [kFinRows][kFinCols]
+  double *npr = lds + kFinRows * kFinCols;    // [n_ratings][kFinCols]
+  const int tx = threadIdx.x % kFinCols, ty = threadIdx.x / kFinCols;
+  const int kl = kp * lp;
+  const int col = blockIdx.x * kFinCols + tx;
+  const bool ok = col < kl;
+  for (int r = 0; r < n_ratings; ++r) {
+    double s = 0.0;
+    if (ok)
+      for (int c = chunk_off[r] + ty; c < chunk_off[r + 1]; c += kFinRows)
+        s += partial[static_cast<size_t>(c) * kl + col];
+    red[ty * kFinCols + tx] = s;
+    __syncthreads();
+    if (ty == 0) {
+      double tot = red[tx];
+      for (int j = 1; j < kFinRows; ++j) tot += red[j * kFinCols + tx];
+      npr[r * kFinCols + tx] = ok ? p_old[static_cast<size_t>(r) * kl + col] * tot : 0.0;
+    }
+    __syncthreads();
+  }
+  if (ty == 0 && ok) {
+    double tot = 0.0;
+    for (int r = 0; r < n_ratings; ++r) tot += npr[r * kFinCols + tx];
+    const double den = (tot == 0.0) ? 1.0 : tot;
+    const int k = col / lp, l = col % lp;
+    for (int r = 0; r < n_ratings; ++r) {
+      const double raw = npr[r * kFinCols + tx];
+      if (n_p_out) n_p_out[static_cast<size_t>(r) * kl + col] = raw;
+      const double v = normalize ? raw / den : raw;
+      p_new[static_cast<size_t>(r) * kl + col] = v;
+      pt_new[static_cast<size_t>(r) * kl + static_cast<size_t>(l) * kp + k] = v;
+    }
+  }
+}
+
+// ======================================================================================
+// kernel 3: item_sum -- eta_new[i,:] = eta[i,:] * sum_{q in item i} T[q,:] / d_i
+// (src/mmsbm.py:249).  One group of G lanes per item.
+// ======================================================================================
+template <int G, int VEC>
+__global__ __launch_bounds__(kBlock) void item_sum_kernel(
+    const double *__restrict__ ttab, const int32_t *__restrict__ item_off,
+    const int32_t *__restrict__ item_pairs, const int32_t *__restrict__ item_deg,
+    const double *__restrict__ eta, double *__restrict__ eta_new, int n_items, int lp,
+    int normalize) {
+  const int it = blockIdx.x * (kBlock / G) + threadIdx.x / G;
+  const int gl = threadIdx.x % G;
+  if (it >= n_items || gl * VEC >= lp) return;
+  const int lane_off = gl * VEC;
+  double acc[VEC], e[VEC], t[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) acc[v] = 0.0;
+  for (int j = item_off[it]; j < item_off[it + 1]; ++j) {
+    load_vec<VEC>(ttab + static_cast<size_t>(item_pairs[j]) * lp + lane_off, t);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v] += t[v];
+  }
+  load_vec<VEC>(eta + static_cast<size_t>(it) * lp + lane_off, e);
+  const double d = static_cast<double>(max(item_deg[it], 1));
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) e[v] = normalize ? (e[v] * acc[v]) / d : e[v] * acc[v];
+  store_vec<VEC>(eta_new + static_cast<size_t>(it) * lp + lane_off, e);
+}
+
+// ======================================================================================
+// once-per-run kernels: likelihood, prod_dist, compute_omegas (element-wise forms that
+// follow the reference's association order)
+// ======================================================================================
+// src/expectation_maximization.py:157-167.  One thread per triple (original order).
+__global__ __launch_bounds__(kBlock) void likelihood_kernel(
+    const int32_t *__restrict__ tu, const int32_t *__restrict__ ti,
+    const int32_t *__restrict__ tr, const double *__restrict__ theta,
+    const double *__restrict__ eta, const double *__restrict__ p, double *__restrict__ block_out,
+    int64_t n_obs, int k_groups, int l_groups, int kp, int lp) {
+  __shared__ double red[kBlock];
+  double total = 0.0;
+  for (int64_t n = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; n < n_obs;
+       n += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const double *th = theta + static_cast<size_t>(tu[n]) * kp;
+    const double *et = eta + static_cast<size_t>(ti[n]) * lp;
+    const double *pr = p + static_cast<size_t>(tr[n]) * kp * lp;
+    double s = 0.0;
+    for (int k = 0; k < k_groups; ++k) {
+      const double tk = th[k];
+      for (int l = 0; l < l_groups; ++l) s += (tk * et[l]) * pr[k * lp + l];
+    }
+    const double ls = log(fmax(s, kEps));
+    double acc = 0.0;
+    for (int k = 0; k < k_groups; ++k) {
+      const double tk = th[k];
+      for (int l = 0; l < l_groups; ++l) {
+        const double w = fmax((tk * et[l]) * pr[k * lp + l], kEps);
+        acc += w * log(w) - w * ls;
+      }
+    }
+    total += acc;
+  }
+  red[threadIdx.x] = total;
+  __syncthreads();
+  for (int h = kBlock / 2; h > 0; h >>= 1) {
+    if (static_cast<int>(threadIdx.x) < h) red[threadIdx.x] += red[threadIdx.x + h];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) block_out[blockIdx.x] = red[0];
+}
+
+// src/kernels_numpy.py:86-96.  One thread per (pair, rating).
+__global__ __launch_bounds__(kBlock) void prod_dist_kernel(
+    const int32_t *__restrict__ pu, const int32_t *__restrict__ pi,
+    const double *__restrict__ theta, const double *__restrict__ eta,
+    const double *__restrict__ p, double *__restrict__ out, int64_t n_pairs, int n_ratings,
+    int k_groups, int l_groups, int kp, int lp) {
+  const int64_t e = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (e >= n_pairs * n_ratings) return;
+  const int64_t m = e / n_ratings;
+  const int r = static_cast<int>(e % n_ratings);
+  const double *th = theta + static_cast<size_t>(pu[m]) * kp;
+  const double *et = eta + static_cast<size_t>(pi[m]) * lp;
+  const double *pr = p + static_cast<size_t>(r) * kp * lp;
+  double acc = 0.0;
+  for (int k = 0; k < k_groups; ++k) {
+    const double tk = th[k];
+    double inner = 0.0;
+    for (int l = 0; l < l_groups; ++l) inner = fma(et[l], pr[k * lp + l], inner);
+    acc = fma(tk, inner, acc);
+  }
+  out[e] = acc;
+}
+
+// src/kernels_numpy.py:21-36.  One thread per element; sk/sl = output strides of the
+// internal (k, l) indices (they differ from (L, 1) when the sides are swapped).
+__global__ __launch_bounds__(kBlock) void omegas_kernel(
+    const int32_t *__restrict__ tu, const int32_t *__restrict__ ti,
+    const int32_t *__restrict__ tr, const double *__restrict__ theta,
+    const double *__restrict__ eta, const double *__restrict__ p, double *__restrict__ out,
+    int64_t n_elems, int k_groups, int l_groups, int kp, int lp, int sk, int sl) {
+  const int64_t e = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (e >= n_elems) return;
+  const int kl = k_groups * l_groups;
+  const int64_t n = e / kl;
+  const int rem = static_cast<int>(e % kl);
+  const int k = rem / l_groups, l = rem % l_groups;
+  const double v = (theta[static_cast<size_t>(tu[n]) * kp + k] *
+                    eta[static_cast<size_t>(ti[n]) * lp + l]) *
+                   p[static_cast<size_t>(tr[n]) * kp * lp + k * lp + l];
+  out[n * kl + static_cast<int64_t>(k) * sk + static_cast<int64_t>(l) * sl] = v;
+}
+
+// ======================================================================================
+// host side
+// ======================================================================================
+int pad_dim(int d) {
+  if (d <= 128) return (d + 1) / 2 * 2;
+  if (d <= 256) return (d + 3) / 4 * 4;
+  return (d + 7) / 8 * 8;
+}
+
+// (G, VEC) instantiation for a padded row length: code 0..6
+int group_code(int dp) {
+  if (dp <= 8) return 0;    // G=4  VEC=2
+  if (dp <= 16) return 1;   // G=8  VEC=2
+  if (dp <= 32) return 2;   // G=16 VEC=2
+  if (dp <= 64) return 3;   // G=32 VEC=2
+  if (dp <= 128) return 4;  // G=64 VEC=2
+  if (dp <= 256) return 5;  // G=64 VEC=4
+  return 6;                 // G=64 VEC=8
+}
+int group_lanes(int code) {
+  static const int g[7] = {4, 8, 16, 32, 64, 64, 64};
+  return g[code];
+}
+
+#define DISPATCH_GV(code, CALL)                                   \
+  switch (code) {                                                 \
+    case 0: CALL(4, 2); break;                                    \
+    case 1: CALL(8, 2); break;                                    \
+    case 2: CALL(16, 2); break;                                   \
+    case 3: CALL(32, 2); break;                                   \
+    case 4: CALL(64, 2); break;                                   \
+    case 5: CALL(64, 4); break;                                   \
+    default: CALL(64, 8); break;                                  \
+  }
+
+template <class T>
+struct DevBuf {
+  T *ptr = nullptr;
+  size_t count = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  ~DevBuf() { release(); }
+  void release() {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    count = 0;
+  }
+  void alloc(size_t n) {
+    release();
+    count = n;
+    HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&ptr), std::max<size_t>(n, 1) * sizeof(T)));
+  }
+  void upload(const std::vector<T> &h, hipStream_t s) {
+    alloc(h.size());
+    if (!h.empty())
+      HIP_CHECK(hipMemcpyAsync(ptr, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s));
+  }
+};
+
+enum KernelId { K_SEG = 0, K_MATVEC_T, K_PPARTIAL, K_ITEMSUM, K_PFINAL, K_MATVEC_A, K_COUNT };
+const char *const kKernelNames[K_COUNT] = {"seg_pass_kernel",  "pair_matvec_kernel(T)",
+                                           "p_partial_kernel", "item_sum_kernel",
+                                           "p_finalize_kernel", "pair_matvec_kernel(A)"};
+
+}  // namespace
+
+struct mmsbm_hip_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool swapped = false;
+  // external dims
+  int64_t n_obs = 0;
+  int ext_users = 0, ext_items = 0, ext_k = 0, ext_l = 0;
+  // internal dims ("item" = the side paired with the rating)
+  int n_users = 0, n_items = 0, n_ratings = 0, k = 0, l = 0, kp = 0, lp = 0;
+  int n_pairs = 0, n_chunks = 0;
+  int code_k = 0, code_l = 0, nacc = 1;
+  mmsbm::Layout lay;  // host copy (degrees, sizes)
+  DevBuf<int32_t> pair_off, pair_user, pair_item, user_off, user_pair, item_off, item_pairs,
+      item_deg, chunk_off, orig_u, orig_i, orig_r;
+  DevBuf<mmsbm::Chunk> chunks;
+  DevBuf<double> theta[2], eta[2], p[2], pt[2], atab, ctab, ttab, partial, npr, lik_part;
+  int cur = 0;
+  bool have_params = false;
+  bool graph_mode = false;
+  // per-launch profiling
+  bool profiling = false;
+  std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> prof_events;
+
+  ~mmsbm_hip_ctx() {
+    for (auto &pe : prof_events) {
+      (void)hipEventDestroy(pe.second.first);
+      (void)hipEventDestroy(pe.second.second);
+    }
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+};
+
+namespace {
+
+struct LaunchScope {  // optional event pair around one launch
+  mmsbm_hip_ctx *c;
+  int id;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  LaunchScope(mmsbm_hip_ctx *ctx, int kid) : c(ctx), id(kid) {
+    if (c->profiling) {
+      HIP_CHECK(hipEventCreate(&e0));
+      HIP_CHECK(hipEventCreate(&e1));
+      HIP_CHECK(hipEventRecord(e0, c->stream));
+    }
+  }
+  void done() {
+    HIP_CHECK(hipGetLastError());
+    if (c->profiling) {
+      HIP_CHECK(hipEventRecord(e1, c->stream));
+      c->prof_events.push_back({id, {e0, e1}});
+    }
+  }
+};
+
+void use_device(const mmsbm_hip_ctx *c) { HIP_CHECK(hipSetDevice(c->device)); }
+
+constexpr size_t kLdsBudget = 64 * 1024;  // static + dynamic LDS a launch may use by default
+
+// groups per batch of pair_matvec such that tile + rows fit the LDS budget (0: tile too big)
+int matvec_gpb(int dinp, int doutp, int g) {
+  const size_t tile = static_cast<size_t>(dinp) * doutp * sizeof(double);
+  if (tile + static_cast<size_t>(dinp) * sizeof(double) > kLdsBudget) return 0;
+  const size_t fit = (kLdsBudget - tile) / (static_cast<size_t>(dinp) * sizeof(double));
+  return static_cast<int>(std::min<size_t>(fit, static_cast<size_t>(kBlock / g)));
+}
+size_t matvec_lds_bytes(int dinp, int doutp, int gpb) {
+  return (static_cast<size_t>(dinp) * doutp + static_cast<size_t>(gpb) * dinp) * sizeof(double);
+}
+int ppartial_batch(int kp, int lp) {
+  const size_t per = static_cast<size_t>(kp + lp) * sizeof(double);
+  return static_cast<int>(std::min<size_t>(kPBatchMax, kLdsBudget / per));
+}
+
+// A[q,:] from (eta, pT) -- needed whenever the parameters change outside em_iterate.
+void launch_matvec_a(mmsbm_hip_ctx *c, const double *pt, const double *eta) {
+  if (c->n_chunks == 0) return;
+  LaunchScope ls(c, K_MATVEC_A);
+  const int gpb = matvec_gpb(c->lp, c->kp, group_lanes(c->code_k));
+  const size_t lds = matvec_lds_bytes(c->lp, c->kp, gpb);
+#define CALL(G, V)                                                                          \
+  pair_matvec_kernel<G, V><<<c->n_chunks, kBlock, lds, c->stream>>>(                        \
+      pt, eta, c->pair_item.ptr, c->chunks.ptr, c->atab.ptr, c->l, c->lp, c->kp, gpb)
+  DISPATCH_GV(c->code_k, CALL);
+#undef CALL
+  ls.done();
+}
+
+// One EM iteration.  commit: parameters advance (theta, eta, p normalised, A refreshed);
+// otherwise the un-normalised numerators are left in the "next" buffers / npr.
+void launch_iteration(mmsbm_hip_ctx *c, bool commit) {
+  const int cur = c->cur, nxt = cur ^ 1;
+  const int gk = group_lanes(c->code_k), gl = group_lanes(c->code_l);
+  {  // ---- seg_pass: theta_new and C ------------------------------------------------------
+    LaunchScope ls(c, K_SEG);
+    SegArgs su{c->theta[cur].ptr, c->atab.ptr,  c->user_off.ptr, c->user_pair.ptr,
+               c->theta[nxt].ptr, c->n_users,   commit ? 1 : 2};
+    SegArgs sp{c->atab.ptr, c->theta[cur].ptr, c->pair_off.ptr, c->pair_user.ptr,
+               c->ctab.ptr, c->n_pairs,        0};
+    const int per = kBlock / gk;
+    const int bu = (c->n_users + per - 1) / per, bp = (c->n_pairs + per - 1) / per;
+#define CALL(G, V) \
+  seg_pass_kernel<G, V, 4><<<bu + bp, kBlock, 0, c->stream>>>(su, sp, bu, c->kp)
+    DISPATCH_GV(c->code_k, CALL);
+#undef CALL
+    ls.done();
+  }
+  if (c->n_chunks > 0) {  // ---- T = P^T C ------------------------------------------------------
+    LaunchScope ls(c, K_MATVEC_T);
+    const int gpb = matvec_gpb(c->kp, c->lp, gl);
+    const size_t lds = matvec_lds_bytes(c->kp, c->lp, gpb);
+#define CALL(G, V)                                                                          \
+  pair_matvec_kernel<G, V><<<c->n_chunks, kBlock, lds, c->stream>>>(                        \
+      c->p[cur].ptr, c->ctab.ptr, nullptr, c->chunks.ptr, c->ttab.ptr, c->k, c->kp, c->lp,  \
+      gpb)
+    DISPATCH_GV(c->code_l, CALL);
+#undef CALL
+    ls.done();
+  }
+  if (c->n_chunks > 0) {  // ---- partial K x L slabs for p ---------------------------------------
+    LaunchScope ls(c, K_PPARTIAL);
+    const int batch = ppartial_batch(c->kp, c->lp);
+    const size_t lds = static_cast<size_t>(batch) * (c->kp + c->lp) * sizeof(double);
+#define PP(N)                                                                               \
+  p_partial_kernel<N><<<c->n_chunks, kBlock, lds, c->stream>>>(                             \
+      c->ctab.ptr, c->eta[cur].ptr, c->pair_item.ptr, c->chunks.ptr, c->partial.ptr, c->kp, \
+      c->lp, batch)
+    switch (c->nacc) {
+      case 1: PP(1); break;
+      case 2: PP(2); break;
+      case 4: PP(4); break;
+      case 8: PP(8); break;
+      case 16: PP(16); break;
+      default: PP(32); break;
+    }
+#undef PP
+    ls.done();
+  }
+  {  // ---- eta_new -------------------------------------------------------------------------
+    LaunchScope ls(c, K_ITEMSUM);
+    const int per = kBlock / gl;
+    const int nb = (c->n_items + per - 1) / per;
+#define CALL(G, V)                                                                          \
+  item_sum_kernel<G, V><<<nb, kBlock, 0, c->stream>>>(                                      \
+      c->ttab.ptr, c->item_off.ptr, c->item_pairs.ptr, c->item_deg.ptr, c->eta[cur].ptr,    \
+      c->eta[nxt].ptr, c->n_items, c->lp, commit ? 1 : 0)
+    DISPATCH_GV(c->code_l, CALL);
+#undef CALL
+    ls.done();
+  }
+  {  // ---- p_new (+ transposed copy) ---------------------------------------------------------
+    LaunchScope ls(c, K_PFINAL);
+    const int kl = c->kp * c->lp;
+    const int nb = (kl + kFinCols - 1) / kFinCols;
+    const size_t lds = static_cast<size_t>(kFinRows + c->n_ratings) * kFinCols * sizeof(double);
+    p_finalize_kernel<<<nb, kFinCols * kFinRows, lds, c->stream>>>(
+        c->partial.ptr, c->chunk_off.ptr, c->p[cur].ptr, c->p[nxt].ptr, c->pt[nxt].ptr,
+        commit ? nullptr : c->npr.ptr, c->n_ratings, c->kp, c->lp, commit ? 1 : 0);
+    ls.done();
+  }
+  if (commit) {
+    launch_matvec_a(c, c->pt[nxt].ptr, c->eta[nxt].ptr);
+    c->cur = nxt;
+  }
+}
+
+void require_params(const mmsbm_hip_ctx *c) {
+  if (!c) throw std::invalid_argument("null context");
+  if (!c->have_params) throw std::invalid_argument("set_params has not been called");
+}
+
+// host (rows, d) row-major  <->  device (rows, dp) zero-padded
+void upload_rows(mmsbm_hip_ctx *c, double *dev, const double *host, int rows, int d, int dp) {
+  if (d == dp) {
+    HIP_CHECK(hipMemcpyAsync(dev, host, sizeof(double) * rows * d, hipMemcpyHostToDevice,
+                             c->stream));
+  } else {
+    HIP_CHECK(hipMemsetAsync(dev, 0, sizeof(double) * rows * dp, c->stream));
+    HIP_CHECK(hipMemcpy2DAsync(dev, sizeof(double) * dp, host, sizeof(double) * d,
+                               sizeof(double) * d, rows, hipMemcpyHostToDevice, c->stream));
+  }
+}
+void download_rows(mmsbm_hip_ctx *c, double *host, const double *dev, int rows, int d, int dp) {
+  if (d == dp) {
+    HIP_CHECK(hipMemcpyAsync(host, dev, sizeof(double) * rows * d, hipMemcpyDeviceToHost,
+                             c->stream));
+  } else {
+    HIP_CHECK(hipMemcpy2DAsync(host, sizeof(double) * d, dev, sizeof(double) * dp,
+                               sizeof(double) * d, rows, hipMemcpyDeviceToHost, c->stream));
+  }
+}
+
+// device p layout [R][kp][lp] (internal k, l)  <->  host pr (K, L, R) external
+void p_host_to_dev(const mmsbm_hip_ctx *c, const double *pr, std::vector<double> &p,
+                   std::vector<double> &pt) {
+  const int R = c->n_ratings, K = c->k, L = c->l, kp = c->kp, lp = c->lp;
+  p.assign(static_cast<size_t>(R) * kp * lp, 0.0);
+  pt.assign(static_cast<size_t>(R) * kp * lp, 0.0);
+  for (int k = 0; k < K; ++k)
+    for (int l = 0; l < L; ++l)
+      for (int r = 0; r < R; ++r) {
+        // internal (k,l) == external (l,k) when swapped
+        const size_t h = c->swapped ? (static_cast<size_t>(l) * c->ext_l + k) * R + r
+                                    : (static_cast<size_t>(k) * c->ext_l + l) * R + r;
+        const double v = pr[h];
+        p[(static_cast<size_t>(r) * kp + k) * lp + l] = v;
+        pt[(static_cast<size_t>(r) * lp + l) * kp + k] = v;
+      }
+}
+void p_dev_to_host(const mmsbm_hip_ctx *c, const std::vector<double> &p, double *pr) {
+  const int R = c->n_ratings, K = c->k, L = c->l, kp = c->kp, lp = c->lp;
+  for (int k = 0; k < K; ++k)
+    for (int l = 0; l < L; ++l)
+      for (int r = 0; r < R; ++r) {
+        const size_t h = c->swapped ? (static_cast<size_t>(l) * c->ext_l + k) * R + r
+                                    : (static_cast<size_t>(k) * c->ext_l + l) * R + r;
+        pr[h] = p[(static_cast<size_t>(r) * kp + k) * lp + l];
+      }
+}
+
+void collect_profile(mmsbm_hip_ctx *c, float *mean_us, int *launches, int n_iters) {
+  std::vector<double> tot(K_COUNT, 0.0);
+  std::vector<int> cnt(K_COUNT, 0);
+  for (auto &pe : c->prof_events) {
+    float ms = 0.f;
+    HIP_CHECK(hipEventElapsedTime(&ms, pe.second.first, pe.second.second));
+    tot[pe.first] += ms * 1000.0;
+    cnt[pe.first]++;
+    (void)hipEventDestroy(pe.second.first);
+    (void)hipEventDestroy(pe.second.second);
+  }
+  c->prof_events.clear();
+  for (int i = 0; i < K_COUNT; ++i) {
+    mean_us[i] = cnt[i] ? static_cast<float>(tot[i] / cnt[i]) : 0.f;
+    if (launches) launches[i] = n_iters > 0 ? cnt[i] / n_iters : 0;
+  }
+}
+
+}  // namespace
+
+// ======================================================================================
+// C ABI
+// ======================================================================================
+extern "C" {
+
+int mmsbm_hip_abi_version(void) { return MMSBM_HIP_ABI_VERSION; }
+
+const char *mmsbm_hip_last_error(void) { return g_last_error.c_str(); }
+
+int mmsbm_hip_device_count(int *count) {
+  return guarded([&] {
+    if (!count) throw std::invalid_argument("null count");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+      *count = 0;
+      throw ApiError(MMSBM_E_NODEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+    }
+    *count = n;
+  });
+}
+
+int mmsbm_hip_device_info(int device, char *name, int name_len, int *compute_units,
+                          int64_t *global_mem_bytes) {
+  return guarded([&] {
+    hipDeviceProp_t prop;
+    HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    if (name && name_len > 0) {
+      std::snprintf(name, static_cast<size_t>(name_len), "%s (%s)", prop.name, prop.gcnArchName);
+    }
+    if (compute_units) *compute_units = prop.multiProcessorCount;
+    if (global_mem_bytes) *global_mem_bytes = static_cast<int64_t>(prop.totalGlobalMem);
+  });
+}
+
+int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items,
+                     int32_t n_ratings, int32_t k_groups, int32_t l_groups,
+                     const int32_t *user, const int32_t *item, const int32_t *rating,
+                     int swap_sides, mmsbm_hip_ctx **out) {
+  return guarded([&] {
+    if (!out) throw std::invalid_argument("null out");
+    *out = nullptr;
+    if (k_groups <= 0 || l_groups <= 0) throw std::invalid_argument("K and L must be positive");
+    if (k_groups > 512 || l_groups > 512)
+      throw ApiError(MMSBM_E_UNSUPPORTED, "K and L are limited to 512 groups");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+      throw ApiError(MMSBM_E_NODEVICE, "no HIP device available (this library has no CPU path)");
+    if (device < 0 || device >= ndev) throw std::invalid_argument("device index out of range");
+
+    std::unique_ptr<mmsbm_hip_ctx> c(new mmsbm_hip_ctx());
+    c->device = device;
+    c->swapped = swap_sides > 0 || (swap_sides < 0 && n_users < n_items);
+    c->n_obs = n_obs;
+    c->ext_users = n_users; c->ext_items = n_items; c->ext_k = k_groups; c->ext_l = l_groups;
+    c->n_ratings = n_ratings;
+    const int32_t *iu = user, *ii = item;
+    if (c->swapped) {
+      c->n_users = n_items; c->n_items = n_users; c->k = l_groups; c->l = k_groups;
+      iu = item; ii = user;
+    } else {
+      c->n_users = n_users; c->n_items = n_items; c->k = k_groups; c->l = l_groups;
+    }
+    c->kp = pad_dim(c->k); c->lp = pad_dim(c->l);
+    c->code_k = group_code(c->kp); c->code_l = group_code(c->lp);
+    {
+      const int nout = c->kp * (c->lp / 2);
+      int need = (nout + kBlock - 1) / kBlock;
+      int n = 1;
+      while (n < need) n *= 2;
+      if (n > 32) throw ApiError(MMSBM_E_UNSUPPORTED, "K*L too large for p_partial (max 16384)");
+      c->nacc = n;
+    }
+    if (matvec_gpb(c->kp, c->lp, group_lanes(c->code_l)) < 1 ||
+        matvec_gpb(c->lp, c->kp, group_lanes(c->code_k)) < 1)
+      throw ApiError(MMSBM_E_UNSUPPORTED, "K*L tile does not fit the 64 KiB LDS budget");
+    if (n_ratings > 112)
+      throw ApiError(MMSBM_E_UNSUPPORTED, "more than 112 distinct ratings are not supported");
+
+    mmsbm::build_layout(n_obs, c->n_users, c->n_items, n_ratings, iu, ii, rating, 1024, c->lay);
+    c->n_pairs = c->lay.n_pairs;
+    c->n_chunks = static_cast<int>(c->lay.chunks.size());
+
+    HIP_CHECK(hipSetDevice(device));
+    HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    hipStream_t s = c->stream;
+    c->pair_off.upload(c->lay.pair_off, s);
+    c->pair_user.upload(c->lay.pair_user, s);
+    c->pair_item.upload(c->lay.pair_item, s);
+    c->user_off.upload(c->lay.user_off, s);
+    c->user_pair.upload(c->lay.user_pair, s);
+    c->item_off.upload(c->lay.item_off, s);
+    c->item_pairs.upload(c->lay.item_pairs, s);
+    c->item_deg.upload(c->lay.item_deg, s);
+    c->chunk_off.upload(c->lay.chunk_off, s);
+    c->chunks.upload(c->lay.chunks, s);
+    {
+      std::vector<int32_t> tmp;
+      tmp.assign(iu, iu + n_obs); c->orig_u.upload(tmp, s);
+      HIP_CHECK(hipStreamSynchronize(s));
+      tmp.assign(ii, ii + n_obs); c->orig_i.upload(tmp, s);
+      HIP_CHECK(hipStreamSynchronize(s));
+      tmp.assign(rating, rating + n_obs); c->orig_r.upload(tmp, s);
+      HIP_CHECK(hipStreamSynchronize(s));
+    }
+    const size_t klr = static_cast<size_t>(n_ratings) * c->kp * c->lp;
+    for (int b = 0; b < 2; ++b) {
+      c->theta[b].alloc(static_cast<size_t>(c->n_users) * c->kp);
+      c->eta[b].alloc(static_cast<size_t>(c->n_items) * c->lp);
+      c->p[b].alloc(klr);
+      c->pt[b].alloc(klr);
+      HIP_CHECK(hipMemsetAsync(c->theta[b].ptr, 0, sizeof(double) * c->theta[b].count, s));
+      HIP_CHECK(hipMemsetAsync(c->eta[b].ptr, 0, sizeof(double) * c->eta[b].count, s));
+      HIP_CHECK(hipMemsetAsync(c->p[b].ptr, 0, sizeof(double) * klr, s));
+      HIP_CHECK(hipMemsetAsync(c->pt[b].ptr, 0, sizeof(double) * klr, s));
+    }
+    c->atab.alloc(static_cast<size_t>(c->n_pairs) * c->kp);
+    c->ctab.alloc(static_cast<size_t>(c->n_pairs) * c->kp);
+    c->ttab.alloc(static_cast<size_t>(c->n_pairs) * c->lp);
+    c->partial.alloc(static_cast<size_t>(std::max(c->n_chunks, 1)) * c->kp * c->lp);
+    c->npr.alloc(klr);
+    c->lik_part.alloc(4096);
+    HIP_CHECK(hipMemsetAsync(c->atab.ptr, 0, sizeof(double) * std::max<size_t>(c->atab.count, 1), s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    *out = c.release();
+  });
+}
+
+int mmsbm_hip_destroy(mmsbm_hip_ctx *ctx) {
+  return guarded([&] {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    delete ctx;
+  });
+}
+
+int mmsbm_hip_dims(const mmsbm_hip_ctx *ctx, int64_t dims[8]) {
+  return guarded([&] {
+    if (!ctx || !dims) throw std::invalid_argument("null argument");
+    dims[0] = ctx->n_obs; dims[1] = ctx->ext_users; dims[2] = ctx->ext_items;
+    dims[3] = ctx->n_ratings; dims[4] = ctx->ext_k; dims[5] = ctx->ext_l;
+    dims[6] = ctx->n_pairs; dims[7] = ctx->swapped ? 1 : 0;
+  });
+}
+
+int mmsbm_hip_degrees(const mmsbm_hip_ctx *ctx, int64_t *d_user, int64_t *d_item) {
+  return guarded([&] {
+    if (!ctx) throw std::invalid_argument("null context");
+    const mmsbm::Layout &L = ctx->lay;
+    int64_t *du = ctx->swapped ? d_item : d_user;  // internal users
+    int64_t *di = ctx->swapped ? d_user : d_item;  // internal items
+    if (du)
+      for (int u = 0; u < L.n_users; ++u)
+        du[u] = std::max<int64_t>(L.user_off[u + 1] - L.user_off[u], 1);
+    if (di)
+      for (int i = 0; i < L.n_items; ++i) di[i] = std::max<int64_t>(L.item_deg[i], 1);
+  });
+}
+
+int mmsbm_hip_set_params(mmsbm_hip_ctx *ctx, const double *theta, const double *eta,
+                         const double *pr) {
+  return guarded([&] {
+    if (!ctx || !theta || !eta || !pr) throw std::invalid_argument("null argument");
+    use_device(ctx);
+    const double *it = ctx->swapped ? eta : theta;  // internal theta rows = internal users
+    const double *ie = ctx->swapped ? theta : eta;
+    const int cur = ctx->cur;
+    upload_rows(ctx, ctx->theta[cur].ptr, it, ctx->n_users, ctx->k, ctx->kp);
+    upload_rows(ctx, ctx->eta[cur].ptr, ie, ctx->n_items, ctx->l, ctx->lp);
+    std::vector<double> p, pt;
+    p_host_to_dev(ctx, pr, p, pt);
+    HIP_CHECK(hipMemcpyAsync(ctx->p[cur].ptr, p.data(), sizeof(double) * p.size(),
+                             hipMemcpyHostToDevice, ctx->stream));
+    HIP_CHECK(hipMemcpyAsync(ctx->pt[cur].ptr, pt.data(), sizeof(double) * pt.size(),
+                             hipMemcpyHostToDevice, ctx->stream));
+    launch_matvec_a(ctx, ctx->pt[cur].ptr, ctx->eta[cur].ptr);
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));  // host staging vectors die here
+    ctx->have_params = true;
+  });
+}
+
+int mmsbm_hip_get_params(mmsbm_hip_ctx *ctx, double *theta, double *eta, double *pr) {
+  return guarded([&] {
+    require_params(ctx);
+    use_device(ctx);
+    double *it = ctx->swapped ? eta : theta;
+    double *ie = ctx->swapped ? theta : eta;
+    const int cur = ctx->cur;
+    if (it) download_rows(ctx, it, ctx->theta[cur].ptr, ctx->n_users, ctx->k, ctx->kp);
+    if (ie) download_rows(ctx, ie, ctx->eta[cur].ptr, ctx->n_items, ctx->l, ctx->lp);
+    std::vector<double> p;
+    if (pr) {
+      p.resize(ctx->p[cur].count);
+      HIP_CHECK(hipMemcpyAsync(p.data(), ctx->p[cur].ptr, sizeof(double) * p.size(),
+                               hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (pr) p_dev_to_host(ctx, p, pr);
+  });
+}
+
+int mmsbm_hip_em_iterate(mmsbm_hip_ctx *ctx, int n_iters) {
+  return guarded([&] {
+    require_params(ctx);
+    if (n_iters < 0) throw std::invalid_argument("n_iters must be >= 0");
+    use_device(ctx);
+    for (int it = 0; it < n_iters; ++it) launch_iteration(ctx, true);
+  });
+}
+
+int mmsbm_hip_synchronize(mmsbm_hip_ctx *ctx) {
+  return guarded([&] {
+    if (!ctx) throw std::invalid_argument("null context");
+    use_device(ctx);
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  });
+}
+
+int mmsbm_hip_update_coefficients(mmsbm_hip_ctx *ctx, double *n_theta, double *n_eta,
+                                  double *n_pr) {
+  return guarded([&] {
+    require_params(ctx);
+    use_device(ctx);
+    launch_iteration(ctx, false);
+    const int nxt = ctx->cur ^ 1;
+    double *it = ctx->swapped ? n_eta : n_theta;
+    double *ie = ctx->swapped ? n_theta : n_eta;
+    if (it) download_rows(ctx, it, ctx->theta[nxt].ptr, ctx->n_users, ctx->k, ctx->kp);
+    if (ie) download_rows(ctx, ie, ctx->eta[nxt].ptr, ctx->n_items, ctx->l, ctx->lp);
+    std::vector<double> p;
+    if (n_pr) {
+      p.resize(ctx->npr.count);
+      HIP_CHECK(hipMemcpyAsync(p.data(), ctx->npr.ptr, sizeof(double) * p.size(),
+                               hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (n_pr) p_dev_to_host(ctx, p, n_pr);
+  });
+}
+
+int mmsbm_hip_likelihood(mmsbm_hip_ctx *ctx, double *out) {
+  return guarded([&] {
+    require_params(ctx);
+    if (!out) throw std::invalid_argument("null out");
+    use_device(ctx);
+    const int cur = ctx->cur;
+    int nb = static_cast<int>(std::min<int64_t>((ctx->n_obs + kBlock - 1) / kBlock, 4096));
+    nb = std::max(nb, 1);
+    likelihood_kernel<<<nb, kBlock, 0, ctx->stream>>>(
+        ctx->orig_u.ptr, ctx->orig_i.ptr, ctx->orig_r.ptr, ctx->theta[cur].ptr,
+        ctx->eta[cur].ptr, ctx->p[cur].ptr, ctx->lik_part.ptr, ctx->n_obs, ctx->k, ctx->l,
+        ctx->kp, ctx->lp);
+    HIP_CHECK(hipGetLastError());
+    std::vector<double> part(nb);
+    HIP_CHECK(hipMemcpyAsync(part.data(), ctx->lik_part.ptr, sizeof(double) * nb,
+                             hipMemcpyDeviceToHost, ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    double tot = 0.0;
+    for (double v : part) tot += v;
+    *out = tot;
+  });
+}
+
+int mmsbm_hip_compute_omegas(mmsbm_hip_ctx *ctx, double *out, int64_t capacity_elems) {
+  return guarded([&] {
+    require_params(ctx);
+    if (!out) throw std::invalid_argument("null out");
+    use_device(ctx);
+    const int64_t kl = static_cast<int64_t>(ctx->k) * ctx->l;
+    const int64_t n_elems = ctx->n_obs * kl;
+    if (n_elems > capacity_elems)
+      throw ApiError(MMSBM_E_TOOLARGE, "omega tensor larger than the caller's buffer");
+    if (n_elems > (int64_t(1) << 31))  // 16 GiB: the factorised path exists so nobody needs this
+      throw ApiError(MMSBM_E_TOOLARGE, "omega tensor above the 2^31-element cap");
+    if (n_elems == 0) return;
+    DevBuf<double> dev;
+    dev.alloc(static_cast<size_t>(n_elems));
+    const int cur = ctx->cur;
+    // internal (k,l) -> external position: not swapped [k][l] strides (L,1); swapped the
+    // external tensor is [l_int][k_int] so strides are (1, K_int)
+    const int sk = ctx->swapped ? 1 : ctx->l;
+    const int sl = ctx->swapped ? ctx->k : 1;
+    const int64_t nb = (n_elems + kBlock - 1) / kBlock;
+    omegas_kernel<<<static_cast<unsigned>(nb), kBlock, 0, ctx->stream>>>(
+        ctx->orig_u.ptr, ctx->orig_i.ptr, ctx->orig_r.ptr, ctx->theta[cur].ptr,
+        ctx->eta[cur].ptr, ctx->p[cur].ptr, dev.ptr, n_elems, ctx->k, ctx->l, ctx->kp, ctx->lp,
+        sk, sl);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(out, dev.ptr, sizeof(double) * n_elems, hipMemcpyDeviceToHost,
+                             ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  });
+}
+
+int mmsbm_hip_prod_dist(mmsbm_hip_ctx *ctx, int64_t n_pairs, const int32_t *user,
+                        const int32_t *item, double *out) {
+  return guarded([&] {
+    require_params(ctx);
+    if (n_pairs < 0) throw std::invalid_argument("negative n_pairs");
+    if (n_pairs == 0) return;
+    if (!user || !item || !out) throw std::invalid_argument("null argument");
+    for (int64_t m = 0; m < n_pairs; ++m)
+      if (user[m] < 0 || user[m] >= ctx->ext_users || item[m] < 0 || item[m] >= ctx->ext_items)
+        throw std::invalid_argument("prod_dist: id out of range at row " + std::to_string(m));
+    use_device(ctx);
+    const int64_t n_elems = n_pairs * ctx->n_ratings;
+    if ((n_elems + kBlock - 1) / kBlock > (int64_t(1) << 31) - 1)
+      throw ApiError(MMSBM_E_TOOLARGE, "prod_dist: too many pairs for one launch");
+    DevBuf<int32_t> du, di;
+    DevBuf<double> dout;
+    du.alloc(n_pairs); di.alloc(n_pairs); dout.alloc(n_elems);
+    const int32_t *iu = ctx->swapped ? item : user;
+    const int32_t *ii = ctx->swapped ? user : item;
+    HIP_CHECK(hipMemcpyAsync(du.ptr, iu, sizeof(int32_t) * n_pairs, hipMemcpyHostToDevice, ctx->stream));
+    HIP_CHECK(hipMemcpyAsync(di.ptr, ii, sizeof(int32_t) * n_pairs, hipMemcpyHostToDevice, ctx->stream));
+    const int cur = ctx->cur;
+    const int64_t nb = (n_elems + kBlock - 1) / kBlock;
+    prod_dist_kernel<<<static_cast<unsigned>(nb), kBlock, 0, ctx->stream>>>(
+        du.ptr, di.ptr, ctx->theta[cur].ptr, ctx->eta[cur].ptr, ctx->p[cur].ptr, dout.ptr,
+        n_pairs, ctx->n_ratings, ctx->k, ctx->l, ctx->kp, ctx->lp);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(out, dout.ptr, sizeof(double) * n_elems, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  });
+}
+
+int mmsbm_hip_time_iterations(mmsbm_hip_ctx *ctx, int n_iters, float *elapsed_ms) {
+  return guarded([&] {
+    require_params(ctx);
+    if (!elapsed_ms || n_iters < 0) throw std::invalid_argument("bad argument");
+    use_device(ctx);
+    hipEvent_t e0, e1;
+    HIP_CHECK(hipEventCreate(&e0));
+    HIP_CHECK(hipEventCreate(&e1));
+    HIP_CHECK(hipEventRecord(e0, ctx->stream));
+    for (int it = 0; it < n_iters; ++it) launch_iteration(ctx, true);
+    HIP_CHECK(hipEventRecord(e1, ctx->stream));
+    HIP_CHECK(hipEventSynchronize(e1));
+    HIP_CHECK(hipEventElapsedTime(elapsed_ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+  });
+}
+
+int mmsbm_hip_kernel_count(void) { return K_COUNT; }
+
+const char *mmsbm_hip_kernel_name(int index) {
+  return (index >= 0 && index < K_COUNT) ? kKernelNames[index] : "";
+}
+
+int mmsbm_hip_profile_iterations(mmsbm_hip_ctx *ctx, int n_iters, float *mean_us,
+                                 int *launches_per_iter) {
+  return guarded([&] {
+    require_params(ctx);
+    if (!mean_us || n_iters <= 0) throw std::invalid_argument("bad argument");
+    use_device(ctx);
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ctx->profiling = true;
+    try {
+      for (int it = 0; it < n_iters; ++it) launch_iteration(ctx, true);
+      HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    } catch (...) {
+      ctx->profiling = false;
+      throw;
+    }
+    ctx->profiling = false;
+    collect_profile(ctx, mean_us, launches_per_iter, n_iters);
+  });
+}
+
+int mmsbm_hip_kernel_bytes(const mmsbm_hip_ctx *ctx, int index, int64_t *bytes_read,
+                           int64_t *bytes_written) {
+  return guarded([&] {
+    if (!ctx || !bytes_read || !bytes_written) throw std::invalid_argument("null argument");
+    const int64_t N = ctx->n_obs, U = ctx->n_users, I = ctx->n_items, R = ctx->n_ratings;
+    const int64_t K = ctx->k, L = ctx->l, Q = ctx->n_pairs, C = ctx->n_chunks;
+    int64_t rd = 0, wr = 0;
+    switch (index) {
+      case K_SEG:  // two passes: index + one gathered K-row per triple; fixed rows and offsets once
+        rd = 2 * N * (4 + 8 * K) + (U + Q) * (8 * K + 4);
+        wr = (U + Q) * 8 * K;
+        break;
+      case K_MATVEC_T: rd = Q * 8 * K + C * 8 * K * L; wr = Q * 8 * L; break;
+      case K_PPARTIAL: rd = Q * (8 * K + 8 * L + 4); wr = C * 8 * K * L; break;
+      case K_ITEMSUM: rd = Q * (8 * L + 4) + I * (8 * L + 8); wr = I * 8 * L; break;
+      case K_PFINAL: rd = C * 8 * K * L + R * 8 * K * L; wr = 2 * R * 8 * K * L; break;
+      case K_MATVEC_A: rd = Q * (8 * L + 4) + C * 8 * K * L; wr = Q * 8 * K; break;
+      default: throw std::invalid_argument("kernel index out of range");
+    }
+    *bytes_read = rd;
+    *bytes_written = wr;
+  });
+}
+
+int mmsbm_hip_set_graph_mode(mmsbm_hip_ctx *ctx, int enabled) {
+  return guarded([&] {
+    if (!ctx) throw std::invalid_argument("null context");
+    ctx->graph_mode = enabled != 0;
+  });
+}
+
+// ---- host-only layout helpers (no device needed; used by the CPU tests) --------------------
+struct mmsbm_hip_layout {
+  mmsbm::Layout lay;
+};
+
+int mmsbm_hip_layout_build(int64_t n_obs, int32_t n_users, int32_t n_items, int32_t n_ratings,
+                           const int32_t *user, const int32_t *item, const int32_t *rating,
+                           int32_t target_chunks, mmsbm_hip_layout **out) {
+  return guarded([&] {
+    if (!out) throw std::invalid_argument("null out");
+    *out = nullptr;
+    std::unique_ptr<mmsbm_hip_layout> h(new mmsbm_hip_layout());
+    mmsbm::build_layout(n_obs, n_users, n_items, n_ratings, user, item, rating, target_chunks,
+                        h->lay);
+    *out = h.release();
+  });
+}
+
+int mmsbm_hip_layout_free(mmsbm_hip_layout *h) {
+  delete h;
+  return MMSBM_OK;
+}
+
+// which: 0 pair_off 1 pair_user 2 pair_item 3 rating_off 4 user_off 5 user_pair 6 item_off
+//        7 item_pairs 8 item_deg 9 chunk_off 10 chunks (4 ints each)
+int mmsbm_hip_layout_array(const mmsbm_hip_layout *h, int which, int32_t *out, int64_t capacity,
+                           int64_t *count) {
+  return guarded([&] {
+    if (!h || !count) throw std::invalid_argument("null argument");
+    const mmsbm::Layout &L = h->lay;
+    const std::vector<int32_t> *v = nullptr;
+    switch (which) {
+      case 0: v = &L.pair_off; break;
+      case 1: v = &L.pair_user; break;
+      case 2: v = &L.pair_item; break;
+      case 3: v = &L.rating_off; break;
+      case 4: v = &L.user_off; break;
+      case 5: v = &L.user_pair; break;
+      case 6: v = &L.item_off; break;
+      case 7: v = &L.item_pairs; break;
+      case 8: v = &L.item_deg; break;
+      case 9: v = &L.chunk_off; break;
+      case 10: break;
+      default: throw std::invalid_argument("unknown layout array");
+    }
+    if (which == 10) {
+      *count = static_cast<int64_t>(L.chunks.size()) * 4;
+      if (out) {
+        if (capacity < *count) throw ApiError(MMSBM_E_TOOLARGE, "buffer too small");
+        std::memcpy(out, L.chunks.data(), sizeof(int32_t) * *count);
+      }
+      return;
+    }
+    *count = static_cast<int64_t>(v->size());
+    if (out) {
+      if (capacity < *count) throw ApiError(MMSBM_E_TOOLARGE, "buffer too small");
+      std::memcpy(out, v->data(), sizeof(int32_t) * v->size());
+    }
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,95 @@
+"""The reference's three-function backend contract, served by the HIP library ("level 1").
+
+Mirrors src/kernels_numpy.py:10-14,21-24,43-46,86-89: module-level ``compute_omegas``,
+``update_coefficients`` and ``prod_dist`` with the signature ``(data, theta, eta, pr)``,
+numpy in / numpy out, inputs never mutated, fresh outputs owned by the caller.  Placed on
+``sys.path`` under the name ``kernels_hip`` (see mmsbm_amd/plugin/) it makes the
+reference's ``MMSBM(backend='hip')`` work unmodified (src/backend.py:16-22).
+
+Like src/kernels_cupy.py:3-17, importing this module raises ImportError -- and nothing
+else -- when the shared library or a GPU is missing, so ``backend='auto'`` fall-through in
+the reference keeps working.  There is no CPU path behind these functions.
+
+The reference calls ``update_coefficients`` once per EM iteration with the same ``data``;
+the sorted device layout is therefore cached per training set (keyed on a fingerprint of
+the array), so only theta/eta/pr cross PCIe per call.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+try:
+    from . import _lib
+    from .core import HipEM
+
+    _lib.load()
+    if _lib.device_count() < 1:
+        raise RuntimeError("no HIP device visible")
+except Exception as _hip_err:  # pragma: no cover - depends on the machine
+    raise ImportError(
+        "HIP backend selected, but libmmsbm_hip.so or a usable MI355X is not available: "
+        f"{_hip_err}") from _hip_err
+
+__all__ = ["compute_omegas", "update_coefficients", "prod_dist"]
+
+_CACHE_SLOTS = 2
+_cache = []  # [(fingerprint, HipEM)], most recent first
+
+
+def _fingerprint(data, theta, eta, pr):
+    d = np.asarray(data)
+    n = d.shape[0]
+    step = max(1, n // 2048)
+    return (d.shape, str(d.dtype), theta.shape, eta.shape, pr.shape,
+            int(d[:, 0].sum()), int(d[:, 1].sum()), int(d[:, 2].sum()) if d.shape[1] > 2 else 0,
+            d[::step].tobytes())
+
+
+def _context(data, theta, eta, pr):
+    theta, eta, pr = (np.asarray(a, dtype=np.float64) for a in (theta, eta, pr))
+    if theta.ndim != 2 or eta.ndim != 2 or pr.ndim != 3:
+        raise ValueError("theta (U,K), eta (I,L) and pr (K,L,R) expected")
+    if pr.shape[0] != theta.shape[1] or pr.shape[1] != eta.shape[1]:
+        raise ValueError("pr must have shape (K, L, R) matching theta (U,K) and eta (I,L)")
+    key = _fingerprint(data, theta, eta, pr)
+    for j, (k, ctx) in enumerate(_cache):
+        if k == key:
+            if j:
+                _cache.insert(0, _cache.pop(j))
+            break
+    else:
+        ctx = HipEM(data, theta.shape[1], eta.shape[1], n_users=theta.shape[0],
+                    n_items=eta.shape[0], n_ratings=pr.shape[2])
+        _cache.insert(0, (key, ctx))
+        while len(_cache) > _CACHE_SLOTS:
+            _cache.pop()[1].close()
+    ctx.set_params(theta, eta, pr)
+    return ctx
+
+
+def clear_cache():
+    """Release the cached device contexts."""
+    while _cache:
+        _cache.pop()[1].close()
+
+
+def compute_omegas(data, theta, eta, pr):
+    """Unnormalised responsibilities, shape (N, K, L); src/kernels_numpy.py:21-36."""
+    return _context(data, theta, eta, pr).compute_omegas()
+
+
+def update_coefficients(data, theta, eta, pr):
+    """(n_theta, n_eta, n_pr) unnormalised numerators; src/kernels_numpy.py:43-79."""
+    return _context(data, theta, eta, pr).update_coefficients()
+
+
+def prod_dist(data, theta, eta, pr):
+    """p(r | u, i) for every row of data, shape (N, R); src/kernels_numpy.py:86-96.
+
+    ``data`` here is usually a test set, so it gets its own tiny context-free path: the
+    parameters are uploaded into a context built on the rows themselves."""
+    d = np.asarray(data)
+    fake = np.zeros((d.shape[0], 3), dtype=np.int64)
+    fake[:, :2] = d[:, :2]
+    ctx = _context(fake, theta, eta, pr)
+    return ctx.prod_dist(d)

@@ -1,0 +1,267 @@
+"""Host class with the surface of the reference's ``MMSBM`` (src/mmsbm.py:15-553) for
+``backend='hip'``: same constructor keywords, ``fit`` / ``predict`` / ``score`` / ``cv_fit``,
+``results`` as a list of ``{"likelihood", "pr", "theta", "eta"}`` dicts in restart order.
+
+What differs from the reference is where things run: a restart is one ``HipEM`` context
+whose whole EM loop stays on the GPU (src/mmsbm.py:243-250 becomes one C-ABI call), and
+restarts are spread over GPUs -- threads over ``devices`` inside one process, or
+ranks of a ``torch.distributed`` job (mmsbm_amd/restarts.py) -- instead of a
+``multiprocessing.Pool`` (src/mmsbm.py:182-185).  Restart ``i`` is seeded exactly like the
+reference (``SeedSequence(seed).spawn(sampling)[i]``, draw order theta, eta, p), so it does
+not depend on ``sampling`` or on which GPU runs it.
+"""
+from __future__ import annotations
+
+import logging
+from concurrent.futures import ThreadPoolExecutor
+from datetime import datetime
+
+import numpy as np
+
+from .backend import load_backend
+from .core import HipEM
+from .encode import Encoder
+
+
+def normalize_with_self(p):
+    """p[k,l,:] /= sum_r p[k,l,r]; zero rows stay zero (src/expectation_maximization.py:152-155).
+    Host-side, used for the random initialisation only."""
+    flat = p.reshape(-1, p.shape[2])
+    tot = flat.sum(axis=1)
+    return (flat / np.where(tot == 0, 1, tot)[:, None]).reshape(p.shape)
+
+
+class MMSBM:
+    data_handler = None
+    results = None
+    test = None
+    theta = None
+    eta = None
+    pr = None
+    likelihood = None
+    prediction_matrix = None
+    rng = None
+
+    def __init__(self, user_groups, item_groups, iterations=400, sampling=1, seed=None,
+                 debug=False, backend="auto", devices=None):
+        self.start_time = datetime.now()
+        self.user_groups = user_groups
+        self.item_groups = item_groups
+        self.iterations = iterations
+        self.sampling = sampling
+        self.debug = debug
+        self.backend = backend
+        self.devices = devices
+        # src/mmsbm.py:81-85
+        self.rng = np.random.default_rng(seed)
+        self.child_states = self.rng.bit_generator._seed_seq.spawn(sampling)
+        self.logger = logging.getLogger("MMSBM")
+        self._backend = None  # resolved in _prepare_objects, like the reference (EM ctor)
+        self.best_by_likelihood = None
+        self._ctxs = {}
+
+    # ------------------------------------------------------------------ preparation
+    def _prepare_objects(self, train):
+        """Dims only; the degrees come from the device layout (src/mmsbm.py:93-146 minus the
+        dead O(U*N) index lists)."""
+        # 'auto'/'hip' -> hip; anything else raises ImportError like src/backend.py:27-28
+        *_, self._backend = load_backend(self.backend)
+        train = np.asarray(train)
+        self.train = train
+        self.ratings = sorted(set(train[:, 2].tolist()))
+        self.r = max(self.ratings)
+        self.p = int(train[:, 0].max())
+        self.m = int(train[:, 1].max())
+        self._dims = {"n_samples": len(train), "n_user_groups": self.user_groups,
+                      "n_item_groups": self.item_groups, "n_ratings": len(self.ratings)}
+        self._release()
+
+    def _device_list(self):
+        if self.devices is not None:
+            return list(self.devices)
+        return [0]
+
+    def _ctx(self, device):
+        ctx = self._ctxs.get(device)
+        if ctx is None:
+            ctx = HipEM(self.train, self.user_groups, self.item_groups, n_users=self.p + 1,
+                        n_items=self.m + 1, n_ratings=self._dims["n_ratings"], device=device)
+            self._ctxs[device] = ctx
+        return ctx
+
+    def _release(self):
+        for ctx in self._ctxs.values():
+            ctx.close()
+        self._ctxs = {}
+
+    # ------------------------------------------------------------------ training
+    def fit(self, data, silent=False):
+        if not silent:
+            self.logger.info(f"Running {self.sampling} runs of {self.iterations} iterations.")
+        self.data_handler = Encoder()
+        train = self.data_handler.fit_transform(data)
+        self.fit_encoded(train)
+
+    def fit_encoded(self, train, restarts=None):
+        """fit() on already encoded (N,3) triples.  ``restarts``: subset of restart indices to
+        run here (used by the multi-GPU driver); default all."""
+        self._prepare_objects(train)
+        todo = list(range(self.sampling)) if restarts is None else list(restarts)
+        devs = self._device_list()
+        if len(devs) == 1 or len(todo) <= 1:
+            done = [self.run_one_sampling(train, self.child_states[i], i, device=devs[0])
+                    for i in todo]
+        else:  # one host thread per GPU; ctypes releases the GIL inside the library
+            def work(slot):
+                return [(i, self.run_one_sampling(train, self.child_states[i], i, device=devs[slot]))
+                        for i in todo[slot::len(devs)]]
+            with ThreadPoolExecutor(max_workers=len(devs)) as pool:
+                parts = list(pool.map(work, range(len(devs))))
+            by_i = dict(x for part in parts for x in part)
+            done = [by_i[i] for i in todo]
+        self.results = done
+        self._restart_ids = todo
+        liks = [float(r["likelihood"]) for r in done]
+        self.best_by_likelihood = todo[int(np.argmax(liks))] if liks else None
+        return self
+
+    def init_params(self, seed, d_u, d_i):
+        """theta0, eta0, p0 with the reference's draw order (src/mmsbm.py:224-233)."""
+        rng = np.random.default_rng(seed)
+        k, l, r = self.user_groups, self.item_groups, self._dims["n_ratings"]
+        theta = rng.random((self.p + 1, k)) / d_u[:, None]
+        eta = rng.random((self.m + 1, l)) / d_i[:, None]
+        pr = normalize_with_self(rng.random((k, l, r)))
+        return theta, eta, pr
+
+    def run_one_sampling(self, data, seed, i, device=0):
+        """One restart, device resident (src/mmsbm.py:187-269)."""
+        ctx = self._ctx(device)
+        d_u, d_i = ctx.degrees()
+        ctx.set_params(*self.init_params(seed, d_u, d_i))
+        if self.debug:
+            done = 0
+            while done < self.iterations:  # likelihood every 50 iterations (src/mmsbm.py:252-254)
+                step = min(50, self.iterations - done)
+                ctx.iterate(step)
+                done += step
+                self.logger.debug(f"\nLikelihood at run {i} is {ctx.likelihood():.0f}")
+        else:
+            ctx.iterate(self.iterations)
+        likelihood = ctx.likelihood()
+        theta, eta, pr = ctx.get_params()
+        return {"likelihood": likelihood, "pr": pr, "theta": theta, "eta": eta}
+
+    # ------------------------------------------------------------------ prediction
+    def _check_is_fitted(self):
+        assert self.results is not None, "You need to fit the model before predicting."
+
+    def _check_has_predictions(self):
+        assert self.prediction_matrix is not None, (
+            "You need to predict before computing the goodness of fit parameters.")
+
+    def predict(self, data):
+        """Mean of prod_dist over restarts; stored objects from the run with the best test
+        accuracy (src/mmsbm.py:279-317)."""
+        self._check_is_fitted()
+        import pandas as pd
+
+        test = self.data_handler.transform(data, self.logger)
+        self.test = test
+        ctx = self._ctx(self._device_list()[0])
+        rats = []
+        for a in self.results:
+            ctx.set_params(a["theta"], a["eta"], a["pr"])
+            rats.append(ctx.prod_dist(test))
+        likelihoods = np.array([a["likelihood"] for a in self.results])
+        best = self.choose_best_run(rats)
+        enc = self.data_handler
+        res = self.results[best]
+        self.theta = pd.DataFrame(res["theta"], index=enc.user_labels())
+        self.eta = pd.DataFrame(res["eta"], index=enc.item_labels())
+        self.pr = {lab: pd.DataFrame(res["pr"][:, :, j]) for j, lab in enumerate(enc.rating_labels())}
+        self.likelihood = likelihoods[best]
+        self.prediction_matrix = np.array(rats).mean(axis=0)
+        return self.prediction_matrix
+
+    def choose_best_run(self, rats):
+        accuracies = [self._compute_stats(a)["accuracy"] for a in rats]
+        return accuracies.index(max(accuracies))
+
+    # ------------------------------------------------------------------ scoring (src/mmsbm.py:319-369,488-539)
+    def score(self, silent=False):
+        self._check_has_predictions()
+        stats = self._compute_stats(self.prediction_matrix)
+        stats["likelihood"] = self.likelihood
+        if not silent:
+            self.logger.info(
+                f"The final accuracy is {stats['accuracy']}, the one off accuracy is "
+                f"{stats['one_off_accuracy']} and the MAE is {stats['mae']}.")
+        return {"stats": stats, "objects": {"theta": self.theta, "eta": self.eta, "pr": self.pr}}
+
+    def _compute_stats(self, rat):
+        return self._compute_final_stats(self._compute_indicators(rat))
+
+    def _compute_indicators(self, rat):
+        pred = np.argmax(rat, axis=1)
+        real = self.test[:, 2]
+        mask = rat.sum(axis=1) != 0
+        if not np.all(mask):
+            pred, real, rat = pred[mask], real[mask], rat[mask]
+        pred_pond = rat @ self.ratings
+        return {"true": (pred == real).astype(int),
+                "almost": (np.abs(pred - real) <= 1).astype(int),
+                "s2": np.abs(pred - real),
+                "true_pond": (real == np.round(pred_pond)).astype(int),
+                "s2pond": np.abs(pred_pond - real)}
+
+    @staticmethod
+    def _compute_final_stats(rat):
+        n = len(rat["true"])
+        return {"accuracy": rat["true"].sum() / n,
+                "one_off_accuracy": rat["almost"].sum() / n,
+                "mae": 1 - rat["true_pond"].sum() / n,
+                "s2": rat["s2"].sum(),
+                "s2pond": rat["s2pond"].sum()}
+
+    def compute_likelihood(self, data, theta, eta, pr):
+        """src/mmsbm.py:541-553 on explicit parameters (device evaluation)."""
+        ctx = self._ctx(self._device_list()[0])
+        ctx.set_params(theta, eta, pr)
+        return ctx.likelihood()
+
+    # ------------------------------------------------------------------ cross-validation (src/mmsbm.py:371-472)
+    def cv_fit(self, data, folds=5):
+        n_items = len(set(data.iloc[:, 1]))
+        assert folds <= n_items, (
+            f"Fold number can't be higher than {n_items} since this is the number of different "
+            f"items you have.")
+        per_fold = int(n_items / folds)
+        temp = data
+        all_results = []
+        for f in range(folds):
+            self.logger.info(f"Running fold {f + 1} of {folds}...")
+            picked = []
+            for _, grp in temp.groupby(temp.columns[0]):
+                for cnt in range(per_fold, 0, -1):  # as many as the user has, at most per_fold
+                    if cnt <= len(grp.index):
+                        picked.extend(self.rng.choice(grp.index, cnt, replace=False).tolist())
+                        break
+            picked = [a for a in picked if str(a) != "0"]
+            test = temp.loc[picked, :]
+            train = data[~data.index.isin(test.index)]
+            temp = temp[~temp.index.isin(picked)]
+            self.fit(train, silent=True)
+            self.prediction_matrix = self.predict(test)
+            results = self.score(silent=True)
+            all_results.append({"stats": results["stats"],
+                                "objects": {"theta": self.theta, "eta": self.eta, "pr": self.pr,
+                                            "rat": self.prediction_matrix}})
+        accuracies = [a["stats"]["accuracy"] for a in all_results]
+        best = accuracies.index(max(accuracies))
+        self.theta = all_results[best]["objects"]["theta"]
+        self.eta = all_results[best]["objects"]["eta"]
+        self.pr = all_results[best]["objects"]["pr"]
+        self.prediction_matrix = all_results[best]["objects"]["rat"]
+        self.logger.info(f"Ran {folds} folds with accuracies {accuracies}.")
+        return accuracies

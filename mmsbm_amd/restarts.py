@@ -1,0 +1,114 @@
+"""Random restarts across GPUs: one process per GPU (``torch.distributed``; backend
+``nccl`` is RCCL on ROCm, ``gloo`` on CPU for tests), restart ``i`` on rank ``i mod W``.
+
+The reference runs restarts in a ``multiprocessing.Pool`` (src/mmsbm.py:182-185) and never
+lets them communicate.  Restarts are independent here too: there is NO collective on the
+data path.  After every rank has finished its restarts one all-reduce (MAX over a
+``sampling``-long vector that each rank fills at its own restart indices, -inf elsewhere)
+tells every rank all likelihoods, hence the maximum-likelihood run.  The parameters of all
+restarts can additionally be gathered (the reference's ``predict`` averages over all of
+them, src/mmsbm.py:297-315).
+
+torch is imported here -- before the HIP library is first loaded -- so that the process
+holds ONE HIP runtime (torch's wheel bundles its own libamdhip64).
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _lib
+
+
+def shard_restarts(sampling, rank, world):
+    """Indices of the restarts rank ``rank`` of ``world`` runs (round robin)."""
+    return list(range(rank, sampling, world))
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK/WORLD_SIZE/MASTER_* (torchrun); returns
+    (rank, world, local_rank, device).  Single process when WORLD_SIZE is unset or 1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    use_gpu = torch.cuda.is_available()
+    if use_gpu:
+        torch.cuda.set_device(local)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend or ("nccl" if use_gpu else "gloo"), rank=rank,
+                                world_size=world)
+    return rank, world, local, (torch.device("cuda", local) if use_gpu else torch.device("cpu"))
+
+
+def check_single_hip_runtime():
+    libs = _lib.loaded_hip_runtimes()
+    if len(libs) > 1:
+        raise RuntimeError("two HIP runtimes are mapped into this process (" + ", ".join(libs) +
+                           "): import torch (or mmsbm_amd.restarts) before the first HipEM is made")
+
+
+def all_likelihoods(local, sampling, device=None):
+    """local: {restart index: likelihood}.  ONE all-reduce(MAX); returns the full vector
+    (length ``sampling``) on every rank."""
+    vec = torch.full((sampling,), float("-inf"), dtype=torch.float64,
+                     device=device if device is not None else "cpu")
+    for i, lik in local.items():
+        vec[i] = float(lik)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(vec, op=dist.ReduceOp.MAX)
+    return vec.cpu().numpy()
+
+
+def pick_max_likelihood(local, sampling, device=None):
+    """(index, likelihood, all likelihoods) of the maximum-likelihood restart; ties -> lowest
+    index (np.argmax)."""
+    liks = all_likelihoods(local, sampling, device)
+    best = int(np.argmax(liks))
+    return best, float(liks[best]), liks
+
+
+def gather_results(local_results, sampling):
+    """local_results: {restart index: result dict}.  Every rank gets the list of all
+    ``sampling`` results in restart order."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [local_results[i] for i in range(sampling)]
+    parts = [None] * dist.get_world_size()
+    dist.all_gather_object(parts, local_results)
+    merged = {}
+    for part in parts:
+        merged.update(part)
+    return [merged[i] for i in range(sampling)]
+
+
+def fit_distributed(model, train, runner=None, gather=True, device=None):
+    """Run ``model.sampling`` restarts sharded over the ranks of the current process group.
+
+    model  : an ``mmsbm_amd.MMSBM`` (only ``sampling`` / ``child_states`` are used when a
+             ``runner`` is given).
+    runner : ``runner(i, child_seed) -> result dict``; default runs the restart on this
+             rank's GPU through ``model.run_one_sampling``.
+    Returns (best index, best likelihood, likelihood vector); ``model.results`` holds all
+    restarts (``gather``) or this rank's share.
+    """
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    mine = shard_restarts(model.sampling, rank, world)
+    if runner is None:
+        local_dev = device.index if (device is not None and device.type == "cuda") else 0
+        model._prepare_objects(train)
+        check_single_hip_runtime()
+
+        def runner(i, seed):
+            return model.run_one_sampling(train, seed, i, device=local_dev)
+    local = {i: runner(i, model.child_states[i]) for i in mine}
+    best, best_lik, liks = pick_max_likelihood({i: r["likelihood"] for i, r in local.items()},
+                                               model.sampling, device)
+    model.best_by_likelihood = best
+    model.results = gather_results(local, model.sampling) if gather else [local[i] for i in mine]
+    model._restart_ids = list(range(model.sampling)) if gather else mine
+    return best, best_lik, liks

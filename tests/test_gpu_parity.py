@@ -1,0 +1,292 @@
+"""Parity of the HIP path (through the C ABI) with the oracle and the reference-generated
+golden vectors.  Needs a real MI355X: run with ``-m gpu``."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, rel_err
+from oracle import mmsbm_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+# Tolerances (float64 everywhere; the HIP path re-associates the sums):
+TOL_STEP = 1e-12   # one update_coefficients call, relative to max |want|
+TOL_LOOP = 1e-9    # after tens..hundreds of EM iterations (north_star bar: 1e-5)
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from mmsbm_amd import _lib
+    if _lib.device_count() < 1:
+        pytest.fail("-m gpu tests need a GPU: no HIP device visible (no CPU fallback exists)")
+    import mmsbm_amd
+    return mmsbm_amd
+
+
+def make_ctx(hip, data, theta, eta, pr, **kw):
+    em = hip.HipEM(data, theta.shape[1], eta.shape[1], theta.shape[0], eta.shape[0], pr.shape[2], **kw)
+    em.set_params(theta, eta, pr)
+    return em
+
+
+def test_reference_backend_test_vectors(hip):
+    """The inputs of the reference's tests/test_backends.py, at its tolerance (atol 1e-8) and ours."""
+    g = load_golden("g0_backend_tests")
+    from mmsbm_amd import kernels_hip
+    for tag in "ab":
+        args = (g["data"], g[f"{tag}_theta"], g[f"{tag}_eta"], g[f"{tag}_pr"])
+        om = kernels_hip.compute_omegas(*args)
+        assert om.shape == (3, 2, 2) and np.allclose(om, g[f"{tag}_omegas"], atol=1e-8)
+        assert np.array_equal(om, g[f"{tag}_omegas"])  # same association order -> bit exact
+        pdist = kernels_hip.prod_dist(*args)
+        assert np.allclose(pdist, g[f"{tag}_prod_dist"], atol=1e-8)
+        assert np.allclose(pdist, g[f"{tag}_prod_dist"], rtol=1e-14, atol=1e-16)
+        for got, nm in zip(kernels_hip.update_coefficients(*args), ("n_theta", "n_eta", "n_pr")):
+            assert rel_err(got, g[f"{tag}_{nm}"]) < TOL_STEP, nm
+    kernels_hip.clear_cache()
+
+
+def test_level1_contract_semantics(hip):
+    from mmsbm_amd import kernels_hip, load_backend
+    fns = load_backend("hip")
+    assert fns[3] == "hip" and fns[1] is kernels_hip.update_coefficients
+    assert load_backend("auto")[3] == "hip"
+    g = load_golden("g4_2k_k10")
+    data = g["train"]
+    theta, eta, pr = g["theta_0"].copy(), g["eta_0"].copy(), g["pr_0"].copy()
+    keep = [a.copy() for a in (data, theta, eta, pr)]
+    strided = np.asfortranarray(data)  # the reference passes whatever pandas gave it
+    out1 = kernels_hip.update_coefficients(strided, theta, eta, pr)
+    out2 = kernels_hip.update_coefficients(data, theta, eta, pr)
+    for a, b, nm in zip(out1, out2, ("n_theta", "n_eta", "n_pr")):
+        assert np.array_equal(a, b)  # bitwise reproducible, cached context or not
+        assert a.flags.owndata or a.base is None
+        assert rel_err(a, g[f"{nm}_1"]) < TOL_STEP
+    for a, b in zip((data, theta, eta, pr), keep):
+        assert np.array_equal(a, b)  # inputs never mutated
+    with pytest.raises(ValueError):
+        kernels_hip.update_coefficients(data, theta, eta, pr[:, :-1])
+    kernels_hip.clear_cache()
+
+
+@pytest.mark.parametrize("tag", ["zero", "dup", "tiny", "mix"])
+def test_edge_cases(hip, tag):
+    g = load_golden("edge_cases")
+    data, theta, eta, pr = (g[f"{tag}_{x}"] for x in ("data", "theta", "eta", "pr"))
+    with make_ctx(hip, data, theta, eta, pr) as em:
+        for got, nm in zip(em.update_coefficients(), ("n_theta", "n_eta", "n_pr")):
+            assert np.allclose(got, g[f"{tag}_{nm}"], rtol=1e-12, atol=1e-300), nm
+        if tag == "zero":  # zero-row guard of normalize_with_self
+            em.iterate(1)
+            p1 = em.get_params()[2]
+            assert np.allclose(p1, g["zero_pr_norm"], rtol=1e-12, atol=0)
+            assert np.all(p1[1] == 0)
+        if tag in ("tiny", "mix"):
+            lik = em.likelihood()
+            assert lik == pytest.approx(float(g[f"{tag}_likelihood"]), rel=1e-12)
+        if tag == "dup":
+            assert np.array_equal(em.compute_omegas(), g["dup_omegas"])
+            assert np.allclose(em.prod_dist(data), g["dup_prod_dist"], rtol=1e-13, atol=1e-16)
+
+
+def test_c1_500_iterations_vs_reference(hip):
+    """BASELINE config 0: 100 ratings, K=2, L=4, 500 iterations, seed 1."""
+    g = load_golden("g1_c1_mock")
+    train = g["train"]
+    with make_ctx(hip, train, g["c1_theta_0"], g["c1_eta_0"], g["c1_pr_0"]) as em:
+        d_u, d_i = em.degrees()
+        assert np.array_equal(d_u, g["d_u"]) and np.array_equal(d_i, g["d_i"])
+        assert np.array_equal(em.compute_omegas(), g["c1_omegas_0"])
+        assert em.likelihood() == pytest.approx(float(g["c1_likelihood_at"][0]), rel=1e-12)
+        for got, nm in zip(em.update_coefficients(), ("n_theta", "n_eta", "n_pr")):
+            assert rel_err(got, g[f"c1_{nm}_1"]) < TOL_STEP
+        done = 0
+        for it in (1, 10, 500):
+            em.iterate(it - done)
+            done = it
+            for got, nm in zip(em.get_params(), ("theta", "eta", "pr")):
+                assert rel_err(got, g[f"c1_{nm}_{it}"]) < TOL_LOOP, (it, nm)
+        assert em.likelihood() == pytest.approx(-9.470339454833308, rel=1e-9)
+
+
+def test_g4_50_iterations_and_swapped_sides(hip):
+    g = load_golden("g4_2k_k10")
+    outs = []
+    for swap in (0, 1):
+        with make_ctx(hip, g["train"], g["theta_0"], g["eta_0"], g["pr_0"], swap_sides=swap) as em:
+            assert em.swapped == bool(swap)
+            for got, nm in zip(em.update_coefficients(), ("n_theta", "n_eta", "n_pr")):
+                assert rel_err(got, g[f"{nm}_1"]) < TOL_STEP, (swap, nm)
+            em.iterate(50)
+            params = em.get_params()
+            for got, nm in zip(params, ("theta", "eta", "pr")):
+                assert rel_err(got, g[f"{nm}_50"]) < TOL_LOOP, (swap, nm)
+            assert em.likelihood() == pytest.approx(float(g["likelihood_50"]), rel=1e-10)
+            pdist = em.prod_dist(g["train"])
+            assert np.allclose(pdist, g["prod_dist_50"], rtol=1e-9, atol=1e-14)
+            outs.append(params)
+            if swap:
+                om = em.compute_omegas()
+                assert np.array_equal(om, orc.compute_omegas(g["train"], *params))
+
+
+@pytest.mark.parametrize("k,l,r", [(1, 1, 2), (3, 5, 4), (7, 2, 3), (16, 17, 5), (33, 50, 6),
+                                   (70, 9, 3), (130, 20, 2), (20, 140, 2), (260, 6, 2)])
+def test_padded_and_wide_group_shapes(hip, k, l, r):
+    """Odd K/L (zero padding), every (lanes-per-row, vector width) instantiation."""
+    rng = np.random.default_rng(k * 1000 + l)
+    data = orc.synthetic_triples(1500, 120, 60, r, seed=k + l)
+    n_u, n_i, n_r = (int(data[:, j].max()) + 1 for j in range(3))
+    d_u, d_i = orc.degrees(data, n_u, n_i)
+    theta, eta, pr = orc.init_params(rng.integers(1 << 30), n_u, n_i, n_r, k, l, d_u, d_i)
+    with make_ctx(hip, data, theta, eta, pr) as em:
+        want = orc.update_coefficients(data, theta, eta, pr)
+        for got, w, nm in zip(em.update_coefficients(), want, ("n_theta", "n_eta", "n_pr")):
+            assert rel_err(got, w) < TOL_STEP, nm
+        em.iterate(3)
+        for _ in range(3):
+            theta, eta, pr = orc.em_step(data, theta, eta, pr, d_u, d_i)
+        for got, w, nm in zip(em.get_params(), (theta, eta, pr), ("theta", "eta", "pr")):
+            assert rel_err(got, w) < 1e-11, nm
+        assert em.likelihood() == pytest.approx(float(orc.compute_likelihood(data, theta, eta, pr)), rel=1e-11)
+        assert np.allclose(em.prod_dist(data[:100]), orc.prod_dist(data[:100], theta, eta, pr),
+                           rtol=1e-11, atol=1e-15)
+
+
+def test_skewed_degrees_and_empty_ids(hip):
+    """One user holds a third of the rows; some users / items / ratings have no rows at all."""
+    rng = np.random.default_rng(5)
+    n = 6000
+    u = np.where(rng.random(n) < 0.33, 7, rng.integers(0, 400, n))
+    i = np.where(rng.random(n) < 0.2, 3, rng.integers(0, 50, n))
+    r = rng.integers(0, 4, n)
+    r[r == 2] = 3  # rating 2 never observed
+    data = np.stack([u, i, r], axis=1).astype(np.int64)
+    n_u, n_i, n_r, k, l = 410, 55, 5, 6, 12  # ids 400..409 / 50..54 / rating 4 unused
+    theta = rng.random((n_u, k)); eta = rng.random((n_i, l))
+    pr = orc.normalize_with_self(rng.random((k, l, n_r)))
+    with make_ctx(hip, data, theta, eta, pr) as em:
+        want = orc.update_coefficients(data, theta, eta, pr)
+        for got, w, nm in zip(em.update_coefficients(), want, ("n_theta", "n_eta", "n_pr")):
+            assert rel_err(got, w) < TOL_STEP, nm
+        d_u, d_i = em.degrees()
+        assert d_u[405] == 1 and d_u[7] == np.sum(u == 7)
+        em.iterate(2)
+        du = np.maximum(np.bincount(u, minlength=n_u), 1); di = np.maximum(np.bincount(i, minlength=n_i), 1)
+        for _ in range(2):
+            theta, eta, pr = orc.em_step(data, theta, eta, pr, du, di)
+        for got, w, nm in zip(em.get_params(), (theta, eta, pr), ("theta", "eta", "pr")):
+            assert rel_err(got, w) < 1e-11, nm
+
+
+def test_bitwise_reproducible(hip):
+    g = load_golden("g4_2k_k10")
+    runs = []
+    for _ in range(2):
+        with make_ctx(hip, g["train"], g["theta_0"], g["eta_0"], g["pr_0"]) as em:
+            em.iterate(20)
+            runs.append(em.get_params() + (em.likelihood(),))
+    for a, b in zip(*runs):
+        assert np.array_equal(a, b)
+
+
+def test_host_class_reference_end_to_end_case(hip):
+    """MMSBM(2, 2, iterations=10, seed=1) on mock_data(1) / mock_data(2): the numbers the
+    reference's tests/test_mmsbm.py:53-102 assert, and the exact reference outputs."""
+    g = load_golden("g1_c1_mock")
+    import pandas as pd
+    def frame(prefix):
+        return pd.DataFrame({"users": g[prefix + "_users"], "items": g[prefix + "_items"],
+                             "ratings": g[prefix + "_ratings"]})
+    mm = hip.MMSBM(2, 2, iterations=10, seed=1, backend="hip")
+    mm.fit(frame("train_raw"), silent=True)
+    assert mm._backend == "hip"
+    res = mm.results[0]
+    assert set(res) == {"likelihood", "pr", "theta", "eta"}
+    for nm in ("theta", "eta", "pr"):
+        assert rel_err(res[nm], g[f"t_{nm}"]) < TOL_LOOP, nm
+    assert float(res["likelihood"]) == pytest.approx(-13.773187406968459, rel=1e-9)
+    pm = mm.predict(frame("test_raw"))
+    assert pm.sum() == pytest.approx(100, 0.01)
+    assert np.allclose(pm, g["t_prediction_matrix"], rtol=1e-8, atol=1e-12)
+    assert np.array_equal(np.argmax(pm, 1), g["t_argmax"])  # identical argmax predictions
+    sc = mm.score(silent=True)
+    want = dict(zip(g["t_stats_keys"].tolist(), g["t_stats_vals"].tolist()))
+    assert sc["stats"]["accuracy"] == pytest.approx(0.13, 0.01)
+    assert sc["stats"]["one_off_accuracy"] == pytest.approx(0.55, 0.01)
+    assert sc["stats"]["mae"] == pytest.approx(0.78, 0.01)
+    assert sc["stats"]["s2"] == want["s2"] == 153
+    assert sc["stats"]["s2pond"] == pytest.approx(129.4766730930339, rel=1e-9)
+    assert sc["objects"]["theta"].sum(axis=0)[0] == pytest.approx(2.11, 0.1)
+    assert sc["objects"]["eta"].sum(axis=0)[0] == pytest.approx(5.93, 0.1)
+    assert set(sc["objects"]["pr"].keys()) == {"1", "2", "3", "4", "5"}
+
+
+def test_host_class_sampling3_matches_reference(hip):
+    g = load_golden("g2_c1_sampling3")
+    mm = hip.MMSBM(2, 2, iterations=10, sampling=3, seed=1, backend="auto")
+    mm.fit_encoded(g["train"])
+    liks = np.array([r["likelihood"] for r in mm.results])
+    assert np.allclose(liks, g["likelihoods"], rtol=1e-9)
+    assert mm.best_by_likelihood == int(np.argmax(g["likelihoods"]))
+    for s in range(3):
+        assert rel_err(mm.results[s]["theta"], g[f"theta_{s}"]) < TOL_LOOP
+    one = hip.MMSBM(2, 2, iterations=10, sampling=1, seed=1).fit_encoded(g["train"])
+    assert np.array_equal(one.results[0]["theta"], mm.results[0]["theta"])  # independent of sampling
+
+
+def test_c2_50_iterations_sampled_entries_and_argmax(hip):
+    """BASELINE config 1 (100k ratings, 10k x 5k, K=L=10) against entries sampled from the
+    reference's run; argmax parity with the tie rule of SURVEY section 7.3 item 6."""
+    g = load_golden("g5_c2_sampled")
+    train = orc.synthetic_triples(int(g["n"]), int(g["u"]), int(g["i"]), int(g["r"]), int(g["gen_seed"]))
+    assert np.array_equal(train[:64], g["train_head"])
+    mm = hip.MMSBM(10, 10, iterations=50, seed=int(g["model_seed"]))
+    mm._prepare_objects(train)
+    ctx = mm._ctx(0)
+    d_u, d_i = ctx.degrees()
+    ctx.set_params(*mm.init_params(mm.child_states[0], d_u, d_i))
+    done = 0
+    for it in (1, 10, 50):
+        ctx.iterate(it - done)
+        done = it
+        t, e, p = ctx.get_params()
+        assert rel_err(t[g["ut"], g["kt"]], g[f"theta_s_{it}"]) < TOL_LOOP, it
+        assert rel_err(e[g["ie"], g["le"]], g[f"eta_s_{it}"]) < TOL_LOOP, it
+        assert rel_err(p, g[f"pr_{it}"]) < TOL_LOOP, it
+        assert rel_err(t.sum(0), g[f"theta_colsum_{it}"]) < TOL_LOOP
+        assert ctx.likelihood() == pytest.approx(float(g["likelihood_at"][(1, 10, 50).index(it)]), rel=1e-9)
+    pdist = ctx.prod_dist(train)
+    clear = g["gap_50"] > 1e-9
+    assert np.array_equal(np.argmax(pdist, 1)[clear], g["argmax_50"][clear])
+    assert clear.mean() > 0.99
+
+
+def test_c3_full_size_invariants(hip):
+    """BASELINE config 2 (1M ratings, 100k x 20k, R=5, K=L=20): size-independent properties.
+    sum_kl inc = 1 per triple  =>  rows of n_theta sum to d_u, of n_eta to d_i, n_p sums to N;
+    after an iteration theta / eta rows and p[k,l,:] sum to 1; a 3,000-triple slice of the
+    SAME parameters agrees with the oracle on the rows it touches."""
+    train = orc.synthetic_triples(1_000_000, 100_000, 20_000, 5, seed=0)
+    n_u, n_i, n_r = (int(train[:, j].max()) + 1 for j in range(3))
+    assert n_u == 99_997
+    mm = hip.MMSBM(20, 20, iterations=3, seed=0)
+    mm._prepare_objects(train)
+    ctx = mm._ctx(0)
+    d_u, d_i = ctx.degrees()
+    assert np.array_equal(d_u, np.bincount(train[:, 0])) and np.array_equal(d_i, np.bincount(train[:, 1]))
+    theta, eta, pr = mm.init_params(mm.child_states[0], d_u, d_i)
+    ctx.set_params(theta, eta, pr)
+    n_t, n_e, n_p = ctx.update_coefficients()
+    assert np.allclose(n_t.sum(1), d_u, rtol=1e-12)
+    assert np.allclose(n_e.sum(1), d_i, rtol=1e-12)
+    assert n_p.sum() == pytest.approx(len(train), rel=1e-12)
+    assert np.allclose(n_p.sum(axis=(0, 1)), np.bincount(train[:, 2]), rtol=1e-12)
+    # oracle on one user block: all rows of users < 300 (n_theta of those users is complete)
+    sub = train[train[:, 0] < 300]
+    w_t, _, _ = orc.update_coefficients(sub, theta, eta, pr)
+    assert rel_err(n_t[:300], w_t[:300]) < TOL_STEP
+    ctx.iterate(3)
+    t, e, p = ctx.get_params()
+    assert np.allclose(t.sum(1), 1, atol=1e-13) and np.allclose(e.sum(1), 1, atol=1e-13)
+    assert np.allclose(p.sum(2), 1, atol=1e-13)
+    assert np.isfinite(ctx.likelihood())

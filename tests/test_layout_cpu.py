@@ -1,0 +1,110 @@
+"""Host-side layout builder (mmsbm_amd/csrc/layout.hpp through the C ABI) -- no GPU needed."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, rel_err
+from mmsbm_amd import _lib
+from mmsbm_amd.core import build_layout
+from oracle import mmsbm_oracle as orc
+
+import emulate
+
+
+def random_triples(rng, n, u, i, r, dense=True):
+    d = np.stack([rng.integers(0, u, n), rng.integers(0, i, n), rng.integers(0, r, n)], axis=1)
+    return d.astype(np.int64)
+
+
+def check_invariants(data, n_users, n_items, n_ratings, lay):
+    n = len(data)
+    u, i, r = data[:, 0], data[:, 1], data[:, 2]
+    # distinct (rating, item) pairs, rating-major
+    keys = np.unique(r * n_items + i)
+    assert len(lay["pair_item"]) == len(keys)
+    assert np.array_equal(lay["pair_item"], keys % n_items)
+    assert np.array_equal(np.diff(lay["rating_off"]), np.bincount(keys // n_items, minlength=n_ratings))
+    assert lay["pair_off"][0] == 0 and lay["pair_off"][-1] == n
+    # triples per pair, users ascending inside a pair
+    order = np.lexsort((u, i, r))
+    assert np.array_equal(lay["pair_user"], u[order])
+    cnt = np.unique(r * n_items + i, return_counts=True)[1]
+    assert np.array_equal(np.diff(lay["pair_off"]), cnt)
+    # user order
+    assert np.array_equal(np.diff(lay["user_off"]), np.bincount(u, minlength=n_users))
+    pair_id = np.searchsorted(keys, r * n_items + i)
+    for uu in range(min(n_users, 50)):
+        got = lay["user_pair"][lay["user_off"][uu]:lay["user_off"][uu + 1]]
+        assert np.array_equal(got, np.sort(pair_id[u == uu]))
+    # pairs of each item, ascending rating
+    assert np.array_equal(lay["item_deg"], np.bincount(i, minlength=n_items))
+    for ii in range(min(n_items, 50)):
+        got = lay["item_pairs"][lay["item_off"][ii]:lay["item_off"][ii + 1]]
+        assert np.array_equal(got, np.nonzero(lay["pair_item"] == ii)[0])
+    # chunks tile every rating's pair range exactly once and never straddle ratings
+    ch = lay["chunks"]
+    covered = np.zeros(len(keys), dtype=int)
+    for rr, qb, qe, _ in ch:
+        assert lay["rating_off"][rr] <= qb < qe <= lay["rating_off"][rr + 1]
+        covered[qb:qe] += 1
+    assert np.all(covered == 1)
+    assert np.array_equal(np.diff(lay["chunk_off"]), np.bincount(ch[:, 0], minlength=n_ratings)
+                          if len(ch) else np.zeros(n_ratings, dtype=int))
+
+
+@pytest.mark.parametrize("n,u,i,r,chunks", [(1, 1, 1, 1, 4), (100, 5, 10, 5, 4), (5000, 300, 40, 7, 16),
+                                            (20000, 50, 2000, 3, 1024), (3000, 3000, 2, 2, 8)])
+def test_layout_invariants(n, u, i, r, chunks):
+    rng = np.random.default_rng(n + u)
+    data = random_triples(rng, n, u, i, r)
+    lay = build_layout(data, u, i, r, target_chunks=chunks)
+    check_invariants(data, u, i, r, lay)
+
+
+def test_layout_with_duplicates_and_absent_ids():
+    # user 3 and item 1 never occur, rating 1 never occurs, rows duplicated
+    data = np.array([[0, 0, 0], [0, 0, 0], [2, 2, 2], [4, 0, 2], [0, 0, 2], [4, 2, 0]], dtype=np.int64)
+    lay = build_layout(data, 5, 3, 3, target_chunks=2)
+    check_invariants(data, 5, 3, 3, lay)
+    assert lay["user_off"][4] - lay["user_off"][3] == 0
+    assert lay["rating_off"][2] == lay["rating_off"][1]
+
+
+def test_layout_empty():
+    lay = build_layout(np.zeros((0, 3), dtype=np.int64), 3, 2, 2)
+    assert len(lay["pair_item"]) == 0 and lay["user_off"].tolist() == [0, 0, 0, 0]
+    assert len(lay["chunks"]) == 0
+
+
+def test_layout_rejects_out_of_range_ids():
+    bad = np.array([[0, 0, 0], [5, 0, 0]], dtype=np.int64)
+    with pytest.raises(_lib.HipLibraryError) as exc:
+        build_layout(bad, 5, 1, 1)
+    assert exc.value.code == _lib.E_INVALID and "out of range" in exc.value.message
+
+
+@pytest.mark.parametrize("fixture,names", [
+    ("g4_2k_k10", ("theta_0", "eta_0", "pr_0", "n_theta_1", "n_eta_1", "n_pr_1")),
+    ("g1_c1_mock", ("c1_theta_0", "c1_eta_0", "c1_pr_0", "c1_n_theta_1", "c1_n_eta_1", "c1_n_pr_1")),
+])
+def test_factorised_form_matches_reference_numerators(fixture, names):
+    """The re-associated sums the kernels use == the reference's dense ones (golden vectors)."""
+    g = load_golden(fixture)
+    train = g["train"]
+    theta, eta, pr = g[names[0]], g[names[1]], g[names[2]]
+    lay = build_layout(train, theta.shape[0], eta.shape[0], pr.shape[2], target_chunks=7)
+    got = emulate.iteration(lay, theta, eta, pr)
+    for a, nm in zip(got, names[3:]):
+        assert rel_err(a, g[nm]) < 1e-13, nm
+
+
+def test_factorised_form_edge_cases():
+    g = load_golden("edge_cases")
+    for tag in ("zero", "dup", "tiny", "mix"):
+        data, theta, eta, pr = (g[f"{tag}_{x}"] for x in ("data", "theta", "eta", "pr"))
+        lay = build_layout(data, theta.shape[0], eta.shape[0], pr.shape[2], target_chunks=3)
+        got = emulate.iteration(lay, theta, eta, pr)
+        for a, nm in zip(got, ("n_theta", "n_eta", "n_pr")):
+            want = g[f"{tag}_{nm}"]
+            # 'tiny': the reference's (theta*eta)*p underflows to exactly 0 where the factorised
+            # theta*(p.eta) keeps a denormal ~1e-315 -- an absolute floor far below any tolerance
+            assert np.allclose(a, want, rtol=1e-12, atol=1e-300), (tag, nm)
