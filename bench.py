@@ -64,7 +64,7 @@ def main():
     ap.add_argument("--cpu-sample-rows", type=int, default=100_000)
     ap.add_argument("--cpu-iters", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--eager", action="store_true", help="plain launches instead of hipGraph replay")
+    ap.add_argument("--graph", action="store_true", help="replay a captured hipGraph instead of eager launches")
     args = ap.parse_args()
 
     from mmsbm_amd import restarts  # imports torch first, then the library
@@ -85,7 +85,7 @@ def main():
     model._prepare_objects(train)
     restarts.check_single_hip_runtime()
     ctx = model._ctx(local)
-    ctx.set_graph_mode(not args.eager)
+    ctx.set_graph_mode(1 if args.graph else 0)
     d_u, d_i = ctx.degrees()
     ctx.set_params(*model.init_params(model.child_states[rank], d_u, d_i))  # restart `rank`
 
@@ -131,7 +131,7 @@ def main():
             "config": {"workload": f"{args.config.upper()}: {n} synthetic ratings, {model.p + 1} users x "
                                    f"{model.m + 1} items, R={r}, K={k}, L={l}, one restart per GPU "
                                    f"(sampling={world}), uniform generator seed 0, model seed 0",
-                       "launch": "eager" if args.eager else "hipGraph",
+                       "launch": "hipGraph replay" if args.graph else "eager",
                        "pairs": ctx.n_pairs},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,

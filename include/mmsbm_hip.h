@@ -108,7 +108,7 @@ int mmsbm_hip_prod_dist(mmsbm_hip_ctx *ctx, int64_t n_pairs, const int32_t *user
 /* Runs n_iters EM iterations bracketed by HIP events on the context's stream; returns
  * the elapsed device time of the whole region in milliseconds (synchronises). */
 int mmsbm_hip_time_iterations(mmsbm_hip_ctx *ctx, int n_iters, float *elapsed_ms);
-/* Number of distinct kernels in one EM iteration and their names. */
+/* Number of kernel launches in one EM iteration and their names. */
 int mmsbm_hip_kernel_count(void);
 const char *mmsbm_hip_kernel_name(int index);
 /* Runs n_iters iterations with a HIP event pair around EVERY kernel launch (on the
@@ -120,7 +120,13 @@ int mmsbm_hip_profile_iterations(mmsbm_hip_ctx *ctx, int n_iters, float *mean_us
  * accounting is stated in DESIGN.md. */
 int mmsbm_hip_kernel_bytes(const mmsbm_hip_ctx *ctx, int index, int64_t *bytes_read,
                            int64_t *bytes_written);
-/* 0 = eager launches, 1 = replay a captured hipGraph of two iterations (default). */
+/* Tuning aid: launches ONE stage of the iteration (index as in mmsbm_hip_kernel_name) `reps`
+ * times back to back on the context's stream and returns the mean time per launch.  The
+ * stage's outputs overwrite scratch/next buffers: call set_params again before trusting the
+ * context's state. */
+int mmsbm_hip_time_stage(mmsbm_hip_ctx *ctx, int stage, int reps, float *mean_us);
+/* How em_iterate launches: 0 (default) = eager launches on the context's stream; 1 = replay
+ * a captured hipGraph of two iterations. */
 int mmsbm_hip_set_graph_mode(mmsbm_hip_ctx *ctx, int enabled);
 
 /* ---- host-only helpers (no device needed) ------------------------------------------- */

@@ -157,8 +157,15 @@ class HipEM:
                                                          int(rd.value), int(wr.value))
         return out
 
-    def set_graph_mode(self, enabled):
-        _lib.call("mmsbm_hip_set_graph_mode", self._h, int(bool(enabled)))
+    def time_stage(self, stage, reps=50):
+        """Mean microseconds of `reps` back-to-back launches of one stage (clobbers state)."""
+        us = C.c_float(0.0)
+        _lib.call("mmsbm_hip_time_stage", self._h, int(stage), int(reps), C.byref(us))
+        return float(us.value)
+
+    def set_graph_mode(self, mode):
+        """0 eager launches (default), 1 replay a captured hipGraph of two iterations."""
+        _lib.call("mmsbm_hip_set_graph_mode", self._h, int(mode))
 
 
 def build_layout(data, n_users, n_items, n_ratings, target_chunks=1024):

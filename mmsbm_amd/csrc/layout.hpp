@@ -43,7 +43,12 @@ struct Layout {
   std::vector<Chunk> chunks;
   std::vector<int32_t> chunk_off;    // n_ratings+1 : chunk range of each rating
   int32_t chunk_pairs = 0;           // max pairs per chunk
+  // fixed-size (<= kMvChunkPairs) rating-homogeneous chunks for the lane-per-pair mat-vecs
+  std::vector<Chunk> mv_chunks;
+  std::vector<int32_t> mv_chunk_off;  // n_ratings+1
 };
+
+constexpr int32_t kMvChunkPairs = 128;  // two 64-pair units per workgroup
 
 inline void build_layout(int64_t n_obs, int32_t n_users, int32_t n_items, int32_t n_ratings,
                          const int32_t *user, const int32_t *item, const int32_t *rating,
@@ -123,10 +128,15 @@ inline void build_layout(int64_t n_obs, int32_t n_users, int32_t n_items, int32_
   cp = (cp + 15) / 16 * 16;
   L.chunk_pairs = cp;
   L.chunk_off.assign(size_t(n_ratings) + 1, 0);
+  L.mv_chunk_off.assign(size_t(n_ratings) + 1, 0);
   for (int r = 0; r < n_ratings; ++r) {
     for (int32_t q = L.rating_off[r]; q < L.rating_off[r + 1]; q += cp)
       L.chunks.push_back(Chunk{r, q, std::min<int32_t>(q + cp, L.rating_off[r + 1]), 0});
     L.chunk_off[r + 1] = int32_t(L.chunks.size());
+    for (int32_t q = L.rating_off[r]; q < L.rating_off[r + 1]; q += kMvChunkPairs)
+      L.mv_chunks.push_back(
+          Chunk{r, q, std::min<int32_t>(q + kMvChunkPairs, L.rating_off[r + 1]), 0});
+    L.mv_chunk_off[r + 1] = int32_t(L.mv_chunks.size());
   }
 }
 

@@ -16,7 +16,7 @@
 //   C[q,k]   = sum_{n in pair q} theta[u_n,k] w_n                (seg_pass, pair segments)
 //   T[q,l]   = sum_k p[k,l,r_q] C[q,k]                           (pair_matvec, L-side)
 //   n_eta[i,l] = eta[i,l] * sum_{q in item i} T[q,l]             (item_sum)
-//   n_p[k,l,r] = p[k,l,r] * sum_{q: r_q=r} C[q,k] eta[i_q,l]     (p_partial + p_finalize)
+//   n_p[k,l,r] = p[k,l,r] * sum_{q: r_q=r} C[q,k] eta[i_q,l]     (p_partial, p_update)
 //
 // which is the same sum re-associated: O(N K + Q K L) flops instead of O(N K L), two
 // row-gather passes over the triples (sorted user-major and (rating,item)-major), every
@@ -263,139 +263,506 @@ __global__ __launch_bounds__(kBlock) void pair_matvec_kernel(
 }
 
 // ======================================================================================
-// kernel 2: p_partial -- per chunk of pairs of one rating, the K x L partial sum
-//   S[k,l] = sum_{q in chunk} C[q,k] * eta[item(q), l]
-// C rows and gathered eta rows are staged in LDS in batches; each thread owns NACC
-// (k, l-pair) accumulators in registers.  One slab per chunk, combined by p_finalize in
-// a fixed order (deterministic, no atomics).
+// kernels 1 and 6 (fast form): pair_matvec_lane -- same contraction, one LANE per pair.
+// A wave owns 64 consecutive pairs of one rating.  Each lane copies its input row into a
+// wave-private, transposed LDS slab rowsT[d][lane] (conflict-free b64 reads); the tile
+// M_r[d][:] is the same for every lane: it is staged once per block in LDS and read with
+// broadcast ds_read_b128, so the inner loop runs at full 64-lane occupancy.
+// Outputs are produced in chunks of 4; NCH = dout/4 is a compile-time constant so the
+// row loop is branch-free.
 // ======================================================================================
-constexpr int kPBatchMax = 32;
-
-template <int NACC>
-__global__ __launch_bounds__(kBlock) void p_partial_kernel(
-    const double *__restrict__ ctab, const double *__restrict__ eta,
-    const int32_t *__restrict__ pair_item, const mmsbm::Chunk *__restrict__ chunks,
-    double *__restrict__ partial, int kp, int lp, int batch) {
+template <int NCH>
+__global__ __launch_bounds__(kBlock) void pair_matvec_lane_kernel(
+    const double *__restrict__ tiles, const double *__restrict__ in_tab,
+    const int32_t *__restrict__ gather, const mmsbm::Chunk *__restrict__ chunks,
+    double *__restrict__ out, int din, int dinp) {
+  constexpr int DOUT = NCH * 4;
   extern __shared__ double lds[];
-  double *cs = lds;                                   // [batch][kp]
-  double *es = lds + static_cast<size_t>(batch) * kp;  // [batch][lp]
   const mmsbm::Chunk ch = chunks[blockIdx.x];
-  const int lh = lp / 2, nout = kp * lh;
-  int coff[NACC], eoff[NACC];
-  double2 acc[NACC];
-#pragma unroll
-  for (int a = 0; a < NACC; ++a) {
-    const int o = min(static_cast<int>(threadIdx.x) + a * kBlock, nout - 1);
-    coff[a] = o / lh;
-    eoff[a] = (o % lh) * 2;
-    acc[a].x = 0.0;
-    acc[a].y = 0.0;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
+  double *tile = lds;                                                   // [dinp][DOUT]
+  double *rows_t = lds + static_cast<size_t>(dinp) * DOUT + static_cast<size_t>(wave) * dinp * 64;
+  {  // all waves stage the rating's tile (one coalesced pass), overlapped with the row loads
+    const double *src = tiles + static_cast<size_t>(ch.rating) * dinp * DOUT;
+    for (int t = threadIdx.x * 2; t < dinp * DOUT; t += blockDim.x * 2)
+      *reinterpret_cast<double2 *>(tile + t) = *reinterpret_cast<const double2 *>(src + t);
   }
-  for (int q0 = ch.q_begin; q0 < ch.q_end; q0 += batch) {
-    const int nb = min(batch, ch.q_end - q0);
-    __syncthreads();
-    for (int t = threadIdx.x * 2; t < nb * kp; t += kBlock * 2)
-      *reinterpret_cast<double2 *>(cs + t) =
-          *reinterpret_cast<const double2 *>(ctab + static_cast<size_t>(q0) * kp + t);
-    for (int t = threadIdx.x * 2; t < nb * lp; t += kBlock * 2) {
-      const int j = t / lp, l = t % lp;
-      *reinterpret_cast<double2 *>(es + t) = *reinterpret_cast<const double2 *>(
-          eta + static_cast<size_t>(pair_item[q0 + j]) * lp + l);
-    }
-    __syncthreads();
-    for (int j = 0; j < nb; ++j) {
+  bool first = true;
+  for (int base = ch.q_begin + wave * 64; base < ch.q_end || first; base += nwaves * 64) {
+    const int q = base + lane;
+    const bool have = q < ch.q_end;
+    const size_t row = have ? (gather ? static_cast<size_t>(gather[q]) : static_cast<size_t>(q)) : 0;
+    const double *src = in_tab + row * dinp;
+    for (int d0 = 0; d0 < dinp; d0 += 16) {  // 8 row pieces in flight per lane
+      double2 v[8];
 #pragma unroll
-      for (int a = 0; a < NACC; ++a) {
-        const double c = cs[j * kp + coff[a]];
-        const double2 e = *reinterpret_cast<const double2 *>(es + j * lp + eoff[a]);
-        acc[a].x = fma(c, e.x, acc[a].x);
-        acc[a].y = fma(c, e.y, acc[a].y);
+      for (int j = 0; j < 8; ++j)
+        v[j] = *reinterpret_cast<const double2 *>(src + min(d0 + 2 * j, dinp - 2));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int d = d0 + 2 * j;
+        if (d < dinp) {
+          rows_t[d * 64 + lane] = have ? v[j].x : 0.0;
+          rows_t[(d + 1) * 64 + lane] = have ? v[j].y : 0.0;
+        }
       }
     }
-  }
-  double *dst = partial + static_cast<size_t>(blockIdx.x) * kp * lp;
+    if (first) {
+      __syncthreads();  // tile staged (every wave of the block reaches this exactly once)
+      first = false;
+    } else {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (base >= ch.q_end) break;
+    double acc[DOUT];
 #pragma unroll
-  for (int a = 0; a < NACC; ++a) {
-    const int o = static_cast<int>(threadIdx.x) + a * kBlock;
-    if (o < nout) *reinterpret_cast<double2 *>(dst + coff[a] * lp + eoff[a]) = acc[a];
+    for (int j = 0; j < DOUT; ++j) acc[j] = 0.0;
+    for (int d = 0; d < din; ++d) {
+      const double x = rows_t[d * 64 + lane];
+      const double *trow = tile + d * DOUT;
+#pragma unroll
+      for (int j = 0; j < DOUT; j += 2) {
+        const double2 m = *reinterpret_cast<const double2 *>(trow + j);
+        acc[j] = fma(x, m.x, acc[j]);
+        acc[j + 1] = fma(x, m.y, acc[j + 1]);
+      }
+    }
+    if (have) {
+      double *dst = out + static_cast<size_t>(q) * DOUT;
+#pragma unroll
+      for (int j = 0; j < DOUT; j += 2) {
+        double2 a;
+        a.x = acc[j]; a.y = acc[j + 1];
+        *reinterpret_cast<double2 *>(dst + j) = a;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();  // rows_t is rewritten by the next trip
   }
 }
 
 // ======================================================================================
-// kernel 4: p_finalize -- n_p[r][k][l] = p[r][k][l] * sum_{chunks of r} S_chunk[k][l], then
-// normalize_with_self over r (src/expectation_maximization.py:152-155, zero rows kept).
-// Block = 64 (k,l) columns x 16 chunk-rows.  Writes p_new both as [R][Kp][Lp] and
-// transposed [R][Lp][Kp] (the tile shape pair_matvec wants for A).
+// pair_block -- the fused dense stage.  A block takes <= kUnitsPerBlock units of 64
+// consecutive pairs of ONE rating and, per unit, stages in LDS (coalesced flat copies):
+//   tile[d][:]      the rating's Din x Dout tile (p[r] or pT[r]),
+//   cst[d][pair]    the 64 input rows, transposed (C rows, or gathered eta rows),
+//   es[pair][:]     (DO_S) the 64 gathered eta rows,
+// then
+//   mat-vec : out[q,:] = sum_d in[q,d] tile[d,:]  -- lane = pair, wave = chunk of 4 outputs,
+//             results transposed through LDS and written as one contiguous 64-row block;
+//   DO_S    : S[k][l] += sum_q C[q,k] eta[i_q,l]  -- thread = (k, 4 l) slot, kept in registers
+//             across the block's units, one K x L slab per block at the end (combined by
+//             p_update in a fixed order: deterministic, no atomics).
+// T-mode: in = C (contiguous), tile = p[r] as [Kp][Lp], out = T, DO_S on.
+// A-mode: in = eta gathered by pair_item, tile = pT[r] as [Lp][Kp], out = A.
 // ======================================================================================
-constexpr int kFinCols = 64, kFinRows = 16;
+constexpr int kUnitPairs = 64;
 
-__global__ __launch_bounds__(kFinCols *kFinRows) void p_finalize_kernel(
-    const double *__restrict__ partial, const int32_t *__restrict__ chunk_off,
-    const double *__restrict__ p_old, double *__restrict__ p_new, double *__restrict__ pt_new,
-    double *__restrict__ n_p_out, int n_ratings, int kp, int lp, int normalize) {
+template <bool GATHER, bool DO_S, int NACC>
+__global__ __launch_bounds__(kBlock) void pair_block_kernel(
+    const double *__restrict__ tiles, const double *__restrict__ in_tab,
+    const double *__restrict__ e_tab, const int32_t *__restrict__ pair_item,
+    const mmsbm::Chunk *__restrict__ chunks, double *__restrict__ out,
+    double *__restrict__ partial, int din, int dinp, int doutp, int spb) {
   extern __shared__ double lds[];
-  double *red = lds;                          // [kFinRows][kFinCols]
-  double *npr = lds + kFinRows * kFinCols;    // [n_ratings][kFinCols]
-  const int tx = threadIdx.x % kFinCols, ty = threadIdx.x / kFinCols;
-  const int kl = kp * lp;
-  const int col = blockIdx.x * kFinCols + tx;
-  const bool ok = col < kl;
-  for (int r = 0; r < n_ratings; ++r) {
-    double s = 0.0;
-    if (ok)
-      for (int c = chunk_off[r] + ty; c < chunk_off[r + 1]; c += kFinRows)
-        s += partial[static_cast<size_t>(c) * kl + col];
-    red[ty * kFinCols + tx] = s;
+  constexpr int CS = kUnitPairs + 1;  // odd stride: conflict-free column AND row reads
+  double *tile = lds;                                          // [dinp][doutp]
+  double *cst = tile + static_cast<size_t>(dinp) * doutp;      // [dinp][CS]
+  double *tout = cst + static_cast<size_t>(dinp) * CS;         // [64][doutp]
+  double *es = tout + static_cast<size_t>(kUnitPairs) * doutp;  // [64][doutp]   (DO_S)
+  __shared__ int32_t rowid[kUnitPairs];
+  const mmsbm::Chunk ch = chunks[blockIdx.x];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int nch = doutp >> 2;
+
+  {  // the rating's tile: one coalesced pass
+    const double *src = tiles + static_cast<size_t>(ch.rating) * dinp * doutp;
+    for (int t = tid * 2; t < dinp * doutp; t += kBlock * 2)
+      *reinterpret_cast<double2 *>(tile + t) = *reinterpret_cast<const double2 *>(src + t);
+  }
+  // S slots (DO_S)
+  const int nsub = kBlock / spb, sub = tid / spb, slot0 = tid % spb;
+  const int nout = dinp * nch;
+  int coff[NACC], eoff[NACC];
+  double acc[NACC][4];
+#pragma unroll
+  for (int a = 0; a < NACC; ++a) {
+    const int o = min(slot0 + a * spb, nout - 1);
+    coff[a] = (o / nch) * CS;
+    eoff[a] = (o % nch) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[a][j] = 0.0;
+  }
+
+  for (int q0 = ch.q_begin; q0 < ch.q_end; q0 += kUnitPairs) {
+    const int np = min(kUnitPairs, ch.q_end - q0);
+    __syncthreads();  // previous unit fully consumed (also orders the tile staging)
+    if (GATHER || DO_S) {
+      if (tid < kUnitPairs) rowid[tid] = pair_item[q0 + min(tid, np - 1)];
+      __syncthreads();
+    }
+    {  // input rows -> cst (transposed).  Two double2 per thread in flight.
+      const int total = np * dinp;
+      for (int t0 = tid * 2; t0 < total; t0 += kBlock * 4) {
+        double2 v[2];
+        int pr[2], d[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int t = min(t0 + j * kBlock * 2, total - 2);
+          pr[j] = t / dinp;
+          d[j] = t - pr[j] * dinp;
+          const size_t row = GATHER ? static_cast<size_t>(rowid[pr[j]]) : static_cast<size_t>(q0 + pr[j]);
+          v[j] = *reinterpret_cast<const double2 *>(in_tab + row * dinp + d[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if (t0 + j * kBlock * 2 < total) {
+            cst[d[j] * CS + pr[j]] = v[j].x;
+            cst[(d[j] + 1) * CS + pr[j]] = v[j].y;
+          }
+        }
+      }
+      if (np < kUnitPairs)  // ragged tail of a rating: zero the missing columns
+        for (int t = tid; t < (kUnitPairs - np) * dinp; t += kBlock)
+          cst[(t / (kUnitPairs - np)) * CS + np + t % (kUnitPairs - np)] = 0.0;
+    }
+    if (DO_S) {  // gathered eta rows -> es (row-major)
+      const int total = np * doutp;
+      for (int t0 = tid * 2; t0 < total; t0 += kBlock * 4) {
+        double2 v[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int t = min(t0 + j * kBlock * 2, total - 2);
+          const int pr = t / doutp;
+          v[j] = *reinterpret_cast<const double2 *>(
+              e_tab + static_cast<size_t>(rowid[pr]) * doutp + (t - pr * doutp));
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int t = t0 + j * kBlock * 2;
+          if (t < total) *reinterpret_cast<double2 *>(es + t) = v[j];
+        }
+      }
+    }
     __syncthreads();
-    if (ty == 0) {
-      double tot = red[tx];
-      for (int j = 1; j < kFinRows; ++j) tot += red[j * kFinCols + tx];
-      npr[r * kFinCols + tx] = ok ? p_old[static_cast<size_t>(r) * kl + col] * tot : 0.0;
+    // ---- mat-vec: lane = pair, wave = output chunk ------------------------------------------
+    for (int c = wave; c < nch; c += kBlock / 64) {
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+      for (int d = 0; d < din; ++d) {
+        const double x = cst[d * CS + lane];
+        const double2 m0 = *reinterpret_cast<const double2 *>(tile + d * doutp + c * 4);
+        const double2 m1 = *reinterpret_cast<const double2 *>(tile + d * doutp + c * 4 + 2);
+        a0 = fma(x, m0.x, a0);
+        a1 = fma(x, m0.y, a1);
+        a2 = fma(x, m1.x, a2);
+        a3 = fma(x, m1.y, a3);
+      }
+      double2 w0, w1;
+      w0.x = a0; w0.y = a1; w1.x = a2; w1.y = a3;
+      *reinterpret_cast<double2 *>(tout + lane * doutp + c * 4) = w0;
+      *reinterpret_cast<double2 *>(tout + lane * doutp + c * 4 + 2) = w1;
+    }
+    // ---- S: thread = (k, 4 l) slot, copies split the unit's pairs --------------------------------
+    if (DO_S) {
+      for (int j = sub; j < np; j += nsub) {
+#pragma unroll
+        for (int a = 0; a < NACC; ++a) {
+          const double cv = cst[coff[a] + j];
+          const double2 e0 = *reinterpret_cast<const double2 *>(es + j * doutp + eoff[a]);
+          const double2 e1 = *reinterpret_cast<const double2 *>(es + j * doutp + eoff[a] + 2);
+          acc[a][0] = fma(cv, e0.x, acc[a][0]);
+          acc[a][1] = fma(cv, e0.y, acc[a][1]);
+          acc[a][2] = fma(cv, e1.x, acc[a][2]);
+          acc[a][3] = fma(cv, e1.y, acc[a][3]);
+        }
+      }
+    }
+    __syncthreads();
+    {  // the unit's 64 output rows are contiguous in memory: flat coalesced copy
+      double *dst = out + static_cast<size_t>(q0) * doutp;
+      const int total = np * doutp;
+      for (int t = tid * 2; t < total; t += kBlock * 2)
+        *reinterpret_cast<double2 *>(dst + t) = *reinterpret_cast<const double2 *>(tout + t);
+    }
+  }
+  if (DO_S) {
+    if (nsub == 2) {  // second copy hands its sums over through LDS (NACC == 1 here)
+      __syncthreads();
+      if (sub == 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lds[slot0 * 4 + j] = acc[0][j];
+      }
+      __syncthreads();
+      if (sub == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[0][j] += lds[slot0 * 4 + j];
+      }
+    }
+    if (sub == 0) {
+      double *dst = partial + static_cast<size_t>(blockIdx.x) * dinp * doutp;
+#pragma unroll
+      for (int a = 0; a < NACC; ++a) {
+        const int o = slot0 + a * spb;
+        if (o < nout) {
+          double2 x, y;
+          x.x = acc[a][0]; x.y = acc[a][1]; y.x = acc[a][2]; y.y = acc[a][3];
+          double *cell = dst + (o / nch) * doutp + eoff[a];
+          *reinterpret_cast<double2 *>(cell) = x;
+          *reinterpret_cast<double2 *>(cell + 2) = y;
+        }
+      }
+    }
+  }
+}
+
+// ======================================================================================
+// kernel 2: p_partial -- per chunk of pairs of one rating, the K x L partial sum
+//   S[k,l] = sum_{q in chunk} C[q,k] * eta[item(q), l]
+// C rows and gathered eta rows are staged in LDS in batches; each thread owns NACC
+// (k, l-pair) accumulators in registers.  One slab per chunk, combined by p_update in
+// a fixed order (deterministic, no atomics).
+// ======================================================================================
+// Thread slot = (k, group of 4 l); when the K x L/4 slots fit in 128 threads the block runs
+// two copies that split the pairs of a batch (combined in a fixed order at the end).  A
+// batch is as many pairs as the LDS budget holds -- normally the whole chunk, so a block
+// pays the (chunk -> item ids -> eta rows) latency chain once.
+template <int NACC>
+__global__ __launch_bounds__(kBlock) void p_partial_kernel(
+    const double *__restrict__ ctab, const double *__restrict__ eta,
+    const int32_t *__restrict__ pair_item, const mmsbm::Chunk *__restrict__ chunks,
+    double *__restrict__ partial, int kp, int lp, int batch, int spb) {
+  extern __shared__ double lds[];
+  double *cs = lds;                                   // [batch][kp]
+  double *es = lds + static_cast<size_t>(batch) * kp;  // [batch][lp]
+  const mmsbm::Chunk ch = chunks[blockIdx.x];
+  const int tid = threadIdx.x;
+  const int nsub = kBlock / spb, sub = tid / spb, slot0 = tid % spb;
+  const int lq = lp >> 2, nout = kp * lq;
+  int coff[NACC], eoff[NACC];
+  double acc[NACC][4];
+#pragma unroll
+  for (int a = 0; a < NACC; ++a) {
+    const int o = min(slot0 + a * spb, nout - 1);
+    coff[a] = o / lq;
+    eoff[a] = (o % lq) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[a][j] = 0.0;
+  }
+  const int kh = kp >> 1, lh = lp >> 1;
+  for (int q0 = ch.q_begin; q0 < ch.q_end; q0 += batch) {
+    const int nb = min(batch, ch.q_end - q0);
+    const int nc2 = nb * kh, ne2 = nb * lh;
+    __syncthreads();  // previous batch consumed
+    for (int u0 = tid; u0 < ne2; u0 += kBlock * 8) {  // gathered eta rows, 8 loads in flight
+      int it[8];
+      double2 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) it[j] = pair_item[q0 + min(u0 + j * kBlock, ne2 - 1) / lh];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int u = min(u0 + j * kBlock, ne2 - 1);
+        v[j] = *reinterpret_cast<const double2 *>(eta + static_cast<size_t>(it[j]) * lp + (u % lh) * 2);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int u = u0 + j * kBlock;
+        if (u < ne2) *reinterpret_cast<double2 *>(es + 2 * u) = v[j];
+      }
+    }
+    for (int u0 = tid; u0 < nc2; u0 += kBlock * 8) {  // C rows are contiguous
+      double2 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        v[j] = *reinterpret_cast<const double2 *>(ctab + static_cast<size_t>(q0) * kp +
+                                                  2 * min(u0 + j * kBlock, nc2 - 1));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int u = u0 + j * kBlock;
+        if (u < nc2) *reinterpret_cast<double2 *>(cs + 2 * u) = v[j];
+      }
+    }
+    __syncthreads();
+    for (int j = sub; j < nb; j += nsub) {
+#pragma unroll
+      for (int a = 0; a < NACC; ++a) {
+        const double c = cs[j * kp + coff[a]];
+        const double2 e0 = *reinterpret_cast<const double2 *>(es + j * lp + eoff[a]);
+        const double2 e1 = *reinterpret_cast<const double2 *>(es + j * lp + eoff[a] + 2);
+        acc[a][0] = fma(c, e0.x, acc[a][0]);
+        acc[a][1] = fma(c, e0.y, acc[a][1]);
+        acc[a][2] = fma(c, e1.x, acc[a][2]);
+        acc[a][3] = fma(c, e1.y, acc[a][3]);
+      }
+    }
+  }
+  if (nsub == 2) {  // second copy hands its sums over through LDS (NACC == 1 here)
+    __syncthreads();
+    if (sub == 1) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) lds[slot0 * 4 + j] = acc[0][j];
+    }
+    __syncthreads();
+    if (sub == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[0][j] += lds[slot0 * 4 + j];
+    }
+  }
+  if (sub == 0) {
+    double *dst = partial + static_cast<size_t>(blockIdx.x) * kp * lp;
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) {
+      const int o = slot0 + a * spb;
+      if (o < nout) {
+        double2 x, y;
+        x.x = acc[a][0]; x.y = acc[a][1]; y.x = acc[a][2]; y.y = acc[a][3];
+        *reinterpret_cast<double2 *>(dst + coff[a] * lp + eoff[a]) = x;
+        *reinterpret_cast<double2 *>(dst + coff[a] * lp + eoff[a] + 2) = y;
+      }
+    }
+  }
+}
+
+// ======================================================================================
+// kernel 4: p_update -- n_p[r][k][l] = p[r][k][l] * sum_{chunks c of r} S_c[k][l] (fixed
+// order: 16 strided partial sums, then a serial sum of the 16), followed by
+// normalize_with_self over r (src/expectation_maximization.py:152-155; zero rows stay
+// zero).  One block owns 64 (k,l) columns for ALL ratings, so no inter-block hand-off is
+// needed; every thread's slab loads are independent and issued back to back.  Writes
+// p_new as [R][Kp][Lp] and transposed [R][Lp][Kp]; optionally the raw numerators.
+// ======================================================================================
+constexpr int kRedCols = 64, kRedRows = 16, kRedGroup = 6;  // ratings per LDS pass
+constexpr int kRedThreads = kRedCols * kRedRows;
+
+__device__ __forceinline__ void p_update_block(
+    double (*red)[kRedRows][kRedCols], int block, const double *__restrict__ partial,
+    const int32_t *__restrict__ chunk_off, const double *__restrict__ p_old,
+    double *__restrict__ p_new, double *__restrict__ pt_new, double *__restrict__ npr,
+    int n_ratings, int kp, int lp, int normalize) {
+  const int tx = threadIdx.x % kRedCols, ty = threadIdx.x / kRedCols;
+  const int kl = kp * lp;
+  const int col = block * kRedCols + tx;
+  const bool ok = col < kl;
+  double tot_all = 0.0;  // meaningful for ty == 0
+  for (int r0 = 0; r0 < n_ratings; r0 += kRedGroup) {
+    const int nr = min(kRedGroup, n_ratings - r0);
+#pragma unroll
+    for (int j = 0; j < kRedGroup; ++j) {
+      if (j < nr) {
+        double s = 0.0;
+        if (ok) {
+          const int c1 = chunk_off[r0 + j + 1];
+          for (int c0 = chunk_off[r0 + j] + ty; c0 < c1; c0 += kRedRows * 8) {
+            double v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {  // 8 independent slab loads in flight
+              const int c = c0 + i * kRedRows;
+              v[i] = partial[static_cast<size_t>(min(c, c1 - 1)) * kl + col];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+              if (c0 + i * kRedRows < c1) s += v[i];
+          }
+        }
+        red[j][ty][tx] = s;
+      }
+    }
+    __syncthreads();
+    if (ty == 0 && ok) {
+      for (int j = 0; j < nr; ++j) {
+        double tot = red[j][0][tx];
+#pragma unroll
+        for (int i = 1; i < kRedRows; ++i) tot += red[j][i][tx];
+        const size_t e = static_cast<size_t>(r0 + j) * kl + col;
+        const double raw = p_old[e] * tot;
+        npr[e] = raw;
+        tot_all += raw;
+      }
     }
     __syncthreads();
   }
-  if (ty == 0 && ok) {
-    double tot = 0.0;
-    for (int r = 0; r < n_ratings; ++r) tot += npr[r * kFinCols + tx];
-    const double den = (tot == 0.0) ? 1.0 : tot;
+  if (ty == 0 && ok && normalize) {
+    const double den = (tot_all == 0.0) ? 1.0 : tot_all;
     const int k = col / lp, l = col % lp;
     for (int r = 0; r < n_ratings; ++r) {
-      const double raw = npr[r * kFinCols + tx];
-      if (n_p_out) n_p_out[static_cast<size_t>(r) * kl + col] = raw;
-      const double v = normalize ? raw / den : raw;
-      p_new[static_cast<size_t>(r) * kl + col] = v;
+      const size_t e = static_cast<size_t>(r) * kl + col;
+      const double v = npr[e] / den;  // this thread's own stores: program order suffices
+      p_new[e] = v;
       pt_new[static_cast<size_t>(r) * kl + static_cast<size_t>(l) * kp + k] = v;
     }
   }
 }
 
 // ======================================================================================
-// kernel 3: item_sum -- eta_new[i,:] = eta[i,:] * sum_{q in item i} T[q,:] / d_i
-// (src/mmsbm.py:249).  One group of G lanes per item.
+// item_sum -- eta_new[i,:] = eta[i,:] * sum_{q in item i} T[q,:] / d_i  (src/mmsbm.py:249).
+// One group of G lanes per item.
 // ======================================================================================
 template <int G, int VEC>
-__global__ __launch_bounds__(kBlock) void item_sum_kernel(
-    const double *__restrict__ ttab, const int32_t *__restrict__ item_off,
+__device__ __forceinline__ void item_sum_block(
+    int block, const double *__restrict__ ttab, const int32_t *__restrict__ item_off,
     const int32_t *__restrict__ item_pairs, const int32_t *__restrict__ item_deg,
     const double *__restrict__ eta, double *__restrict__ eta_new, int n_items, int lp,
     int normalize) {
-  const int it = blockIdx.x * (kBlock / G) + threadIdx.x / G;
+  constexpr int B = 4;
+  const int it = block * (static_cast<int>(blockDim.x) / G) + threadIdx.x / G;
   const int gl = threadIdx.x % G;
   if (it >= n_items || gl * VEC >= lp) return;
   const int lane_off = gl * VEC;
-  double acc[VEC], e[VEC], t[VEC];
+  double acc[VEC], e[VEC];
 #pragma unroll
   for (int v = 0; v < VEC; ++v) acc[v] = 0.0;
-  for (int j = item_off[it]; j < item_off[it + 1]; ++j) {
-    load_vec<VEC>(ttab + static_cast<size_t>(item_pairs[j]) * lp + lane_off, t);
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) acc[v] += t[v];
-  }
+  const int beg = item_off[it], end = item_off[it + 1];
   load_vec<VEC>(eta + static_cast<size_t>(it) * lp + lane_off, e);
+  for (int j = beg; j < end; j += B) {
+    int id[B];
+    double t[B][VEC];
+#pragma unroll
+    for (int b = 0; b < B; ++b) id[b] = item_pairs[min(j + b, end - 1)];
+#pragma unroll
+    for (int b = 0; b < B; ++b) load_vec<VEC>(ttab + static_cast<size_t>(id[b]) * lp + lane_off, t[b]);
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+      if (j + b < end) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] += t[b][v];
+      }
+    }
+  }
   const double d = static_cast<double>(max(item_deg[it], 1));
 #pragma unroll
   for (int v = 0; v < VEC; ++v) e[v] = normalize ? (e[v] * acc[v]) / d : e[v] * acc[v];
   store_vec<VEC>(eta_new + static_cast<size_t>(it) * lp + lane_off, e);
+}
+
+// eta_p -- the two independent updates that follow the T / slab stage share ONE launch:
+// blocks [0, nb_p) run p_update_block, the rest run item_sum_block.
+struct EtaPArgs {
+  const double *partial; const int32_t *chunk_off; const double *p_old;
+  double *p_new; double *pt_new; double *npr;
+  const double *ttab; const int32_t *item_off; const int32_t *item_pairs; const int32_t *item_deg;
+  const double *eta; double *eta_new;
+  int n_ratings, kp, lp, n_items, normalize, nb_p;
+};
+
+template <int G, int VEC>
+__global__ __launch_bounds__(kRedThreads) void eta_p_kernel(EtaPArgs a) {
+  __shared__ double red[kRedGroup][kRedRows][kRedCols];
+  if (static_cast<int>(blockIdx.x) < a.nb_p)
+    p_update_block(red, blockIdx.x, a.partial, a.chunk_off, a.p_old, a.p_new, a.pt_new, a.npr,
+                   a.n_ratings, a.kp, a.lp, a.normalize);
+  else
+    item_sum_block<G, VEC>(blockIdx.x - a.nb_p, a.ttab, a.item_off, a.item_pairs, a.item_deg,
+                           a.eta, a.eta_new, a.n_items, a.lp, a.normalize);
+}
+
+// stand-alone forms (fallback path for shapes the fused kernels do not cover)
+__global__ __launch_bounds__(kRedThreads) void p_update_kernel(
+    const double *__restrict__ partial, const int32_t *__restrict__ chunk_off,
+    const double *__restrict__ p_old, double *__restrict__ p_new, double *__restrict__ pt_new,
+    double *__restrict__ npr, int n_ratings, int kp, int lp, int normalize) {
+  __shared__ double red[kRedGroup][kRedRows][kRedCols];
+  p_update_block(red, blockIdx.x, partial, chunk_off, p_old, p_new, pt_new, npr, n_ratings, kp, lp,
+                 normalize);
 }
 
 // ======================================================================================
@@ -485,8 +852,8 @@ __global__ __launch_bounds__(kBlock) void omegas_kernel(
 // ======================================================================================
 // host side
 // ======================================================================================
-int pad_dim(int d) {
-  if (d <= 128) return (d + 1) / 2 * 2;
+int pad_dim(int d) {  // multiples of 4: 32-byte row granules, whole chunks of 4 outputs
+  if (d <= 128) return (d + 3) / 4 * 4;
   if (d <= 256) return (d + 3) / 4 * 4;
   return (d + 7) / 8 * 8;
 }
@@ -542,10 +909,9 @@ struct DevBuf {
   }
 };
 
-enum KernelId { K_SEG = 0, K_MATVEC_T, K_PPARTIAL, K_ITEMSUM, K_PFINAL, K_MATVEC_A, K_COUNT };
-const char *const kKernelNames[K_COUNT] = {"seg_pass_kernel",  "pair_matvec_kernel(T)",
-                                           "p_partial_kernel", "item_sum_kernel",
-                                           "p_finalize_kernel", "pair_matvec_kernel(A)"};
+enum KernelId { K_SEG = 0, K_DENSE, K_ETAP, K_MATVEC_A, K_COUNT };
+const char *const kKernelNames[K_COUNT] = {"seg_pass_kernel", "pair_block_kernel(T+S)",
+                                           "eta_p_kernel", "pair_block_kernel(A)"};
 
 }  // namespace
 
@@ -560,19 +926,29 @@ struct mmsbm_hip_ctx {
   int n_users = 0, n_items = 0, n_ratings = 0, k = 0, l = 0, kp = 0, lp = 0;
   int n_pairs = 0, n_chunks = 0;
   int code_k = 0, code_l = 0, nacc = 1;
+  bool fused = false;       // pair_block path (else: pair_matvec + p_partial fallback)
+  size_t lds_t = 0, lds_a = 0;
   mmsbm::Layout lay;  // host copy (degrees, sizes)
   DevBuf<int32_t> pair_off, pair_user, pair_item, user_off, user_pair, item_off, item_pairs,
-      item_deg, chunk_off, orig_u, orig_i, orig_r;
-  DevBuf<mmsbm::Chunk> chunks;
+      item_deg, chunk_off, mv_chunk_off, orig_u, orig_i, orig_r;
+  DevBuf<mmsbm::Chunk> chunks, mv_chunks;
   DevBuf<double> theta[2], eta[2], p[2], pt[2], atab, ctab, ttab, partial, npr, lik_part;
   int cur = 0;
   bool have_params = false;
-  bool graph_mode = false;
+  bool graph_mode = false;  // replay a captured two-iteration hipGraph instead of eager launches
+  hipGraphExec_t graph_exec[2] = {nullptr, nullptr};  // indexed by `cur` at capture time
   // per-launch profiling
   bool profiling = false;
   std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> prof_events;
 
+  void drop_graphs() {
+    for (auto &g : graph_exec) {
+      if (g) (void)hipGraphExecDestroy(g);
+      g = nullptr;
+    }
+  }
   ~mmsbm_hip_ctx() {
+    drop_graphs();
     for (auto &pe : prof_events) {
       (void)hipEventDestroy(pe.second.first);
       (void)hipEventDestroy(pe.second.second);
@@ -617,101 +993,201 @@ int matvec_gpb(int dinp, int doutp, int g) {
 size_t matvec_lds_bytes(int dinp, int doutp, int gpb) {
   return (static_cast<size_t>(dinp) * doutp + static_cast<size_t>(gpb) * dinp) * sizeof(double);
 }
+// p_partial: pairs per batch that the LDS budget holds; threads per copy (128 -> two copies
+// split each batch).
 int ppartial_batch(int kp, int lp) {
   const size_t per = static_cast<size_t>(kp + lp) * sizeof(double);
-  return static_cast<int>(std::min<size_t>(kPBatchMax, kLdsBudget / per));
+  return static_cast<int>(std::max<size_t>(std::min<size_t>(kLdsBudget / per, 1024), 1));
+}
+int ppartial_spb(int kp, int lp) { return (kp * (lp / 4) <= kBlock / 2) ? kBlock / 2 : kBlock; }
+
+// lane-per-pair mat-vec: waves per block the transposed row slabs allow (0: use the
+// group-per-pair kernel instead), and the compile-time bound on dout/4
+int lane_matvec_waves(int dinp, int doutp) {
+  if (doutp / 4 > 16) return 0;
+  const size_t tile = static_cast<size_t>(dinp) * doutp * sizeof(double);
+  const size_t per_wave = static_cast<size_t>(dinp) * 64 * sizeof(double);
+  if (tile + per_wave > kLdsBudget) return 0;
+  return static_cast<int>(std::min<size_t>(kBlock / 64, (kLdsBudget - tile) / per_wave));
 }
 
-// A[q,:] from (eta, pT) -- needed whenever the parameters change outside em_iterate.
-void launch_matvec_a(mmsbm_hip_ctx *c, const double *pt, const double *eta) {
-  if (c->n_chunks == 0) return;
-  LaunchScope ls(c, K_MATVEC_A);
-  const int gpb = matvec_gpb(c->lp, c->kp, group_lanes(c->code_k));
-  const size_t lds = matvec_lds_bytes(c->lp, c->kp, gpb);
+constexpr size_t kLdsMax = 160 * 1024;  // with hipFuncAttributeMaxDynamicSharedMemorySize
+
+// dynamic LDS of pair_block: tile + transposed rows + output rows (+ eta rows)
+size_t pair_block_lds(int dinp, int doutp, bool with_s) {
+  const size_t d = static_cast<size_t>(dinp) * doutp + static_cast<size_t>(dinp) * (kUnitPairs + 1) +
+                   static_cast<size_t>(kUnitPairs) * doutp * (with_s ? 2 : 1);
+  return std::max(d, static_cast<size_t>(kBlock) * 2) * sizeof(double);
+}
+
+template <class K>
+void allow_big_lds(K kernel, size_t bytes) {
+  if (bytes > kLdsBudget)
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  static_cast<int>(bytes)));
+}
+
+// fallback mat-vec (one group of lanes per pair, tile in LDS)
+void launch_group_matvec(mmsbm_hip_ctx *c, const double *tiles, const double *in_tab,
+                         const int32_t *gather, double *out, int din, int dinp, int doutp,
+                         int code_out) {
+  const int gpb = matvec_gpb(dinp, doutp, group_lanes(code_out));
+  const size_t lds = matvec_lds_bytes(dinp, doutp, gpb);
 #define CALL(G, V)                                                                          \
   pair_matvec_kernel<G, V><<<c->n_chunks, kBlock, lds, c->stream>>>(                        \
-      pt, eta, c->pair_item.ptr, c->chunks.ptr, c->atab.ptr, c->l, c->lp, c->kp, gpb)
+      tiles, in_tab, gather, c->chunks.ptr, out, din, dinp, doutp, gpb)
+  DISPATCH_GV(code_out, CALL);
+#undef CALL
+}
+
+// ---- the stages of one EM iteration ---------------------------------------------------------
+// commit: parameters advance (theta, eta, p normalised, A refreshed); otherwise the
+// un-normalised numerators are left in the "next" buffers / npr.
+void stage_seg(mmsbm_hip_ctx *c, bool commit) {  // C (pair segments) and theta_new (user segments)
+  const int cur = c->cur, nxt = cur ^ 1;
+  LaunchScope ls(c, K_SEG);
+  SegArgs sp{c->atab.ptr, c->theta[cur].ptr, c->pair_off.ptr, c->pair_user.ptr,
+             c->ctab.ptr, c->n_pairs,        0};
+  SegArgs su{c->theta[cur].ptr, c->atab.ptr,  c->user_off.ptr, c->user_pair.ptr,
+             c->theta[nxt].ptr, c->n_users,   commit ? 1 : 2};
+  const int per = kBlock / group_lanes(c->code_k);
+  const int bp = (c->n_pairs + per - 1) / per, bu = (c->n_users + per - 1) / per;
+#define CALL(G, V) \
+  seg_pass_kernel<G, V, 4><<<bp + bu, kBlock, 0, c->stream>>>(sp, su, bp, c->kp)
   DISPATCH_GV(c->code_k, CALL);
 #undef CALL
   ls.done();
 }
 
-// One EM iteration.  commit: parameters advance (theta, eta, p normalised, A refreshed);
-// otherwise the un-normalised numerators are left in the "next" buffers / npr.
-void launch_iteration(mmsbm_hip_ctx *c, bool commit) {
-  const int cur = c->cur, nxt = cur ^ 1;
-  const int gk = group_lanes(c->code_k), gl = group_lanes(c->code_l);
-  {  // ---- seg_pass: theta_new and C ------------------------------------------------------
-    LaunchScope ls(c, K_SEG);
-    SegArgs su{c->theta[cur].ptr, c->atab.ptr,  c->user_off.ptr, c->user_pair.ptr,
-               c->theta[nxt].ptr, c->n_users,   commit ? 1 : 2};
-    SegArgs sp{c->atab.ptr, c->theta[cur].ptr, c->pair_off.ptr, c->pair_user.ptr,
-               c->ctab.ptr, c->n_pairs,        0};
-    const int per = kBlock / gk;
-    const int bu = (c->n_users + per - 1) / per, bp = (c->n_pairs + per - 1) / per;
-#define CALL(G, V) \
-  seg_pass_kernel<G, V, 4><<<bu + bp, kBlock, 0, c->stream>>>(su, sp, bu, c->kp)
-    DISPATCH_GV(c->code_k, CALL);
-#undef CALL
+void stage_dense(mmsbm_hip_ctx *c) {  // T = P^T C  and the K x L slabs for p
+  if (c->n_chunks == 0) return;
+  const int cur = c->cur;
+  if (c->fused) {
+    LaunchScope ls(c, K_DENSE);
+    const int nb = static_cast<int>(c->lay.mv_chunks.size());
+    const int spb = ppartial_spb(c->kp, c->lp);
+#define PB(N)                                                                               \
+  do {                                                                                      \
+    allow_big_lds(pair_block_kernel<false, true, N>, c->lds_t);                             \
+    pair_block_kernel<false, true, N><<<nb, kBlock, c->lds_t, c->stream>>>(                 \
+        c->p[cur].ptr, c->ctab.ptr, c->eta[cur].ptr, c->pair_item.ptr, c->mv_chunks.ptr,    \
+        c->ttab.ptr, c->partial.ptr, c->k, c->kp, c->lp, spb);                              \
+  } while (0)
+    switch (c->nacc) {
+      case 1: PB(1); break;
+      case 2: PB(2); break;
+      case 4: PB(4); break;
+      case 8: PB(8); break;
+      default: PB(16); break;
+    }
+#undef PB
+    ls.done();
+    return;
+  }
+  {
+    LaunchScope ls(c, K_DENSE);
+    launch_group_matvec(c, c->p[cur].ptr, c->ctab.ptr, nullptr, c->ttab.ptr, c->k, c->kp, c->lp,
+                        c->code_l);
     ls.done();
   }
-  if (c->n_chunks > 0) {  // ---- T = P^T C ------------------------------------------------------
-    LaunchScope ls(c, K_MATVEC_T);
-    const int gpb = matvec_gpb(c->kp, c->lp, gl);
-    const size_t lds = matvec_lds_bytes(c->kp, c->lp, gpb);
-#define CALL(G, V)                                                                          \
-  pair_matvec_kernel<G, V><<<c->n_chunks, kBlock, lds, c->stream>>>(                        \
-      c->p[cur].ptr, c->ctab.ptr, nullptr, c->chunks.ptr, c->ttab.ptr, c->k, c->kp, c->lp,  \
-      gpb)
-    DISPATCH_GV(c->code_l, CALL);
-#undef CALL
-    ls.done();
-  }
-  if (c->n_chunks > 0) {  // ---- partial K x L slabs for p ---------------------------------------
-    LaunchScope ls(c, K_PPARTIAL);
-    const int batch = ppartial_batch(c->kp, c->lp);
-    const size_t lds = static_cast<size_t>(batch) * (c->kp + c->lp) * sizeof(double);
+  LaunchScope ls(c, K_DENSE);
+  const int batch = std::min(ppartial_batch(c->kp, c->lp), std::max(c->lay.chunk_pairs, 1));
+  const int spb = ppartial_spb(c->kp, c->lp);
+  const size_t lds = std::max(static_cast<size_t>(batch) * (c->kp + c->lp),
+                              static_cast<size_t>(kBlock) * 2) * sizeof(double);
 #define PP(N)                                                                               \
   p_partial_kernel<N><<<c->n_chunks, kBlock, lds, c->stream>>>(                             \
-      c->ctab.ptr, c->eta[cur].ptr, c->pair_item.ptr, c->chunks.ptr, c->partial.ptr, c->kp, \
-      c->lp, batch)
-    switch (c->nacc) {
-      case 1: PP(1); break;
-      case 2: PP(2); break;
-      case 4: PP(4); break;
-      case 8: PP(8); break;
-      case 16: PP(16); break;
-      default: PP(32); break;
-    }
+      c->ctab.ptr, c->eta[cur].ptr, c->pair_item.ptr, c->chunks.ptr, c->partial.ptr, c->kp,  \
+      c->lp, batch, spb)
+  switch (c->nacc) {
+    case 1: PP(1); break;
+    case 2: PP(2); break;
+    case 4: PP(4); break;
+    case 8: PP(8); break;
+    default: PP(16); break;
+  }
 #undef PP
-    ls.done();
-  }
-  {  // ---- eta_new -------------------------------------------------------------------------
-    LaunchScope ls(c, K_ITEMSUM);
-    const int per = kBlock / gl;
-    const int nb = (c->n_items + per - 1) / per;
-#define CALL(G, V)                                                                          \
-  item_sum_kernel<G, V><<<nb, kBlock, 0, c->stream>>>(                                      \
-      c->ttab.ptr, c->item_off.ptr, c->item_pairs.ptr, c->item_deg.ptr, c->eta[cur].ptr,    \
-      c->eta[nxt].ptr, c->n_items, c->lp, commit ? 1 : 0)
-    DISPATCH_GV(c->code_l, CALL);
+  ls.done();
+}
+
+void stage_eta_p(mmsbm_hip_ctx *c, bool commit) {  // eta_new ; p_new, pT_new, raw n_p
+  const int cur = c->cur, nxt = cur ^ 1;
+  const int kl = c->kp * c->lp;
+  LaunchScope ls(c, K_ETAP);
+  EtaPArgs a;
+  a.partial = c->partial.ptr;
+  a.chunk_off = c->fused ? c->mv_chunk_off.ptr : c->chunk_off.ptr;
+  a.p_old = c->p[cur].ptr; a.p_new = c->p[nxt].ptr; a.pt_new = c->pt[nxt].ptr; a.npr = c->npr.ptr;
+  a.ttab = c->ttab.ptr; a.item_off = c->item_off.ptr; a.item_pairs = c->item_pairs.ptr;
+  a.item_deg = c->item_deg.ptr; a.eta = c->eta[cur].ptr; a.eta_new = c->eta[nxt].ptr;
+  a.n_ratings = c->n_ratings; a.kp = c->kp; a.lp = c->lp; a.n_items = c->n_items;
+  a.normalize = commit ? 1 : 0;
+  a.nb_p = (kl + kRedCols - 1) / kRedCols;
+  const int per = kRedThreads / group_lanes(c->code_l);
+  const int nb_i = (c->n_items + per - 1) / per;
+#define CALL(G, V) eta_p_kernel<G, V><<<a.nb_p + nb_i, kRedThreads, 0, c->stream>>>(a)
+  DISPATCH_GV(c->code_l, CALL);
 #undef CALL
-    ls.done();
+  ls.done();
+}
+
+// A[q,:] from (eta, pT) of parameter slot `slot`
+void stage_matvec_a(mmsbm_hip_ctx *c, int slot) {
+  if (c->n_chunks == 0) return;
+  LaunchScope ls(c, K_MATVEC_A);
+  if (c->fused) {
+    const int nb = static_cast<int>(c->lay.mv_chunks.size());
+    allow_big_lds(pair_block_kernel<true, false, 1>, c->lds_a);
+    pair_block_kernel<true, false, 1><<<nb, kBlock, c->lds_a, c->stream>>>(
+        c->pt[slot].ptr, c->eta[slot].ptr, nullptr, c->pair_item.ptr, c->mv_chunks.ptr,
+        c->atab.ptr, nullptr, c->l, c->lp, c->kp, kBlock);
+  } else {
+    launch_group_matvec(c, c->pt[slot].ptr, c->eta[slot].ptr, c->pair_item.ptr, c->atab.ptr, c->l,
+                        c->lp, c->kp, c->code_k);
   }
-  {  // ---- p_new (+ transposed copy) ---------------------------------------------------------
-    LaunchScope ls(c, K_PFINAL);
-    const int kl = c->kp * c->lp;
-    const int nb = (kl + kFinCols - 1) / kFinCols;
-    const size_t lds = static_cast<size_t>(kFinRows + c->n_ratings) * kFinCols * sizeof(double);
-    p_finalize_kernel<<<nb, kFinCols * kFinRows, lds, c->stream>>>(
-        c->partial.ptr, c->chunk_off.ptr, c->p[cur].ptr, c->p[nxt].ptr, c->pt[nxt].ptr,
-        commit ? nullptr : c->npr.ptr, c->n_ratings, c->kp, c->lp, commit ? 1 : 0);
-    ls.done();
-  }
+  ls.done();
+}
+
+void launch_iteration(mmsbm_hip_ctx *c, bool commit) {
+  stage_seg(c, commit);
+  stage_dense(c);
+  stage_eta_p(c, commit);
   if (commit) {
-    launch_matvec_a(c, c->pt[nxt].ptr, c->eta[nxt].ptr);
-    c->cur = nxt;
+    stage_matvec_a(c, c->cur ^ 1);
+    c->cur ^= 1;
   }
+}
+
+// n committed iterations: graph replays of two iterations each when enabled, the rest eager
+void run_iterations(mmsbm_hip_ctx *c, int n) {
+  if (c->graph_mode && !c->profiling) {
+    while (n >= 2) {
+      const int slot = c->cur;
+      if (!c->graph_exec[slot]) {
+        hipGraph_t graph = nullptr;
+        HIP_CHECK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        try {
+          launch_iteration(c, true);
+          launch_iteration(c, true);
+        } catch (...) {
+          (void)hipStreamEndCapture(c->stream, &graph);
+          if (graph) (void)hipGraphDestroy(graph);
+          c->cur = slot;
+          throw;
+        }
+        HIP_CHECK(hipStreamEndCapture(c->stream, &graph));
+        hipError_t e = hipGraphInstantiate(&c->graph_exec[slot], graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (e != hipSuccess)
+          throw ApiError(MMSBM_E_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+        // capture only records: cur is back where it started and nothing has run yet
+      }
+      HIP_CHECK(hipGraphLaunch(c->graph_exec[slot], c->stream));
+      n -= 2;
+    }
+  }
+  for (; n > 0; --n) launch_iteration(c, true);
 }
 
 void require_params(const mmsbm_hip_ctx *c) {
@@ -854,20 +1330,33 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
     c->kp = pad_dim(c->k); c->lp = pad_dim(c->l);
     c->code_k = group_code(c->kp); c->code_l = group_code(c->lp);
     {
-      const int nout = c->kp * (c->lp / 2);
-      int need = (nout + kBlock - 1) / kBlock;
+      const int nout = c->kp * (c->lp / 4);
+      const int spb = ppartial_spb(c->kp, c->lp);
+      int need = (nout + spb - 1) / spb;
       int n = 1;
       while (n < need) n *= 2;
-      if (n > 32) throw ApiError(MMSBM_E_UNSUPPORTED, "K*L too large for p_partial (max 16384)");
+      if (n > 16) throw ApiError(MMSBM_E_UNSUPPORTED, "K*L too large for p_partial (max 16384)");
       c->nacc = n;
     }
+    c->lds_t = pair_block_lds(c->kp, c->lp, true);
+    c->lds_a = pair_block_lds(c->lp, c->kp, false);
+    c->fused = c->lds_t <= kLdsMax && c->lds_a <= kLdsMax;
     if (matvec_gpb(c->kp, c->lp, group_lanes(c->code_l)) < 1 ||
         matvec_gpb(c->lp, c->kp, group_lanes(c->code_k)) < 1)
       throw ApiError(MMSBM_E_UNSUPPORTED, "K*L tile does not fit the 64 KiB LDS budget");
-    if (n_ratings > 112)
-      throw ApiError(MMSBM_E_UNSUPPORTED, "more than 112 distinct ratings are not supported");
+    if (n_ratings > 65535)
+      throw ApiError(MMSBM_E_UNSUPPORTED, "more than 65535 distinct ratings are not supported");
 
-    mmsbm::build_layout(n_obs, c->n_users, c->n_items, n_ratings, iu, ii, rating, 1024, c->lay);
+    {
+      // chunks small enough for one p_partial batch, and at least ~2 per CU
+      const int cap = ppartial_batch(c->kp, c->lp);
+      int target = 512;
+      mmsbm::build_layout(n_obs, c->n_users, c->n_items, n_ratings, iu, ii, rating, target, c->lay);
+      if (c->lay.chunk_pairs > cap && cap >= 64) {
+        target = (c->lay.n_pairs + (cap / 16 * 16) - 1) / (cap / 16 * 16) + n_ratings;
+        mmsbm::build_layout(n_obs, c->n_users, c->n_items, n_ratings, iu, ii, rating, target, c->lay);
+      }
+    }
     c->n_pairs = c->lay.n_pairs;
     c->n_chunks = static_cast<int>(c->lay.chunks.size());
 
@@ -884,6 +1373,8 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
     c->item_deg.upload(c->lay.item_deg, s);
     c->chunk_off.upload(c->lay.chunk_off, s);
     c->chunks.upload(c->lay.chunks, s);
+    c->mv_chunks.upload(c->lay.mv_chunks, s);
+    c->mv_chunk_off.upload(c->lay.mv_chunk_off, s);
     {
       std::vector<int32_t> tmp;
       tmp.assign(iu, iu + n_obs); c->orig_u.upload(tmp, s);
@@ -905,12 +1396,13 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
       HIP_CHECK(hipMemsetAsync(c->pt[b].ptr, 0, sizeof(double) * klr, s));
     }
     c->atab.alloc(static_cast<size_t>(c->n_pairs) * c->kp);
+    HIP_CHECK(hipMemsetAsync(c->atab.ptr, 0, sizeof(double) * std::max<size_t>(c->atab.count, 1), s));
     c->ctab.alloc(static_cast<size_t>(c->n_pairs) * c->kp);
     c->ttab.alloc(static_cast<size_t>(c->n_pairs) * c->lp);
-    c->partial.alloc(static_cast<size_t>(std::max(c->n_chunks, 1)) * c->kp * c->lp);
+    c->partial.alloc(std::max<size_t>(std::max<size_t>(c->n_chunks, c->lay.mv_chunks.size()), 1) *
+                     c->kp * c->lp);
     c->npr.alloc(klr);
     c->lik_part.alloc(4096);
-    HIP_CHECK(hipMemsetAsync(c->atab.ptr, 0, sizeof(double) * std::max<size_t>(c->atab.count, 1), s));
     HIP_CHECK(hipStreamSynchronize(s));
     *out = c.release();
   });
@@ -964,7 +1456,7 @@ int mmsbm_hip_set_params(mmsbm_hip_ctx *ctx, const double *theta, const double *
                              hipMemcpyHostToDevice, ctx->stream));
     HIP_CHECK(hipMemcpyAsync(ctx->pt[cur].ptr, pt.data(), sizeof(double) * pt.size(),
                              hipMemcpyHostToDevice, ctx->stream));
-    launch_matvec_a(ctx, ctx->pt[cur].ptr, ctx->eta[cur].ptr);
+    stage_matvec_a(ctx, cur);
     HIP_CHECK(hipStreamSynchronize(ctx->stream));  // host staging vectors die here
     ctx->have_params = true;
   });
@@ -995,7 +1487,7 @@ int mmsbm_hip_em_iterate(mmsbm_hip_ctx *ctx, int n_iters) {
     require_params(ctx);
     if (n_iters < 0) throw std::invalid_argument("n_iters must be >= 0");
     use_device(ctx);
-    for (int it = 0; it < n_iters; ++it) launch_iteration(ctx, true);
+    run_iterations(ctx, n_iters);
   });
 }
 
@@ -1124,7 +1616,7 @@ int mmsbm_hip_time_iterations(mmsbm_hip_ctx *ctx, int n_iters, float *elapsed_ms
     HIP_CHECK(hipEventCreate(&e0));
     HIP_CHECK(hipEventCreate(&e1));
     HIP_CHECK(hipEventRecord(e0, ctx->stream));
-    for (int it = 0; it < n_iters; ++it) launch_iteration(ctx, true);
+    run_iterations(ctx, n_iters);
     HIP_CHECK(hipEventRecord(e1, ctx->stream));
     HIP_CHECK(hipEventSynchronize(e1));
     HIP_CHECK(hipEventElapsedTime(elapsed_ms, e0, e1));
@@ -1164,17 +1656,22 @@ int mmsbm_hip_kernel_bytes(const mmsbm_hip_ctx *ctx, int index, int64_t *bytes_r
   return guarded([&] {
     if (!ctx || !bytes_read || !bytes_written) throw std::invalid_argument("null argument");
     const int64_t N = ctx->n_obs, U = ctx->n_users, I = ctx->n_items, R = ctx->n_ratings;
-    const int64_t K = ctx->k, L = ctx->l, Q = ctx->n_pairs, C = ctx->n_chunks;
+    const int64_t K = ctx->k, L = ctx->l, Q = ctx->n_pairs;
+    const int64_t C = ctx->fused ? static_cast<int64_t>(ctx->lay.mv_chunks.size()) : ctx->n_chunks;
     int64_t rd = 0, wr = 0;
     switch (index) {
       case K_SEG:  // two passes: index + one gathered K-row per triple; fixed rows and offsets once
         rd = 2 * N * (4 + 8 * K) + (U + Q) * (8 * K + 4);
         wr = (U + Q) * 8 * K;
         break;
-      case K_MATVEC_T: rd = Q * 8 * K + C * 8 * K * L; wr = Q * 8 * L; break;
-      case K_PPARTIAL: rd = Q * (8 * K + 8 * L + 4); wr = C * 8 * K * L; break;
-      case K_ITEMSUM: rd = Q * (8 * L + 4) + I * (8 * L + 8); wr = I * 8 * L; break;
-      case K_PFINAL: rd = C * 8 * K * L + R * 8 * K * L; wr = 2 * R * 8 * K * L; break;
+      case K_DENSE:  // C rows + gathered eta rows + item ids + one tile per block; T rows + slabs
+        rd = Q * (8 * K + 8 * L + 4) + C * 8 * K * L;
+        wr = Q * 8 * L + C * 8 * K * L;
+        break;
+      case K_ETAP:  // slabs + p ; T rows through the item CSR + eta
+        rd = C * 8 * K * L + R * 8 * K * L + Q * (8 * L + 4) + I * (8 * L + 8);
+        wr = 3 * R * 8 * K * L + I * 8 * L;
+        break;
       case K_MATVEC_A: rd = Q * (8 * L + 4) + C * 8 * K * L; wr = Q * 8 * K; break;
       default: throw std::invalid_argument("kernel index out of range");
     }
@@ -1183,10 +1680,41 @@ int mmsbm_hip_kernel_bytes(const mmsbm_hip_ctx *ctx, int index, int64_t *bytes_r
   });
 }
 
+int mmsbm_hip_time_stage(mmsbm_hip_ctx *ctx, int stage, int reps, float *mean_us) {
+  return guarded([&] {
+    require_params(ctx);
+    if (!mean_us || reps <= 0 || stage < 0 || stage >= K_COUNT)
+      throw std::invalid_argument("bad argument");
+    use_device(ctx);
+    auto one = [&] {
+      switch (stage) {
+        case K_SEG: stage_seg(ctx, true); break;
+        case K_DENSE: stage_dense(ctx); break;
+        case K_ETAP: stage_eta_p(ctx, true); break;
+        default: stage_matvec_a(ctx, ctx->cur); break;
+      }
+    };
+    for (int w = 0; w < 3; ++w) one();
+    hipEvent_t e0, e1;
+    HIP_CHECK(hipEventCreate(&e0));
+    HIP_CHECK(hipEventCreate(&e1));
+    HIP_CHECK(hipEventRecord(e0, ctx->stream));
+    for (int r = 0; r < reps; ++r) one();
+    HIP_CHECK(hipEventRecord(e1, ctx->stream));
+    HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    *mean_us = ms * 1000.f / reps;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+  });
+}
+
 int mmsbm_hip_set_graph_mode(mmsbm_hip_ctx *ctx, int enabled) {
   return guarded([&] {
     if (!ctx) throw std::invalid_argument("null context");
     ctx->graph_mode = enabled != 0;
+    ctx->drop_graphs();
   });
 }
 
