@@ -163,6 +163,10 @@ class HipEM:
         _lib.call("mmsbm_hip_time_stage", self._h, int(stage), int(reps), C.byref(us))
         return float(us.value)
 
+    def set_option(self, name, value):
+        """Tuning knob of the library ("rolefuse", "fill0".."fill2")."""
+        _lib.call("mmsbm_hip_set_option", self._h, name.encode(), float(value))
+
     def set_graph_mode(self, mode):
         """0 eager launches (default), 1 replay a captured hipGraph of two iterations."""
         _lib.call("mmsbm_hip_set_graph_mode", self._h, int(mode))

@@ -48,7 +48,7 @@ struct Layout {
   std::vector<int32_t> mv_chunk_off;  // n_ratings+1
 };
 
-constexpr int32_t kMvChunkPairs = 128;  // two 64-pair units per workgroup
+constexpr int32_t kMvChunkPairs = 64;  // one 64-pair unit per workgroup
 
 inline void build_layout(int64_t n_obs, int32_t n_users, int32_t n_items, int32_t n_ratings,
                          const int32_t *user, const int32_t *item, const int32_t *rating,

@@ -150,12 +150,7 @@ struct SegArgs {
 };
 
 template <int G, int VEC, int B>
-__global__ __launch_bounds__(kBlock) void seg_pass_kernel(SegArgs sa, SegArgs sb,
-                                                          int blocks_a, int dp) {
-  const bool first = static_cast<int>(blockIdx.x) < blocks_a;
-  const SegArgs a = first ? sa : sb;
-  const int blk = first ? blockIdx.x : blockIdx.x - blocks_a;
-  const int seg = blk * (kBlock / G) + threadIdx.x / G;
+__device__ __forceinline__ void seg_body(const SegArgs &a, int seg, int dp) {
   const int gl = threadIdx.x % G;
   if (seg >= a.nseg) return;  // whole groups leave together
   const bool act = gl * VEC < dp;
@@ -170,25 +165,31 @@ __global__ __launch_bounds__(kBlock) void seg_pass_kernel(SegArgs sa, SegArgs sb
     for (int v = 0; v < VEC; ++v) f[v] = 0.0;
   }
 
+  // Every lane of the group fetches one index of the segment (one coalesced load per G
+  // triples); the indices are then broadcast inside the group with ds_bpermute, so the
+  // dependent chain is offsets -> indices -> rows instead of one index load per batch.
   const int beg = a.off[seg], end = a.off[seg + 1];
-  for (int n = beg; n < end; n += B) {
-    int id[B];
+  for (int c0 = beg; c0 < end; c0 += G) {
+    const int cnt = min(G, end - c0);
+    const int mine = a.idx[c0 + min(gl, cnt - 1)];
+    for (int n = 0; n < cnt; n += B) {
+      double g[B][VEC];
 #pragma unroll
-    for (int b = 0; b < B; ++b) id[b] = a.idx[min(n + b, end - 1)];
-    double g[B][VEC];
+      for (int b = 0; b < B; ++b) {
+        const int id = __shfl(mine, min(n + b, cnt - 1), G);
+        load_vec<VEC>(a.gath + static_cast<size_t>(id) * dp + lane_off, g[b]);
+      }
 #pragma unroll
-    for (int b = 0; b < B; ++b)
-      load_vec<VEC>(a.gath + static_cast<size_t>(id[b]) * dp + lane_off, g[b]);
+      for (int b = 0; b < B; ++b) {
+        if (n + b < cnt) {
+          double part = 0.0;
 #pragma unroll
-    for (int b = 0; b < B; ++b) {
-      if (n + b < end) {
-        double part = 0.0;
+          for (int v = 0; v < VEC; ++v) part = fma(g[b][v], f[v], part);
+          const double s = group_sum<G>(part);
+          const double w = 1.0 / fmax(s, kEps);
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) part = fma(g[b][v], f[v], part);
-        const double s = group_sum<G>(part);
-        const double w = 1.0 / fmax(s, kEps);
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) acc[v] = fma(g[b][v], w, acc[v]);
+          for (int v = 0; v < VEC; ++v) acc[v] = fma(g[b][v], w, acc[v]);
+        }
       }
     }
   }
@@ -207,6 +208,15 @@ __global__ __launch_bounds__(kBlock) void seg_pass_kernel(SegArgs sa, SegArgs sb
     for (int v = 0; v < VEC; ++v) o[v] = f[v] * acc[v];
   }
   store_vec<VEC>(a.out + static_cast<size_t>(seg) * dp + lane_off, o);
+}
+
+// blocks [0, blocks_a) work on segment set `sa`, the rest on `sb`
+template <int G, int VEC, int B>
+__global__ __launch_bounds__(kBlock) void seg_pass_kernel(SegArgs sa, SegArgs sb,
+                                                          int blocks_a, int dp) {
+  const bool first = static_cast<int>(blockIdx.x) < blocks_a;
+  const int blk = first ? blockIdx.x : blockIdx.x - blocks_a;
+  seg_body<G, VEC, B>(first ? sa : sb, blk * (kBlock / G) + threadIdx.x / G, dp);
 }
 
 // ======================================================================================
@@ -343,11 +353,11 @@ __global__ __launch_bounds__(kBlock) void pair_matvec_lane_kernel(
 }
 
 // ======================================================================================
-// pair_block -- the fused dense stage.  A block takes <= kUnitsPerBlock units of 64
-// consecutive pairs of ONE rating and, per unit, stages in LDS (coalesced flat copies):
+// pair_block -- the fused dense stage.  A block takes a unit of <= 64 consecutive pairs of
+// ONE rating (more if its chunk is longer) and, per unit, stages in LDS (coalesced flat copies):
 //   tile[d][:]      the rating's Din x Dout tile (p[r] or pT[r]),
 //   cst[d][pair]    the 64 input rows, transposed (C rows, or gathered eta rows),
-//   es[pair][:]     (DO_S) the 64 gathered eta rows,
+//   es[pair][:]     (DO_S) the 64 gathered eta rows (the region is reused for the output rows),
 // then
 //   mat-vec : out[q,:] = sum_d in[q,d] tile[d,:]  -- lane = pair, wave = chunk of 4 outputs,
 //             results transposed through LDS and written as one contiguous 64-row block;
@@ -359,24 +369,35 @@ __global__ __launch_bounds__(kBlock) void pair_matvec_lane_kernel(
 // ======================================================================================
 constexpr int kUnitPairs = 64;
 
+struct PairBlockArgs {
+  const double *tiles; const double *in_tab; const double *e_tab; const int32_t *pair_item;
+  const mmsbm::Chunk *chunks; double *out; double *partial;
+  int din, dinp, doutp, spb, abl;
+};
+
 template <bool GATHER, bool DO_S, int NACC>
-__global__ __launch_bounds__(kBlock) void pair_block_kernel(
-    const double *__restrict__ tiles, const double *__restrict__ in_tab,
-    const double *__restrict__ e_tab, const int32_t *__restrict__ pair_item,
-    const mmsbm::Chunk *__restrict__ chunks, double *__restrict__ out,
-    double *__restrict__ partial, int din, int dinp, int doutp, int spb) {
+__device__ __forceinline__ void pair_block_body(const PairBlockArgs &pa, int block) {
+  const double *__restrict__ tiles = pa.tiles;
+  const double *__restrict__ in_tab = pa.in_tab;
+  const double *__restrict__ e_tab = pa.e_tab;
+  const int32_t *__restrict__ pair_item = pa.pair_item;
+  double *__restrict__ out = pa.out;
+  double *__restrict__ partial = pa.partial;
+  const int din = pa.din, dinp = pa.dinp, doutp = pa.doutp, spb = pa.spb, abl = pa.abl;
+  // abl: tuning aid, normally 0 -- bit0 rows, bit1 eta rows, bit2 S, bit3 mat-vec, bit4 output
+  // copy, bit5 slab store, bit6 tile staging are skipped when set
   extern __shared__ double lds[];
   constexpr int CS = kUnitPairs + 1;  // odd stride: conflict-free column AND row reads
   double *tile = lds;                                          // [dinp][doutp]
   double *cst = tile + static_cast<size_t>(dinp) * doutp;      // [dinp][CS]
-  double *tout = cst + static_cast<size_t>(dinp) * CS;         // [64][doutp]
-  double *es = tout + static_cast<size_t>(kUnitPairs) * doutp;  // [64][doutp]   (DO_S)
+  double *es = cst + static_cast<size_t>(dinp) * CS;  // [64][doutp]  gathered eta rows (DO_S) ...
+  double *tout = es;                                  // ... then the mat-vec's output rows
   __shared__ int32_t rowid[kUnitPairs];
-  const mmsbm::Chunk ch = chunks[blockIdx.x];
+  const mmsbm::Chunk ch = pa.chunks[block];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int nch = doutp >> 2;
 
-  {  // the rating's tile: one coalesced pass
+  if (!(abl & 64)) {  // the rating's tile: one coalesced pass
     const double *src = tiles + static_cast<size_t>(ch.rating) * dinp * doutp;
     for (int t = tid * 2; t < dinp * doutp; t += kBlock * 2)
       *reinterpret_cast<double2 *>(tile + t) = *reinterpret_cast<const double2 *>(src + t);
@@ -400,9 +421,9 @@ __global__ __launch_bounds__(kBlock) void pair_block_kernel(
     __syncthreads();  // previous unit fully consumed (also orders the tile staging)
     if (GATHER || DO_S) {
       if (tid < kUnitPairs) rowid[tid] = pair_item[q0 + min(tid, np - 1)];
-      __syncthreads();
+      if (GATHER) __syncthreads();
     }
-    {  // input rows -> cst (transposed).  Two double2 per thread in flight.
+    if (!(abl & 1)) {  // input rows -> cst (transposed).  Two double2 per thread in flight.
       const int total = np * dinp;
       for (int t0 = tid * 2; t0 < total; t0 += kBlock * 4) {
         double2 v[2];
@@ -427,7 +448,8 @@ __global__ __launch_bounds__(kBlock) void pair_block_kernel(
         for (int t = tid; t < (kUnitPairs - np) * dinp; t += kBlock)
           cst[(t / (kUnitPairs - np)) * CS + np + t % (kUnitPairs - np)] = 0.0;
     }
-    if (DO_S) {  // gathered eta rows -> es (row-major)
+    if (DO_S && !GATHER) __syncthreads();  // item ids visible
+    if (DO_S && !(abl & 2)) {  // gathered eta rows -> es (row-major)
       const int total = np * doutp;
       for (int t0 = tid * 2; t0 < total; t0 += kBlock * 4) {
         double2 v[2];
@@ -446,40 +468,66 @@ __global__ __launch_bounds__(kBlock) void pair_block_kernel(
       }
     }
     __syncthreads();
+    // ---- S: thread = (k, 4 l) slot, copies split the unit's pairs --------------------------------
+    if (DO_S) {
+      if (!(abl & 4))
+      for (int j0 = sub; j0 < np; j0 += 4 * nsub) {  // 4 pairs' operands in flight per slot
+        double cv[NACC][4];
+        double2 e0[NACC][4], e1[NACC][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int j = min(j0 + i * nsub, np - 1);
+#pragma unroll
+          for (int a = 0; a < NACC; ++a) {
+            cv[a][i] = cst[coff[a] + j];
+            e0[a][i] = *reinterpret_cast<const double2 *>(es + j * doutp + eoff[a]);
+            e1[a][i] = *reinterpret_cast<const double2 *>(es + j * doutp + eoff[a] + 2);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (j0 + i * nsub < np) {
+#pragma unroll
+            for (int a = 0; a < NACC; ++a) {
+              acc[a][0] = fma(cv[a][i], e0[a][i].x, acc[a][0]);
+              acc[a][1] = fma(cv[a][i], e0[a][i].y, acc[a][1]);
+              acc[a][2] = fma(cv[a][i], e1[a][i].x, acc[a][2]);
+              acc[a][3] = fma(cv[a][i], e1[a][i].y, acc[a][3]);
+            }
+          }
+        }
+      }
+      __syncthreads();  // es is dead: its space becomes tout
+    }
     // ---- mat-vec: lane = pair, wave = output chunk ------------------------------------------
-    for (int c = wave; c < nch; c += kBlock / 64) {
+    for (int c = wave; c < nch && !(abl & 8); c += kBlock / 64) {
       double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-      for (int d = 0; d < din; ++d) {
-        const double x = cst[d * CS + lane];
-        const double2 m0 = *reinterpret_cast<const double2 *>(tile + d * doutp + c * 4);
-        const double2 m1 = *reinterpret_cast<const double2 *>(tile + d * doutp + c * 4 + 2);
-        a0 = fma(x, m0.x, a0);
-        a1 = fma(x, m0.y, a1);
-        a2 = fma(x, m1.x, a2);
-        a3 = fma(x, m1.y, a3);
+      // rows d >= din of the tile and of the inputs are zero padding, dinp is a multiple of 4:
+      // four rows' operands are fetched from LDS before any of them is used
+      for (int d = 0; d < dinp; d += 4) {
+        double x[4];
+        double2 m0[4], m1[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          x[i] = cst[(d + i) * CS + lane];
+          m0[i] = *reinterpret_cast<const double2 *>(tile + (d + i) * doutp + c * 4);
+          m1[i] = *reinterpret_cast<const double2 *>(tile + (d + i) * doutp + c * 4 + 2);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          a0 = fma(x[i], m0[i].x, a0);
+          a1 = fma(x[i], m0[i].y, a1);
+          a2 = fma(x[i], m1[i].x, a2);
+          a3 = fma(x[i], m1[i].y, a3);
+        }
       }
       double2 w0, w1;
       w0.x = a0; w0.y = a1; w1.x = a2; w1.y = a3;
       *reinterpret_cast<double2 *>(tout + lane * doutp + c * 4) = w0;
       *reinterpret_cast<double2 *>(tout + lane * doutp + c * 4 + 2) = w1;
     }
-    // ---- S: thread = (k, 4 l) slot, copies split the unit's pairs --------------------------------
-    if (DO_S) {
-      for (int j = sub; j < np; j += nsub) {
-#pragma unroll
-        for (int a = 0; a < NACC; ++a) {
-          const double cv = cst[coff[a] + j];
-          const double2 e0 = *reinterpret_cast<const double2 *>(es + j * doutp + eoff[a]);
-          const double2 e1 = *reinterpret_cast<const double2 *>(es + j * doutp + eoff[a] + 2);
-          acc[a][0] = fma(cv, e0.x, acc[a][0]);
-          acc[a][1] = fma(cv, e0.y, acc[a][1]);
-          acc[a][2] = fma(cv, e1.x, acc[a][2]);
-          acc[a][3] = fma(cv, e1.y, acc[a][3]);
-        }
-      }
-    }
     __syncthreads();
-    {  // the unit's 64 output rows are contiguous in memory: flat coalesced copy
+    if (!(abl & 16)) {  // the unit's 64 output rows are contiguous in memory: flat coalesced copy
       double *dst = out + static_cast<size_t>(q0) * doutp;
       const int total = np * doutp;
       for (int t = tid * 2; t < total; t += kBlock * 2)
@@ -499,8 +547,8 @@ __global__ __launch_bounds__(kBlock) void pair_block_kernel(
         for (int j = 0; j < 4; ++j) acc[0][j] += lds[slot0 * 4 + j];
       }
     }
-    if (sub == 0) {
-      double *dst = partial + static_cast<size_t>(blockIdx.x) * dinp * doutp;
+    if (sub == 0 && !(abl & 32)) {
+      double *dst = partial + static_cast<size_t>(block) * dinp * doutp;
 #pragma unroll
       for (int a = 0; a < NACC; ++a) {
         const int o = slot0 + a * spb;
@@ -514,6 +562,25 @@ __global__ __launch_bounds__(kBlock) void pair_block_kernel(
       }
     }
   }
+}
+
+template <bool GATHER, bool DO_S, int NACC>
+__global__ __launch_bounds__(kBlock) void pair_block_kernel(PairBlockArgs pa) {
+  pair_block_body<GATHER, DO_S, NACC>(pa, blockIdx.x);
+}
+
+// Role-fused form: the first nb_dense blocks are pair_block units, the rest are filler --
+// a slice of the user segments of seg_pass (bandwidth-bound, no LDS), so that the
+// LDS/latency-bound dense stage and the gather pass share the machine inside ONE launch.
+template <bool GATHER, bool DO_S, int NACC, int G, int VEC>
+__global__ __launch_bounds__(kBlock) void pair_block_fill_kernel(PairBlockArgs pa, int nb_dense,
+                                                                 SegArgs fill, int fill_seg0,
+                                                                 int dp) {
+  if (static_cast<int>(blockIdx.x) < nb_dense)
+    pair_block_body<GATHER, DO_S, NACC>(pa, blockIdx.x);
+  else
+    seg_body<G, VEC, 4>(fill, fill_seg0 + (blockIdx.x - nb_dense) * (kBlock / G) + threadIdx.x / G,
+                        dp);
 }
 
 // ======================================================================================
@@ -625,17 +692,19 @@ __global__ __launch_bounds__(kBlock) void p_partial_kernel(
 
 // ======================================================================================
 // kernel 4: p_update -- n_p[r][k][l] = p[r][k][l] * sum_{chunks c of r} S_c[k][l] (fixed
-// order: 16 strided partial sums, then a serial sum of the 16), followed by
+// order: 64 strided partial sums, then 8 sums of 8, then a sum of 8), followed by
 // normalize_with_self over r (src/expectation_maximization.py:152-155; zero rows stay
-// zero).  One block owns 64 (k,l) columns for ALL ratings, so no inter-block hand-off is
+// zero).  One block owns 16 (k,l) columns for ALL ratings, so no inter-block hand-off is
 // needed; every thread's slab loads are independent and issued back to back.  Writes
 // p_new as [R][Kp][Lp] and transposed [R][Lp][Kp]; optionally the raw numerators.
 // ======================================================================================
-constexpr int kRedCols = 64, kRedRows = 16, kRedGroup = 6;  // ratings per LDS pass
-constexpr int kRedThreads = kRedCols * kRedRows;
+constexpr int kRedCols = 16, kRedRows = 64, kRedGroup = 6;  // ratings per LDS pass
+constexpr int kRedThreads = kRedCols * kRedRows, kRedBatch = 4;
+constexpr int kRedRowsSmall = kBlock / kRedCols;  // the 256-thread form used inside fused launches
 
+template <int ROWS>
 __device__ __forceinline__ void p_update_block(
-    double (*red)[kRedRows][kRedCols], int block, const double *__restrict__ partial,
+    double (*red)[ROWS][kRedCols], int block, const double *__restrict__ partial,
     const int32_t *__restrict__ chunk_off, const double *__restrict__ p_old,
     double *__restrict__ p_new, double *__restrict__ pt_new, double *__restrict__ npr,
     int n_ratings, int kp, int lp, int normalize) {
@@ -646,33 +715,56 @@ __device__ __forceinline__ void p_update_block(
   double tot_all = 0.0;  // meaningful for ty == 0
   for (int r0 = 0; r0 < n_ratings; r0 += kRedGroup) {
     const int nr = min(kRedGroup, n_ratings - r0);
+    int c0[kRedGroup], c1[kRedGroup];
+    double s[kRedGroup];
+    int longest = 0;
 #pragma unroll
     for (int j = 0; j < kRedGroup; ++j) {
-      if (j < nr) {
-        double s = 0.0;
-        if (ok) {
-          const int c1 = chunk_off[r0 + j + 1];
-          for (int c0 = chunk_off[r0 + j] + ty; c0 < c1; c0 += kRedRows * 8) {
-            double v[8];
+      const int r = min(r0 + j, n_ratings - 1);
+      c0[j] = chunk_off[r];
+      c1[j] = (j < nr) ? chunk_off[r + 1] : c0[j];
+      longest = max(longest, c1[j] - c0[j]);
+      s[j] = 0.0;
+    }
+    if (ok) {
+      for (int off = ty; off < longest; off += ROWS * kRedBatch) {
+        double v[kRedGroup][kRedBatch];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {  // 8 independent slab loads in flight
-              const int c = c0 + i * kRedRows;
-              v[i] = partial[static_cast<size_t>(min(c, c1 - 1)) * kl + col];
-            }
+        for (int j = 0; j < kRedGroup; ++j)
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
-              if (c0 + i * kRedRows < c1) s += v[i];
+          for (int i = 0; i < kRedBatch; ++i) {  // every rating's slab loads issued together
+            const int c = c0[j] + off + i * ROWS;
+            v[j][i] = (c < c1[j]) ? partial[static_cast<size_t>(c) * kl + col] : 0.0;
           }
-        }
-        red[j][ty][tx] = s;
+#pragma unroll
+        for (int j = 0; j < kRedGroup; ++j)
+#pragma unroll
+          for (int i = 0; i < kRedBatch; ++i) s[j] += v[j][i];
       }
+    }
+#pragma unroll
+    for (int j = 0; j < kRedGroup; ++j) red[j][ty][tx] = s[j];
+    __syncthreads();
+    if (ty < 8) {  // ROWS rows -> 8 partial sums (fixed order)
+#pragma unroll
+      for (int j = 0; j < kRedGroup; ++j) {
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < ROWS / 8; ++i) t += red[j][ty * (ROWS / 8) + i][tx];
+        s[j] = t;
+      }
+    }
+    __syncthreads();
+    if (ty < 8) {
+#pragma unroll
+      for (int j = 0; j < kRedGroup; ++j) red[j][ty][tx] = s[j];
     }
     __syncthreads();
     if (ty == 0 && ok) {
       for (int j = 0; j < nr; ++j) {
         double tot = red[j][0][tx];
 #pragma unroll
-        for (int i = 1; i < kRedRows; ++i) tot += red[j][i][tx];
+        for (int i = 1; i < 8; ++i) tot += red[j][i][tx];
         const size_t e = static_cast<size_t>(r0 + j) * kl + col;
         const double raw = p_old[e] * tot;
         npr[e] = raw;
@@ -748,11 +840,27 @@ template <int G, int VEC>
 __global__ __launch_bounds__(kRedThreads) void eta_p_kernel(EtaPArgs a) {
   __shared__ double red[kRedGroup][kRedRows][kRedCols];
   if (static_cast<int>(blockIdx.x) < a.nb_p)
-    p_update_block(red, blockIdx.x, a.partial, a.chunk_off, a.p_old, a.p_new, a.pt_new, a.npr,
-                   a.n_ratings, a.kp, a.lp, a.normalize);
+    p_update_block<kRedRows>(red, blockIdx.x, a.partial, a.chunk_off, a.p_old, a.p_new, a.pt_new,
+                             a.npr, a.n_ratings, a.kp, a.lp, a.normalize);
   else
     item_sum_block<G, VEC>(blockIdx.x - a.nb_p, a.ttab, a.item_off, a.item_pairs, a.item_deg,
                            a.eta, a.eta_new, a.n_items, a.lp, a.normalize);
+}
+
+// Role-fused, 256-thread form: [p_update | item_sum | filler user segments of seg_pass]
+template <int G2, int VEC2, int G, int VEC>
+__global__ __launch_bounds__(kBlock) void eta_p_fill_kernel(EtaPArgs a, int nb_i, SegArgs fill,
+                                                            int fill_seg0, int dp) {
+  __shared__ double red[kRedGroup][kRedRowsSmall][kRedCols];
+  const int b = blockIdx.x;
+  if (b < a.nb_p)
+    p_update_block<kRedRowsSmall>(red, b, a.partial, a.chunk_off, a.p_old, a.p_new, a.pt_new, a.npr,
+                                  a.n_ratings, a.kp, a.lp, a.normalize);
+  else if (b < a.nb_p + nb_i)
+    item_sum_block<G2, VEC2>(b - a.nb_p, a.ttab, a.item_off, a.item_pairs, a.item_deg, a.eta,
+                             a.eta_new, a.n_items, a.lp, a.normalize);
+  else
+    seg_body<G, VEC, 4>(fill, fill_seg0 + (b - a.nb_p - nb_i) * (kBlock / G) + threadIdx.x / G, dp);
 }
 
 // stand-alone forms (fallback path for shapes the fused kernels do not cover)
@@ -761,8 +869,8 @@ __global__ __launch_bounds__(kRedThreads) void p_update_kernel(
     const double *__restrict__ p_old, double *__restrict__ p_new, double *__restrict__ pt_new,
     double *__restrict__ npr, int n_ratings, int kp, int lp, int normalize) {
   __shared__ double red[kRedGroup][kRedRows][kRedCols];
-  p_update_block(red, blockIdx.x, partial, chunk_off, p_old, p_new, pt_new, npr, n_ratings, kp, lp,
-                 normalize);
+  p_update_block<kRedRows>(red, blockIdx.x, partial, chunk_off, p_old, p_new, pt_new, npr, n_ratings,
+                           kp, lp, normalize);
 }
 
 // ======================================================================================
@@ -910,8 +1018,10 @@ struct DevBuf {
 };
 
 enum KernelId { K_SEG = 0, K_DENSE, K_ETAP, K_MATVEC_A, K_COUNT };
-const char *const kKernelNames[K_COUNT] = {"seg_pass_kernel", "pair_block_kernel(T+S)",
-                                           "eta_p_kernel", "pair_block_kernel(A)"};
+// With role fusion (the normal path) launch 0 holds the pair segments only and launches 1-3
+// carry slices of the user segments as filler blocks next to their dense blocks.
+const char *const kKernelNames[K_COUNT] = {"seg_pass_kernel", "pair_block(T+S)|user-fill",
+                                           "eta_p|user-fill", "pair_block(A)|user-fill"};
 
 }  // namespace
 
@@ -926,13 +1036,16 @@ struct mmsbm_hip_ctx {
   int n_users = 0, n_items = 0, n_ratings = 0, k = 0, l = 0, kp = 0, lp = 0;
   int n_pairs = 0, n_chunks = 0;
   int code_k = 0, code_l = 0, nacc = 1;
+  int ablate = 0;           // tuning aid (mmsbm_hip_time_stage): phases pair_block skips
   bool fused = false;       // pair_block path (else: pair_matvec + p_partial fallback)
+  bool rolefuse = false;    // user segments ride as filler blocks inside the dense launches
+  float fill_frac[3] = {0.55f, 0.20f, 0.25f};  // share of the user segments per dense launch
   size_t lds_t = 0, lds_a = 0;
   mmsbm::Layout lay;  // host copy (degrees, sizes)
   DevBuf<int32_t> pair_off, pair_user, pair_item, user_off, user_pair, item_off, item_pairs,
       item_deg, chunk_off, mv_chunk_off, orig_u, orig_i, orig_r;
   DevBuf<mmsbm::Chunk> chunks, mv_chunks;
-  DevBuf<double> theta[2], eta[2], p[2], pt[2], atab, ctab, ttab, partial, npr, lik_part;
+  DevBuf<double> theta[2], eta[2], p[2], pt[2], atab[2], ctab, ttab, partial, npr, lik_part;
   int cur = 0;
   bool have_params = false;
   bool graph_mode = false;  // replay a captured two-iteration hipGraph instead of eager launches
@@ -1015,8 +1128,9 @@ constexpr size_t kLdsMax = 160 * 1024;  // with hipFuncAttributeMaxDynamicShared
 
 // dynamic LDS of pair_block: tile + transposed rows + output rows (+ eta rows)
 size_t pair_block_lds(int dinp, int doutp, bool with_s) {
+  (void)with_s;  // the eta rows and the output rows share one region
   const size_t d = static_cast<size_t>(dinp) * doutp + static_cast<size_t>(dinp) * (kUnitPairs + 1) +
-                   static_cast<size_t>(kUnitPairs) * doutp * (with_s ? 2 : 1);
+                   static_cast<size_t>(kUnitPairs) * doutp;
   return std::max(d, static_cast<size_t>(kBlock) * 2) * sizeof(double);
 }
 
@@ -1044,19 +1158,50 @@ void launch_group_matvec(mmsbm_hip_ctx *c, const double *tiles, const double *in
 // ---- the stages of one EM iteration ---------------------------------------------------------
 // commit: parameters advance (theta, eta, p normalised, A refreshed); otherwise the
 // un-normalised numerators are left in the "next" buffers / npr.
-void stage_seg(mmsbm_hip_ctx *c, bool commit) {  // C (pair segments) and theta_new (user segments)
+SegArgs seg_pairs_args(const mmsbm_hip_ctx *c) {  // C = sum over a pair's triples
+  return SegArgs{c->atab[c->cur].ptr, c->theta[c->cur].ptr, c->pair_off.ptr, c->pair_user.ptr,
+                 c->ctab.ptr,         c->n_pairs,            0};
+}
+SegArgs seg_users_args(const mmsbm_hip_ctx *c, bool commit, int seg_end) {  // theta_new
+  return SegArgs{c->theta[c->cur].ptr,     c->atab[c->cur].ptr, c->user_off.ptr, c->user_pair.ptr,
+                 c->theta[c->cur ^ 1].ptr, seg_end,             commit ? 1 : 2};
+}
+PairBlockArgs pair_block_t_args(const mmsbm_hip_ctx *c) {
+  return PairBlockArgs{c->p[c->cur].ptr, c->ctab.ptr,        c->eta[c->cur].ptr, c->pair_item.ptr,
+                       c->mv_chunks.ptr, c->ttab.ptr,        c->partial.ptr,     c->k,
+                       c->kp,            c->lp,              ppartial_spb(c->kp, c->lp), c->ablate};
+}
+PairBlockArgs pair_block_a_args(const mmsbm_hip_ctx *c, int param_slot, int a_slot) {
+  return PairBlockArgs{c->pt[param_slot].ptr, c->eta[param_slot].ptr, nullptr, c->pair_item.ptr,
+                       c->mv_chunks.ptr,      c->atab[a_slot].ptr,    nullptr, c->l,
+                       c->lp,                 c->kp,                  kBlock,  c->ablate};
+}
+EtaPArgs eta_p_args(const mmsbm_hip_ctx *c, bool commit, int cols_per_block) {
   const int cur = c->cur, nxt = cur ^ 1;
+  EtaPArgs a;
+  a.partial = c->partial.ptr;
+  a.chunk_off = c->fused ? c->mv_chunk_off.ptr : c->chunk_off.ptr;
+  a.p_old = c->p[cur].ptr; a.p_new = c->p[nxt].ptr; a.pt_new = c->pt[nxt].ptr; a.npr = c->npr.ptr;
+  a.ttab = c->ttab.ptr; a.item_off = c->item_off.ptr; a.item_pairs = c->item_pairs.ptr;
+  a.item_deg = c->item_deg.ptr; a.eta = c->eta[cur].ptr; a.eta_new = c->eta[nxt].ptr;
+  a.n_ratings = c->n_ratings; a.kp = c->kp; a.lp = c->lp; a.n_items = c->n_items;
+  a.normalize = commit ? 1 : 0;
+  a.nb_p = (c->kp * c->lp + cols_per_block - 1) / cols_per_block;
+  return a;
+}
+
+void stage_seg(mmsbm_hip_ctx *c, bool commit, bool with_users) {
   LaunchScope ls(c, K_SEG);
-  SegArgs sp{c->atab.ptr, c->theta[cur].ptr, c->pair_off.ptr, c->pair_user.ptr,
-             c->ctab.ptr, c->n_pairs,        0};
-  SegArgs su{c->theta[cur].ptr, c->atab.ptr,  c->user_off.ptr, c->user_pair.ptr,
-             c->theta[nxt].ptr, c->n_users,   commit ? 1 : 2};
+  const SegArgs sp = seg_pairs_args(c), su = seg_users_args(c, commit, c->n_users);
   const int per = kBlock / group_lanes(c->code_k);
-  const int bp = (c->n_pairs + per - 1) / per, bu = (c->n_users + per - 1) / per;
+  const int bp = (c->n_pairs + per - 1) / per;
+  const int bu = with_users ? (c->n_users + per - 1) / per : 0;
+  if (bp + bu > 0) {
 #define CALL(G, V) \
   seg_pass_kernel<G, V, 4><<<bp + bu, kBlock, 0, c->stream>>>(sp, su, bp, c->kp)
-  DISPATCH_GV(c->code_k, CALL);
+    DISPATCH_GV(c->code_k, CALL);
 #undef CALL
+  }
   ls.done();
 }
 
@@ -1066,13 +1211,11 @@ void stage_dense(mmsbm_hip_ctx *c) {  // T = P^T C  and the K x L slabs for p
   if (c->fused) {
     LaunchScope ls(c, K_DENSE);
     const int nb = static_cast<int>(c->lay.mv_chunks.size());
-    const int spb = ppartial_spb(c->kp, c->lp);
+    const PairBlockArgs pa = pair_block_t_args(c);
 #define PB(N)                                                                               \
   do {                                                                                      \
     allow_big_lds(pair_block_kernel<false, true, N>, c->lds_t);                             \
-    pair_block_kernel<false, true, N><<<nb, kBlock, c->lds_t, c->stream>>>(                 \
-        c->p[cur].ptr, c->ctab.ptr, c->eta[cur].ptr, c->pair_item.ptr, c->mv_chunks.ptr,    \
-        c->ttab.ptr, c->partial.ptr, c->k, c->kp, c->lp, spb);                              \
+    pair_block_kernel<false, true, N><<<nb, kBlock, c->lds_t, c->stream>>>(pa);             \
   } while (0)
     switch (c->nacc) {
       case 1: PB(1); break;
@@ -1112,18 +1255,8 @@ void stage_dense(mmsbm_hip_ctx *c) {  // T = P^T C  and the K x L slabs for p
 }
 
 void stage_eta_p(mmsbm_hip_ctx *c, bool commit) {  // eta_new ; p_new, pT_new, raw n_p
-  const int cur = c->cur, nxt = cur ^ 1;
-  const int kl = c->kp * c->lp;
   LaunchScope ls(c, K_ETAP);
-  EtaPArgs a;
-  a.partial = c->partial.ptr;
-  a.chunk_off = c->fused ? c->mv_chunk_off.ptr : c->chunk_off.ptr;
-  a.p_old = c->p[cur].ptr; a.p_new = c->p[nxt].ptr; a.pt_new = c->pt[nxt].ptr; a.npr = c->npr.ptr;
-  a.ttab = c->ttab.ptr; a.item_off = c->item_off.ptr; a.item_pairs = c->item_pairs.ptr;
-  a.item_deg = c->item_deg.ptr; a.eta = c->eta[cur].ptr; a.eta_new = c->eta[nxt].ptr;
-  a.n_ratings = c->n_ratings; a.kp = c->kp; a.lp = c->lp; a.n_items = c->n_items;
-  a.normalize = commit ? 1 : 0;
-  a.nb_p = (kl + kRedCols - 1) / kRedCols;
+  const EtaPArgs a = eta_p_args(c, commit, kRedCols);
   const int per = kRedThreads / group_lanes(c->code_l);
   const int nb_i = (c->n_items + per - 1) / per;
 #define CALL(G, V) eta_p_kernel<G, V><<<a.nb_p + nb_i, kRedThreads, 0, c->stream>>>(a)
@@ -1132,29 +1265,127 @@ void stage_eta_p(mmsbm_hip_ctx *c, bool commit) {  // eta_new ; p_new, pT_new, r
   ls.done();
 }
 
-// A[q,:] from (eta, pT) of parameter slot `slot`
-void stage_matvec_a(mmsbm_hip_ctx *c, int slot) {
+// A[q,:] from (eta, pT) of parameter slot `slot` into atab[a_slot]
+void stage_matvec_a(mmsbm_hip_ctx *c, int slot, int a_slot) {
   if (c->n_chunks == 0) return;
   LaunchScope ls(c, K_MATVEC_A);
   if (c->fused) {
     const int nb = static_cast<int>(c->lay.mv_chunks.size());
     allow_big_lds(pair_block_kernel<true, false, 1>, c->lds_a);
     pair_block_kernel<true, false, 1><<<nb, kBlock, c->lds_a, c->stream>>>(
-        c->pt[slot].ptr, c->eta[slot].ptr, nullptr, c->pair_item.ptr, c->mv_chunks.ptr,
-        c->atab.ptr, nullptr, c->l, c->lp, c->kp, kBlock);
+        pair_block_a_args(c, slot, a_slot));
   } else {
-    launch_group_matvec(c, c->pt[slot].ptr, c->eta[slot].ptr, c->pair_item.ptr, c->atab.ptr, c->l,
-                        c->lp, c->kp, c->code_k);
+    launch_group_matvec(c, c->pt[slot].ptr, c->eta[slot].ptr, c->pair_item.ptr,
+                        c->atab[a_slot].ptr, c->l, c->lp, c->kp, c->code_k);
   }
   ls.done();
 }
 
+// ---- role-fused launches (commit iterations, small K and L) ---------------------------------------
+struct FillPlan {  // user-segment slices [u[j], u[j+1]) for dense launches j = 0, 1, 2
+  int u[4];
+  int blocks[3];
+};
+FillPlan fill_plan(const mmsbm_hip_ctx *c) {
+  FillPlan f;
+  const int per = kBlock / group_lanes(c->code_k);
+  const int n = c->n_users;
+  float acc = 0.f;
+  f.u[0] = 0;
+  for (int j = 0; j < 3; ++j) {
+    acc += c->fill_frac[j];
+    int e = (j == 2) ? n : static_cast<int>(static_cast<double>(n) * acc);
+    e = std::min(n, (e + per - 1) / per * per);
+    f.u[j + 1] = std::max(e, f.u[j]);
+    f.blocks[j] = (f.u[j + 1] - f.u[j] + per - 1) / per;
+  }
+  return f;
+}
+
+template <int G, int V>
+void launch_fused_dense_t(mmsbm_hip_ctx *c, const SegArgs &fill, int seg0, int nfill) {
+  const int nb = static_cast<int>(c->lay.mv_chunks.size());
+  const PairBlockArgs pa = pair_block_t_args(c);
+  if (c->nacc == 1) {
+    allow_big_lds(pair_block_fill_kernel<false, true, 1, G, V>, c->lds_t);
+    pair_block_fill_kernel<false, true, 1, G, V><<<nb + nfill, kBlock, c->lds_t, c->stream>>>(
+        pa, nb, fill, seg0, c->kp);
+  } else {
+    allow_big_lds(pair_block_fill_kernel<false, true, 2, G, V>, c->lds_t);
+    pair_block_fill_kernel<false, true, 2, G, V><<<nb + nfill, kBlock, c->lds_t, c->stream>>>(
+        pa, nb, fill, seg0, c->kp);
+  }
+}
+template <int G, int V>
+void launch_fused_eta_p(mmsbm_hip_ctx *c, const SegArgs &fill, int seg0, int nfill) {
+  const EtaPArgs a = eta_p_args(c, true, kRedCols);
+  const int per = kBlock / group_lanes(c->code_l);
+  const int nb_i = (c->n_items + per - 1) / per;
+  const int grid = a.nb_p + nb_i + nfill;
+  switch (c->code_l) {
+    case 0: eta_p_fill_kernel<4, 2, G, V><<<grid, kBlock, 0, c->stream>>>(a, nb_i, fill, seg0, c->kp); break;
+    case 1: eta_p_fill_kernel<8, 2, G, V><<<grid, kBlock, 0, c->stream>>>(a, nb_i, fill, seg0, c->kp); break;
+    case 2: eta_p_fill_kernel<16, 2, G, V><<<grid, kBlock, 0, c->stream>>>(a, nb_i, fill, seg0, c->kp); break;
+    default: eta_p_fill_kernel<32, 2, G, V><<<grid, kBlock, 0, c->stream>>>(a, nb_i, fill, seg0, c->kp); break;
+  }
+}
+template <int G, int V>
+void launch_fused_dense_a(mmsbm_hip_ctx *c, const SegArgs &fill, int seg0, int nfill) {
+  const int nb = static_cast<int>(c->lay.mv_chunks.size());
+  const int nxt = c->cur ^ 1;
+  allow_big_lds(pair_block_fill_kernel<true, false, 1, G, V>, c->lds_a);
+  pair_block_fill_kernel<true, false, 1, G, V><<<nb + nfill, kBlock, c->lds_a, c->stream>>>(
+      pair_block_a_args(c, nxt, nxt), nb, fill, seg0, c->kp);
+}
+
+#define DISPATCH_SMALL_GV(code, FN, ...)                          \
+  switch (code) {                                                 \
+    case 0: FN<4, 2>(__VA_ARGS__); break;                         \
+    case 1: FN<8, 2>(__VA_ARGS__); break;                         \
+    case 2: FN<16, 2>(__VA_ARGS__); break;                        \
+    default: FN<32, 2>(__VA_ARGS__); break;                       \
+  }
+
+//   launch 0 : pair segments (C)
+//   launch 1 : [T mat-vec + p slabs | user segments, slice 0]
+//   launch 2 : [p_update | item_sum | user segments, slice 1]
+//   launch 3 : [A mat-vec (new eta, new p) -> atab[next] | user segments, slice 2]
+// The user segments read theta[cur] and atab[cur] only, so they may run beside any of the
+// dense stages; atab is double-buffered because launch 3 writes the next A while they read.
+void launch_iteration_rolefused(mmsbm_hip_ctx *c) {
+  const FillPlan f = fill_plan(c);
+  stage_seg(c, true, false);
+  {
+    LaunchScope ls(c, K_DENSE);
+    const SegArgs fill = seg_users_args(c, true, f.u[1]);
+    DISPATCH_SMALL_GV(c->code_k, launch_fused_dense_t, c, fill, f.u[0], f.blocks[0]);
+    ls.done();
+  }
+  {
+    LaunchScope ls(c, K_ETAP);
+    const SegArgs fill = seg_users_args(c, true, f.u[2]);
+    DISPATCH_SMALL_GV(c->code_k, launch_fused_eta_p, c, fill, f.u[1], f.blocks[1]);
+    ls.done();
+  }
+  {
+    LaunchScope ls(c, K_MATVEC_A);
+    const SegArgs fill = seg_users_args(c, true, f.u[3]);
+    DISPATCH_SMALL_GV(c->code_k, launch_fused_dense_a, c, fill, f.u[2], f.blocks[2]);
+    ls.done();
+  }
+  c->cur ^= 1;
+}
+
 void launch_iteration(mmsbm_hip_ctx *c, bool commit) {
-  stage_seg(c, commit);
+  if (commit && c->rolefuse && c->n_chunks > 0) {
+    launch_iteration_rolefused(c);
+    return;
+  }
+  stage_seg(c, commit, true);
   stage_dense(c);
   stage_eta_p(c, commit);
   if (commit) {
-    stage_matvec_a(c, c->cur ^ 1);
+    stage_matvec_a(c, c->cur ^ 1, c->cur ^ 1);
     c->cur ^= 1;
   }
 }
@@ -1341,6 +1572,8 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
     c->lds_t = pair_block_lds(c->kp, c->lp, true);
     c->lds_a = pair_block_lds(c->lp, c->kp, false);
     c->fused = c->lds_t <= kLdsMax && c->lds_a <= kLdsMax;
+    c->rolefuse = false;  // measured slower at C3 (the filler inherits the dense roles' VGPR/LDS
+                          // footprint); kept as a tuning option, see mmsbm_hip_set_option
     if (matvec_gpb(c->kp, c->lp, group_lanes(c->code_l)) < 1 ||
         matvec_gpb(c->lp, c->kp, group_lanes(c->code_k)) < 1)
       throw ApiError(MMSBM_E_UNSUPPORTED, "K*L tile does not fit the 64 KiB LDS budget");
@@ -1395,8 +1628,11 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
       HIP_CHECK(hipMemsetAsync(c->p[b].ptr, 0, sizeof(double) * klr, s));
       HIP_CHECK(hipMemsetAsync(c->pt[b].ptr, 0, sizeof(double) * klr, s));
     }
-    c->atab.alloc(static_cast<size_t>(c->n_pairs) * c->kp);
-    HIP_CHECK(hipMemsetAsync(c->atab.ptr, 0, sizeof(double) * std::max<size_t>(c->atab.count, 1), s));
+    for (int b = 0; b < 2; ++b) {
+      c->atab[b].alloc(static_cast<size_t>(c->n_pairs) * c->kp);
+      HIP_CHECK(hipMemsetAsync(c->atab[b].ptr, 0,
+                               sizeof(double) * std::max<size_t>(c->atab[b].count, 1), s));
+    }
     c->ctab.alloc(static_cast<size_t>(c->n_pairs) * c->kp);
     c->ttab.alloc(static_cast<size_t>(c->n_pairs) * c->lp);
     c->partial.alloc(std::max<size_t>(std::max<size_t>(c->n_chunks, c->lay.mv_chunks.size()), 1) *
@@ -1456,7 +1692,7 @@ int mmsbm_hip_set_params(mmsbm_hip_ctx *ctx, const double *theta, const double *
                              hipMemcpyHostToDevice, ctx->stream));
     HIP_CHECK(hipMemcpyAsync(ctx->pt[cur].ptr, pt.data(), sizeof(double) * pt.size(),
                              hipMemcpyHostToDevice, ctx->stream));
-    stage_matvec_a(ctx, cur);
+    stage_matvec_a(ctx, cur, cur);
     HIP_CHECK(hipStreamSynchronize(ctx->stream));  // host staging vectors die here
     ctx->have_params = true;
   });
@@ -1683,15 +1919,18 @@ int mmsbm_hip_kernel_bytes(const mmsbm_hip_ctx *ctx, int index, int64_t *bytes_r
 int mmsbm_hip_time_stage(mmsbm_hip_ctx *ctx, int stage, int reps, float *mean_us) {
   return guarded([&] {
     require_params(ctx);
+    ctx->ablate = stage >> 8;  // bits 8.. : phases to skip (timing experiments only)
+    stage &= 0xff;
+    struct Reset { mmsbm_hip_ctx *c; ~Reset() { c->ablate = 0; } } reset{ctx};
     if (!mean_us || reps <= 0 || stage < 0 || stage >= K_COUNT)
       throw std::invalid_argument("bad argument");
     use_device(ctx);
     auto one = [&] {
       switch (stage) {
-        case K_SEG: stage_seg(ctx, true); break;
+        case K_SEG: stage_seg(ctx, true, !ctx->rolefuse); break;
         case K_DENSE: stage_dense(ctx); break;
         case K_ETAP: stage_eta_p(ctx, true); break;
-        default: stage_matvec_a(ctx, ctx->cur); break;
+        default: stage_matvec_a(ctx, ctx->cur, ctx->cur ^ 1); break;
       }
     };
     for (int w = 0; w < 3; ++w) one();
@@ -1707,6 +1946,23 @@ int mmsbm_hip_time_stage(mmsbm_hip_ctx *ctx, int stage, int reps, float *mean_us
     *mean_us = ms * 1000.f / reps;
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
+  });
+}
+
+int mmsbm_hip_set_option(mmsbm_hip_ctx *ctx, const char *name, double value) {
+  return guarded([&] {
+    if (!ctx || !name) throw std::invalid_argument("null argument");
+    const std::string key(name);
+    if (key == "rolefuse") {
+      ctx->rolefuse = value != 0.0 && ctx->fused && ctx->code_k <= 3 && ctx->code_l <= 3 &&
+                      ctx->nacc <= 2;
+    } else if (key == "fill0" || key == "fill1" || key == "fill2") {
+      if (value < 0.0 || value > 1.0) throw std::invalid_argument("fill share must be in [0, 1]");
+      ctx->fill_frac[key[4] - '0'] = static_cast<float>(value);
+    } else {
+      throw std::invalid_argument("unknown option: " + key);
+    }
+    ctx->drop_graphs();
   });
 }
 

@@ -14,7 +14,15 @@ lib = _lib.load()
 for st in range(lib.mmsbm_hip_kernel_count()):
     print(f"{lib.mmsbm_hip_kernel_name(st).decode():28s} {ctx.time_stage(st, 100):8.2f} us back-to-back")
 ctx.set_params(*mm.init_params(mm.child_states[0], d_u, d_i))
-for mode, nm in ((0, "eager"), (1, "graph")):
-    ctx.set_graph_mode(mode); ctx.iterate(10)
-    best = min(ctx.time_iterations(200) for _ in range(3))
-    print(f"iteration, {nm:14s} {best * 5:8.2f} us")
+def best(n=200, reps=3):
+    ctx.iterate(10)
+    return min(ctx.time_iterations(n) for _ in range(reps)) * 1000.0 / n
+for rf in (0, 1):
+    ctx.set_option("rolefuse", rf)
+    for mode, nm in ((0, "eager"), (1, "graph")):
+        ctx.set_graph_mode(mode)
+        print(f"iteration, rolefuse={rf} {nm:6s} {best():8.2f} us")
+ctx.set_graph_mode(0); ctx.set_option("rolefuse", 1)
+for f in ((0.55, 0.20, 0.25), (0.5, 0.2, 0.3), (0.6, 0.15, 0.25), (0.45, 0.25, 0.3), (0.4, 0.2, 0.4), (0.65, 0.1, 0.25), (0.34, 0.33, 0.33), (0.7, 0.1, 0.2)):
+    for j, v in enumerate(f): ctx.set_option(f"fill{j}", v)
+    print(f"fill {f}: {best():8.2f} us")
