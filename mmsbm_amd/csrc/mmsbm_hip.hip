@@ -354,8 +354,8 @@ __global__ __launch_bounds__(kBlock) void pair_matvec_lane_kernel(
 
 // ======================================================================================
 // pair_block -- the fused dense stage.  A block takes a unit of <= 64 consecutive pairs of
-// ONE rating (more if its chunk is longer) and, per unit, stages in LDS (coalesced flat copies):
-//   tile[d][:]      the rating's Din x Dout tile (p[r] or pT[r]),
+// ONE rating (more if its chunk is longer) and, per unit, stages in LDS (coalesced flat copies;
+// the rating's Din x Dout tile p[r] / pT[r] is lane-uniform and comes through SGPRs instead):
 //   cst[d][pair]    the 64 input rows, transposed (C rows, or gathered eta rows),
 //   es[pair][:]     (DO_S) the 64 gathered eta rows (the region is reused for the output rows),
 // then
@@ -376,8 +376,8 @@ struct PairBlockArgs {
 };
 
 template <bool GATHER, bool DO_S, int NACC>
-__device__ __forceinline__ void pair_block_body(const PairBlockArgs &pa, int block) {
-  const double *__restrict__ tiles = pa.tiles;
+__device__ __forceinline__ void pair_block_body(const PairBlockArgs &pa,
+                                                const double *__restrict__ tiles, int block) {
   const double *__restrict__ in_tab = pa.in_tab;
   const double *__restrict__ e_tab = pa.e_tab;
   const int32_t *__restrict__ pair_item = pa.pair_item;
@@ -388,8 +388,7 @@ __device__ __forceinline__ void pair_block_body(const PairBlockArgs &pa, int blo
   // copy, bit5 slab store, bit6 tile staging are skipped when set
   extern __shared__ double lds[];
   constexpr int CS = kUnitPairs + 1;  // odd stride: conflict-free column AND row reads
-  double *tile = lds;                                          // [dinp][doutp]
-  double *cst = tile + static_cast<size_t>(dinp) * doutp;      // [dinp][CS]
+  double *cst = lds;                                  // [dinp][CS]
   double *es = cst + static_cast<size_t>(dinp) * CS;  // [64][doutp]  gathered eta rows (DO_S) ...
   double *tout = es;                                  // ... then the mat-vec's output rows
   __shared__ int32_t rowid[kUnitPairs];
@@ -397,11 +396,13 @@ __device__ __forceinline__ void pair_block_body(const PairBlockArgs &pa, int blo
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int nch = doutp >> 2;
 
-  if (!(abl & 64)) {  // the rating's tile: one coalesced pass
-    const double *src = tiles + static_cast<size_t>(ch.rating) * dinp * doutp;
-    for (int t = tid * 2; t < dinp * doutp; t += kBlock * 2)
-      *reinterpret_cast<double2 *>(tile + t) = *reinterpret_cast<const double2 *>(src + t);
-  }
+  // The rating's tile is the same for every lane: it is read through the scalar cache
+  // (s_load into SGPRs) and never touches LDS.
+  // (constant address space: the tiles are never written by this launch, and AS4 loads
+  // with a uniform address are always selected as scalar loads.)
+  typedef const double __attribute__((address_space(4))) * const_tile_ptr;
+  const const_tile_ptr gtile = (const_tile_ptr)(reinterpret_cast<uintptr_t>(
+      tiles + static_cast<size_t>(ch.rating) * dinp * doutp));
   // S slots (DO_S)
   const int nsub = kBlock / spb, sub = tid / spb, slot0 = tid % spb;
   const int nout = dinp * nch;
@@ -418,7 +419,7 @@ __device__ __forceinline__ void pair_block_body(const PairBlockArgs &pa, int blo
 
   for (int q0 = ch.q_begin; q0 < ch.q_end; q0 += kUnitPairs) {
     const int np = min(kUnitPairs, ch.q_end - q0);
-    __syncthreads();  // previous unit fully consumed (also orders the tile staging)
+    __syncthreads();  // previous unit fully consumed
     if (GATHER || DO_S) {
       if (tid < kUnitPairs) rowid[tid] = pair_item[q0 + min(tid, np - 1)];
       if (GATHER) __syncthreads();
@@ -500,7 +501,8 @@ __device__ __forceinline__ void pair_block_body(const PairBlockArgs &pa, int blo
       __syncthreads();  // es is dead: its space becomes tout
     }
     // ---- mat-vec: lane = pair, wave = output chunk ------------------------------------------
-    for (int c = wave; c < nch && !(abl & 8); c += kBlock / 64) {
+    // (readfirstlane: tell the compiler the wave index is uniform so the tile loads scalarise)
+    for (int c = __builtin_amdgcn_readfirstlane(wave); c < nch && !(abl & 8); c += kBlock / 64) {
       double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
       // rows d >= din of the tile and of the inputs are zero padding, dinp is a multiple of 4:
       // four rows' operands are fetched from LDS before any of them is used
@@ -510,8 +512,9 @@ __device__ __forceinline__ void pair_block_body(const PairBlockArgs &pa, int blo
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           x[i] = cst[(d + i) * CS + lane];
-          m0[i] = *reinterpret_cast<const double2 *>(tile + (d + i) * doutp + c * 4);
-          m1[i] = *reinterpret_cast<const double2 *>(tile + (d + i) * doutp + c * 4 + 2);
+          const const_tile_ptr row = gtile + static_cast<size_t>(d + i) * doutp + c * 4;  // uniform
+          m0[i].x = row[0]; m0[i].y = row[1];
+          m1[i].x = row[2]; m1[i].y = row[3];
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -565,19 +568,21 @@ __device__ __forceinline__ void pair_block_body(const PairBlockArgs &pa, int blo
 }
 
 template <bool GATHER, bool DO_S, int NACC>
-__global__ __launch_bounds__(kBlock) void pair_block_kernel(PairBlockArgs pa) {
-  pair_block_body<GATHER, DO_S, NACC>(pa, blockIdx.x);
+__global__ __launch_bounds__(kBlock) void pair_block_kernel(PairBlockArgs pa,
+                                                            const double *__restrict__ tiles) {
+  pair_block_body<GATHER, DO_S, NACC>(pa, tiles, blockIdx.x);
 }
 
 // Role-fused form: the first nb_dense blocks are pair_block units, the rest are filler --
 // a slice of the user segments of seg_pass (bandwidth-bound, no LDS), so that the
 // LDS/latency-bound dense stage and the gather pass share the machine inside ONE launch.
 template <bool GATHER, bool DO_S, int NACC, int G, int VEC>
-__global__ __launch_bounds__(kBlock) void pair_block_fill_kernel(PairBlockArgs pa, int nb_dense,
-                                                                 SegArgs fill, int fill_seg0,
-                                                                 int dp) {
+__global__ __launch_bounds__(kBlock) void pair_block_fill_kernel(PairBlockArgs pa,
+                                                                 const double *__restrict__ tiles,
+                                                                 int nb_dense, SegArgs fill,
+                                                                 int fill_seg0, int dp) {
   if (static_cast<int>(blockIdx.x) < nb_dense)
-    pair_block_body<GATHER, DO_S, NACC>(pa, blockIdx.x);
+    pair_block_body<GATHER, DO_S, NACC>(pa, tiles, blockIdx.x);
   else
     seg_body<G, VEC, 4>(fill, fill_seg0 + (blockIdx.x - nb_dense) * (kBlock / G) + threadIdx.x / G,
                         dp);
@@ -1126,11 +1131,10 @@ int lane_matvec_waves(int dinp, int doutp) {
 
 constexpr size_t kLdsMax = 160 * 1024;  // with hipFuncAttributeMaxDynamicSharedMemorySize
 
-// dynamic LDS of pair_block: tile + transposed rows + output rows (+ eta rows)
+// dynamic LDS of pair_block: transposed rows + output rows (shared with the eta rows)
 size_t pair_block_lds(int dinp, int doutp, bool with_s) {
   (void)with_s;  // the eta rows and the output rows share one region
-  const size_t d = static_cast<size_t>(dinp) * doutp + static_cast<size_t>(dinp) * (kUnitPairs + 1) +
-                   static_cast<size_t>(kUnitPairs) * doutp;
+  const size_t d = static_cast<size_t>(dinp) * (kUnitPairs + 1) + static_cast<size_t>(kUnitPairs) * doutp;
   return std::max(d, static_cast<size_t>(kBlock) * 2) * sizeof(double);
 }
 
@@ -1215,7 +1219,7 @@ void stage_dense(mmsbm_hip_ctx *c) {  // T = P^T C  and the K x L slabs for p
 #define PB(N)                                                                               \
   do {                                                                                      \
     allow_big_lds(pair_block_kernel<false, true, N>, c->lds_t);                             \
-    pair_block_kernel<false, true, N><<<nb, kBlock, c->lds_t, c->stream>>>(pa);             \
+    pair_block_kernel<false, true, N><<<nb, kBlock, c->lds_t, c->stream>>>(pa, pa.tiles);   \
   } while (0)
     switch (c->nacc) {
       case 1: PB(1); break;
@@ -1272,8 +1276,8 @@ void stage_matvec_a(mmsbm_hip_ctx *c, int slot, int a_slot) {
   if (c->fused) {
     const int nb = static_cast<int>(c->lay.mv_chunks.size());
     allow_big_lds(pair_block_kernel<true, false, 1>, c->lds_a);
-    pair_block_kernel<true, false, 1><<<nb, kBlock, c->lds_a, c->stream>>>(
-        pair_block_a_args(c, slot, a_slot));
+    const PairBlockArgs pa = pair_block_a_args(c, slot, a_slot);
+    pair_block_kernel<true, false, 1><<<nb, kBlock, c->lds_a, c->stream>>>(pa, pa.tiles);
   } else {
     launch_group_matvec(c, c->pt[slot].ptr, c->eta[slot].ptr, c->pair_item.ptr,
                         c->atab[a_slot].ptr, c->l, c->lp, c->kp, c->code_k);
@@ -1309,11 +1313,11 @@ void launch_fused_dense_t(mmsbm_hip_ctx *c, const SegArgs &fill, int seg0, int n
   if (c->nacc == 1) {
     allow_big_lds(pair_block_fill_kernel<false, true, 1, G, V>, c->lds_t);
     pair_block_fill_kernel<false, true, 1, G, V><<<nb + nfill, kBlock, c->lds_t, c->stream>>>(
-        pa, nb, fill, seg0, c->kp);
+        pa, pa.tiles, nb, fill, seg0, c->kp);
   } else {
     allow_big_lds(pair_block_fill_kernel<false, true, 2, G, V>, c->lds_t);
     pair_block_fill_kernel<false, true, 2, G, V><<<nb + nfill, kBlock, c->lds_t, c->stream>>>(
-        pa, nb, fill, seg0, c->kp);
+        pa, pa.tiles, nb, fill, seg0, c->kp);
   }
 }
 template <int G, int V>
@@ -1334,8 +1338,9 @@ void launch_fused_dense_a(mmsbm_hip_ctx *c, const SegArgs &fill, int seg0, int n
   const int nb = static_cast<int>(c->lay.mv_chunks.size());
   const int nxt = c->cur ^ 1;
   allow_big_lds(pair_block_fill_kernel<true, false, 1, G, V>, c->lds_a);
+  const PairBlockArgs pa = pair_block_a_args(c, nxt, nxt);
   pair_block_fill_kernel<true, false, 1, G, V><<<nb + nfill, kBlock, c->lds_a, c->stream>>>(
-      pair_block_a_args(c, nxt, nxt), nb, fill, seg0, c->kp);
+      pa, pa.tiles, nb, fill, seg0, c->kp);
 }
 
 #define DISPATCH_SMALL_GV(code, FN, ...)                          \
