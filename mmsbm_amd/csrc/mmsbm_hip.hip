@@ -372,7 +372,7 @@ constexpr int kUnitPairs = 64;
 struct PairBlockArgs {
   const double *tiles; const double *in_tab; const double *e_tab; const int32_t *pair_item;
   const mmsbm::Chunk *chunks; double *out; double *partial;
-  int din, dinp, doutp, spb, abl;
+  int din, dinp, doutp, spb, nsub, abl;
 };
 
 template <bool GATHER, bool DO_S, int NACC>
@@ -384,6 +384,7 @@ __device__ __forceinline__ void pair_block_body(const PairBlockArgs &pa,
   double *__restrict__ out = pa.out;
   double *__restrict__ partial = pa.partial;
   const int din = pa.din, dinp = pa.dinp, doutp = pa.doutp, spb = pa.spb, abl = pa.abl;
+  const int nsub = pa.nsub;
   // abl: tuning aid, normally 0 -- bit0 rows, bit1 eta rows, bit2 S, bit3 mat-vec, bit4 output
   // copy, bit5 slab store, bit6 tile staging are skipped when set
   extern __shared__ double lds[];
@@ -403,18 +404,20 @@ __device__ __forceinline__ void pair_block_body(const PairBlockArgs &pa,
   typedef const double __attribute__((address_space(4))) * const_tile_ptr;
   const const_tile_ptr gtile = (const_tile_ptr)(reinterpret_cast<uintptr_t>(
       tiles + static_cast<size_t>(ch.rating) * dinp * doutp));
-  // S slots (DO_S)
-  const int nsub = kBlock / spb, sub = tid / spb, slot0 = tid % spb;
-  const int nout = dinp * nch;
+  // S slots (DO_S): a slot is a 2 (k) x 4 (l) register tile; `spb` threads form one copy of
+  // the K x L slot grid and the block's nsub copies split each unit's pairs.
+  const int nslot = (dinp >> 1) * nch;
+  const int sub = tid / spb, slot0 = tid % spb;
+  const bool s_active = sub < nsub;
   int coff[NACC], eoff[NACC];
-  double acc[NACC][4];
+  double acc[NACC][8];
 #pragma unroll
   for (int a = 0; a < NACC; ++a) {
-    const int o = min(slot0 + a * spb, nout - 1);
-    coff[a] = (o / nch) * CS;
+    const int o = min(slot0 + a * spb, nslot - 1);
+    coff[a] = (o / nch) * 2 * CS;
     eoff[a] = (o % nch) * 4;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[a][j] = 0.0;
+    for (int j = 0; j < 8; ++j) acc[a][j] = 0.0;
   }
 
   for (int q0 = ch.q_begin; q0 < ch.q_end; q0 += kUnitPairs) {
@@ -471,30 +474,22 @@ __device__ __forceinline__ void pair_block_body(const PairBlockArgs &pa,
     __syncthreads();
     // ---- S: thread = (k, 4 l) slot, copies split the unit's pairs --------------------------------
     if (DO_S) {
-      if (!(abl & 4))
-      for (int j0 = sub; j0 < np; j0 += 4 * nsub) {  // 4 pairs' operands in flight per slot
-        double cv[NACC][4];
-        double2 e0[NACC][4], e1[NACC][4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int j = min(j0 + i * nsub, np - 1);
+      if (!(abl & 4) && s_active) {
+#pragma unroll 2
+        for (int j = sub; j < np; j += nsub) {
 #pragma unroll
           for (int a = 0; a < NACC; ++a) {
-            cv[a][i] = cst[coff[a] + j];
-            e0[a][i] = *reinterpret_cast<const double2 *>(es + j * doutp + eoff[a]);
-            e1[a][i] = *reinterpret_cast<const double2 *>(es + j * doutp + eoff[a] + 2);
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          if (j0 + i * nsub < np) {
-#pragma unroll
-            for (int a = 0; a < NACC; ++a) {
-              acc[a][0] = fma(cv[a][i], e0[a][i].x, acc[a][0]);
-              acc[a][1] = fma(cv[a][i], e0[a][i].y, acc[a][1]);
-              acc[a][2] = fma(cv[a][i], e1[a][i].x, acc[a][2]);
-              acc[a][3] = fma(cv[a][i], e1[a][i].y, acc[a][3]);
-            }
+            const double c0 = cst[coff[a] + j], c1 = cst[coff[a] + CS + j];
+            const double2 e0 = *reinterpret_cast<const double2 *>(es + j * doutp + eoff[a]);
+            const double2 e1 = *reinterpret_cast<const double2 *>(es + j * doutp + eoff[a] + 2);
+            acc[a][0] = fma(c0, e0.x, acc[a][0]);
+            acc[a][1] = fma(c0, e0.y, acc[a][1]);
+            acc[a][2] = fma(c0, e1.x, acc[a][2]);
+            acc[a][3] = fma(c0, e1.y, acc[a][3]);
+            acc[a][4] = fma(c1, e0.x, acc[a][4]);
+            acc[a][5] = fma(c1, e0.y, acc[a][5]);
+            acc[a][6] = fma(c1, e1.x, acc[a][6]);
+            acc[a][7] = fma(c1, e1.y, acc[a][7]);
           }
         }
       }
@@ -538,16 +533,18 @@ __device__ __forceinline__ void pair_block_body(const PairBlockArgs &pa,
     }
   }
   if (DO_S) {
-    if (nsub == 2) {  // second copy hands its sums over through LDS (NACC == 1 here)
+    if (nsub > 1) {  // the other copies hand their sums over through LDS, added in copy order
       __syncthreads();
-      if (sub == 1) {
+      if (s_active && sub > 0 && slot0 < nslot) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) lds[slot0 * 4 + j] = acc[0][j];
+        for (int j = 0; j < 8; ++j)  // [value][copy][slot]: consecutive lanes, consecutive words
+          lds[(j * (nsub - 1) + sub - 1) * nslot + slot0] = acc[0][j];
       }
       __syncthreads();
-      if (sub == 0) {
+      if (sub == 0 && slot0 < nslot) {
+        for (int o = 1; o < nsub; ++o)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[0][j] += lds[slot0 * 4 + j];
+          for (int j = 0; j < 8; ++j) acc[0][j] += lds[(j * (nsub - 1) + o - 1) * nslot + slot0];
       }
     }
     if (sub == 0 && !(abl & 32)) {
@@ -555,12 +552,15 @@ __device__ __forceinline__ void pair_block_body(const PairBlockArgs &pa,
 #pragma unroll
       for (int a = 0; a < NACC; ++a) {
         const int o = slot0 + a * spb;
-        if (o < nout) {
-          double2 x, y;
-          x.x = acc[a][0]; x.y = acc[a][1]; y.x = acc[a][2]; y.y = acc[a][3];
-          double *cell = dst + (o / nch) * doutp + eoff[a];
-          *reinterpret_cast<double2 *>(cell) = x;
-          *reinterpret_cast<double2 *>(cell + 2) = y;
+        if (o < nslot) {
+          double *cell = dst + (o / nch) * 2 * doutp + eoff[a];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            double2 x, y;
+            x.x = acc[a][4 * h]; x.y = acc[a][4 * h + 1]; y.x = acc[a][4 * h + 2]; y.y = acc[a][4 * h + 3];
+            *reinterpret_cast<double2 *>(cell + h * doutp) = x;
+            *reinterpret_cast<double2 *>(cell + h * doutp + 2) = y;
+          }
         }
       }
     }
@@ -1043,6 +1043,7 @@ struct mmsbm_hip_ctx {
   int code_k = 0, code_l = 0, nacc = 1;
   int ablate = 0;           // tuning aid (mmsbm_hip_time_stage): phases pair_block skips
   bool fused = false;       // pair_block path (else: pair_matvec + p_partial fallback)
+  int pb_spb = kBlock, pb_nacc = 1, pb_nsub = 1;  // pair_block S phase: threads per slot-grid copy, slots per thread
   bool rolefuse = false;    // user segments ride as filler blocks inside the dense launches
   float fill_frac[3] = {0.55f, 0.20f, 0.25f};  // share of the user segments per dense launch
   size_t lds_t = 0, lds_a = 0;
@@ -1135,7 +1136,7 @@ constexpr size_t kLdsMax = 160 * 1024;  // with hipFuncAttributeMaxDynamicShared
 size_t pair_block_lds(int dinp, int doutp, bool with_s) {
   (void)with_s;  // the eta rows and the output rows share one region
   const size_t d = static_cast<size_t>(dinp) * (kUnitPairs + 1) + static_cast<size_t>(kUnitPairs) * doutp;
-  return std::max(d, static_cast<size_t>(kBlock) * 2) * sizeof(double);
+  return std::max(d, static_cast<size_t>(kBlock) * 8) * sizeof(double);  // >= hand-over area of S
 }
 
 template <class K>
@@ -1173,12 +1174,14 @@ SegArgs seg_users_args(const mmsbm_hip_ctx *c, bool commit, int seg_end) {  // t
 PairBlockArgs pair_block_t_args(const mmsbm_hip_ctx *c) {
   return PairBlockArgs{c->p[c->cur].ptr, c->ctab.ptr,        c->eta[c->cur].ptr, c->pair_item.ptr,
                        c->mv_chunks.ptr, c->ttab.ptr,        c->partial.ptr,     c->k,
-                       c->kp,            c->lp,              ppartial_spb(c->kp, c->lp), c->ablate};
+                       c->kp,            c->lp,              c->pb_spb,          c->pb_nsub,
+                       c->ablate};
 }
 PairBlockArgs pair_block_a_args(const mmsbm_hip_ctx *c, int param_slot, int a_slot) {
   return PairBlockArgs{c->pt[param_slot].ptr, c->eta[param_slot].ptr, nullptr, c->pair_item.ptr,
                        c->mv_chunks.ptr,      c->atab[a_slot].ptr,    nullptr, c->l,
-                       c->lp,                 c->kp,                  kBlock,  c->ablate};
+                       c->lp,                 c->kp,                  kBlock,  1,
+                       c->ablate};
 }
 EtaPArgs eta_p_args(const mmsbm_hip_ctx *c, bool commit, int cols_per_block) {
   const int cur = c->cur, nxt = cur ^ 1;
@@ -1221,12 +1224,11 @@ void stage_dense(mmsbm_hip_ctx *c) {  // T = P^T C  and the K x L slabs for p
     allow_big_lds(pair_block_kernel<false, true, N>, c->lds_t);                             \
     pair_block_kernel<false, true, N><<<nb, kBlock, c->lds_t, c->stream>>>(pa, pa.tiles);   \
   } while (0)
-    switch (c->nacc) {
+    switch (c->pb_nacc) {
       case 1: PB(1); break;
       case 2: PB(2); break;
       case 4: PB(4); break;
-      case 8: PB(8); break;
-      default: PB(16); break;
+      default: PB(8); break;
     }
 #undef PB
     ls.done();
@@ -1310,7 +1312,7 @@ template <int G, int V>
 void launch_fused_dense_t(mmsbm_hip_ctx *c, const SegArgs &fill, int seg0, int nfill) {
   const int nb = static_cast<int>(c->lay.mv_chunks.size());
   const PairBlockArgs pa = pair_block_t_args(c);
-  if (c->nacc == 1) {
+  if (c->pb_nacc == 1) {
     allow_big_lds(pair_block_fill_kernel<false, true, 1, G, V>, c->lds_t);
     pair_block_fill_kernel<false, true, 1, G, V><<<nb + nfill, kBlock, c->lds_t, c->stream>>>(
         pa, pa.tiles, nb, fill, seg0, c->kp);
@@ -1574,9 +1576,19 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
       if (n > 16) throw ApiError(MMSBM_E_UNSUPPORTED, "K*L too large for p_partial (max 16384)");
       c->nacc = n;
     }
+    {
+      const int nslot = (c->kp / 2) * (c->lp / 4);
+      if (nslot <= kBlock / 2) {
+        c->pb_spb = nslot; c->pb_nacc = 1;
+        const int room = (c->kp * (kUnitPairs + 1) + kUnitPairs * c->lp) / (nslot * 8);  // hand-over area
+        c->pb_nsub = std::max(1, std::min(std::min(kBlock / nslot, 8), 1 + room));
+      }
+      else { c->pb_spb = kBlock; int n = 1; while (n * kBlock < nslot) n *= 2; c->pb_nacc = n; }
+    }
     c->lds_t = pair_block_lds(c->kp, c->lp, true);
     c->lds_a = pair_block_lds(c->lp, c->kp, false);
     c->fused = c->lds_t <= kLdsMax && c->lds_a <= kLdsMax;
+    if (c->pb_nacc > 8) c->fused = false;
     c->rolefuse = false;  // measured slower at C3 (the filler inherits the dense roles' VGPR/LDS
                           // footprint); kept as a tuning option, see mmsbm_hip_set_option
     if (matvec_gpb(c->kp, c->lp, group_lanes(c->code_l)) < 1 ||
@@ -1960,7 +1972,7 @@ int mmsbm_hip_set_option(mmsbm_hip_ctx *ctx, const char *name, double value) {
     const std::string key(name);
     if (key == "rolefuse") {
       ctx->rolefuse = value != 0.0 && ctx->fused && ctx->code_k <= 3 && ctx->code_l <= 3 &&
-                      ctx->nacc <= 2;
+                      ctx->pb_nacc <= 2;
     } else if (key == "fill0" || key == "fill1" || key == "fill2") {
       if (value < 0.0 || value > 1.0) throw std::invalid_argument("fill share must be in [0, 1]");
       ctx->fill_frac[key[4] - '0'] = static_cast<float>(value);

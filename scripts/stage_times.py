@@ -14,6 +14,14 @@ lib = _lib.load()
 for st in range(lib.mmsbm_hip_kernel_count()):
     print(f"{lib.mmsbm_hip_kernel_name(st).decode():28s} {ctx.time_stage(st, 100):8.2f} us back-to-back")
 ctx.set_params(*mm.init_params(mm.child_states[0], d_u, d_i))
+for st in range(lib.mmsbm_hip_kernel_count()):
+    print(f"{lib.mmsbm_hip_kernel_name(st).decode():28s} {ctx.time_stage(st, 100):8.2f} us back-to-back")
+names = {1: "rows", 2: "eta rows", 4: "S", 8: "mat-vec", 16: "out copy", 32: "slab store"}
+for st in (1, 3):
+    for abl in (63, 63 - 1, 63 - 2, 63 - 4, 63 - 8, 63 - 16, 63 - 32):
+        kept = "+".join(v for k, v in names.items() if not (abl & k)) or "nothing"
+        print(f"  stage {st} with only [{kept}]: {ctx.time_stage(st | (abl << 8), 100):8.2f} us")
+ctx.set_params(*mm.init_params(mm.child_states[0], d_u, d_i))
 def best(n=200, reps=3):
     ctx.iterate(10)
     return min(ctx.time_iterations(n) for _ in range(reps)) * 1000.0 / n
@@ -22,7 +30,3 @@ for rf in (0, 1):
     for mode, nm in ((0, "eager"), (1, "graph")):
         ctx.set_graph_mode(mode)
         print(f"iteration, rolefuse={rf} {nm:6s} {best():8.2f} us")
-ctx.set_graph_mode(0); ctx.set_option("rolefuse", 1)
-for f in ((0.55, 0.20, 0.25), (0.5, 0.2, 0.3), (0.6, 0.15, 0.25), (0.45, 0.25, 0.3), (0.4, 0.2, 0.4), (0.65, 0.1, 0.25), (0.34, 0.33, 0.33), (0.7, 0.1, 0.2)):
-    for j, v in enumerate(f): ctx.set_option(f"fill{j}", v)
-    print(f"fill {f}: {best():8.2f} us")
