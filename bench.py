@@ -65,13 +65,18 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay a captured hipGraph instead of eager launches")
+    ap.add_argument("--dist-backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal only: every rank uses GPU 0 (use with --dist-backend gloo)")
     args = ap.parse_args()
 
     from mmsbm_amd import restarts  # imports torch first, then the library
     from mmsbm_amd import MMSBM
     from mmsbm_amd.synthetic import CONFIGS, algorithmic_bytes, synthetic_triples
 
-    rank, world, local, device = restarts.init_from_env()
+    if args.share_gpu:
+        os.environ["LOCAL_RANK"] = "0"
+    rank, world, local, device = restarts.init_from_env(args.dist_backend)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with "
                          f"python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...")
@@ -103,7 +108,7 @@ def main():
     ctx.synchronize()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=restarts._collective_device(device))
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed_max = float(t.item())
@@ -121,6 +126,14 @@ def main():
         dom_us, dom_launches, dom_rd, dom_wr = prof[dom]
         achieved = dom_rd / (dom_us * 1e-6) / 1e9
         ev_ms = ctx.time_iterations(args.steps)
+        traffic, traffic_src = None, None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_summary.json")
+        if os.path.exists(pmc_path):  # rocprofv3 --pmc passes of this same command (scripts/profile_round.sh)
+            with open(pmc_path) as fh:
+                pmc = json.load(fh)
+            ent = pmc.get(args.config, {}).get(dom)
+            if ent:
+                traffic, traffic_src = ent["hbm_bytes_per_launch"], ent["source"]
         out = {
             "metric": "EM iterations/sec (1M ratings, K=L=20)" if args.config == "c3"
                       else f"EM iterations/sec ({args.config})",
@@ -137,7 +150,7 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "frac_of_measured_copy_ceiling": achieved / HBM_MEASURED_GBPS,
                          "algorithmic_bytes_per_launch": dom_rd, "avg_launch_us": dom_us,
-                         "traffic": None},
+                         "traffic": traffic, "traffic_source": traffic_src},
             "iteration": {"algorithmic_read_bytes": rd, "algorithmic_write_bytes": wr,
                           "achieved_gbps_per_gpu": rd * (its / world) / 1e9,
                           "frac_of_hbm_peak": rd * (its / world) / 1e9 / HBM_PEAK_GBPS,

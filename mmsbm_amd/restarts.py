@@ -37,11 +37,14 @@ def init_from_env(backend=None):
     use_gpu = torch.cuda.is_available()
     if use_gpu:
         torch.cuda.set_device(local)
+    backend = backend or ("nccl" if use_gpu else "gloo")
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group(backend or ("nccl" if use_gpu else "gloo"), rank=rank,
-                                world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    # tensors for the collectives live where the backend wants them
+    coll = torch.device("cuda", local) if (use_gpu and backend == "nccl") else torch.device("cpu")
+    init_from_env.collective_device = coll
     return rank, world, local, (torch.device("cuda", local) if use_gpu else torch.device("cpu"))
 
 
@@ -52,11 +55,17 @@ def check_single_hip_runtime():
                            "): import torch (or mmsbm_amd.restarts) before the first HipEM is made")
 
 
+def _collective_device(device):
+    if dist.is_available() and dist.is_initialized() and dist.get_backend() != "nccl":
+        return torch.device("cpu")
+    return device if device is not None else torch.device("cpu")
+
+
 def all_likelihoods(local, sampling, device=None):
     """local: {restart index: likelihood}.  ONE all-reduce(MAX); returns the full vector
     (length ``sampling``) on every rank."""
     vec = torch.full((sampling,), float("-inf"), dtype=torch.float64,
-                     device=device if device is not None else "cpu")
+                     device=_collective_device(device))
     for i, lik in local.items():
         vec[i] = float(lik)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:

@@ -1,0 +1,20 @@
+#!/usr/bin/env bash
+# rocprofv3 evidence for one round, run ON THE GPU BOX (through gpurun):
+#   scripts/profile_round.sh r1
+# kernel trace + stats of the default bench command, then separate --pmc passes (never
+# combined with trace domains other than --kernel-trace).  Raw output -> gpurun_out/prof_<tag>_*;
+# scripts/summarize_profile.py turns it into the small files committed under profiles/.
+set -u
+tag=${1:-r1}
+root=${GRAFT_REPO_ROOT:-$(pwd)}
+out=$root/gpurun_out
+mkdir -p "$out"
+cd /tmp && export TMPDIR=/tmp
+bench="python3 $root/bench.py --steps 200 --warmup 20 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof_${tag}_trace" -- $bench > "$out/prof_${tag}_trace.log" 2>&1 || exit 1
+short="python3 $root/bench.py --steps 20 --warmup 2 --no-cpu-baseline --profile-iters 2"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/prof_${tag}_fetch" -- $short > "$out/prof_${tag}_fetch.log" 2>&1 || exit 1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/prof_${tag}_write" -- $short > "$out/prof_${tag}_write.log" 2>&1 || exit 1
+rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$out/prof_${tag}_l2" -- $short > "$out/prof_${tag}_l2.log" 2>&1 || exit 1
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VALU_FMA_F64 SQ_WAIT_ANY SQ_BUSY_CYCLES --output-format csv -d "$out/prof_${tag}_sq" -- $short > "$out/prof_${tag}_sq.log" 2>&1 || exit 1
+echo done

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Turn the raw rocprofv3 CSVs of scripts/profile_round.sh (under gpurun_out/) into the small,
+committed summaries under profiles/:  <tag>_kernel_stats.csv (the --stats table, our kernels),
+<tag>_pmc.csv (mean counter values per kernel) and pmc_summary.json (HBM bytes per launch,
+corrected as /opt/skills/guides/MI355X_MICROARCH.md section HBM prescribes: FETCH_SIZE and
+WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies 128-byte requests at 64 bytes, so the
+read side is doubled; WRITE_SIZE is exact)."""
+import csv, glob, json, os, sys, collections
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
+config = sys.argv[2] if len(sys.argv) > 2 else "c3"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out")
+dst = os.path.join(root, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+def short(name):
+    for key, nm in (("seg_pass_kernel", "seg_pass_kernel"), ("pair_block_kernel<false", "pair_block(T+S)|user-fill"),
+                    ("pair_block_kernel<true", "pair_block(A)|user-fill"), ("eta_p_kernel", "eta_p|user-fill"),
+                    ("likelihood_kernel", "likelihood_kernel"), ("prod_dist_kernel", "prod_dist_kernel")):
+        if key in name:
+            return nm
+    return None
+
+stats = glob.glob(os.path.join(src, f"prof_{tag}_trace", "*", "*_kernel_stats.csv"))
+rows = []
+if stats:
+    for r in csv.DictReader(open(stats[0])):
+        nm = short(r["Name"])
+        if nm:
+            rows.append({"kernel": nm, "full_name": r["Name"], "calls": r["Calls"],
+                         "avg_us": f'{float(r["AverageNs"]) / 1e3:.2f}', "min_us": f'{float(r["MinNs"]) / 1e3:.2f}',
+                         "max_us": f'{float(r["MaxNs"]) / 1e3:.2f}', "total_ms": f'{float(r["TotalDurationNs"]) / 1e6:.3f}',
+                         "percent": r["Percentage"]})
+    with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w", newline="") as fh:
+        w = csv.DictWriter(fh, fieldnames=list(rows[0].keys())); w.writeheader(); w.writerows(rows)
+
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for part in ("fetch", "write", "l2", "sq"):
+    for f in glob.glob(os.path.join(src, f"prof_{tag}_{part}", "*", "*_counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            nm = short(r["Kernel_Name"])
+            if nm:
+                agg[nm][r["Counter_Name"]].append(float(r["Counter_Value"]))
+with open(os.path.join(dst, f"{tag}_pmc.csv"), "w", newline="") as fh:
+    w = csv.writer(fh); w.writerow(["kernel", "counter", "mean_per_launch", "launches_sampled"])
+    for nm in sorted(agg):
+        for cn in sorted(agg[nm]):
+            v = agg[nm][cn]; w.writerow([nm, cn, f"{sum(v) / len(v):.1f}", len(v)])
+
+summary_path = os.path.join(dst, "pmc_summary.json")
+summary = json.load(open(summary_path)) if os.path.exists(summary_path) else {}
+summary.setdefault(config, {})
+for nm, cs in agg.items():
+    if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+        fetch = sum(cs["FETCH_SIZE"]) / len(cs["FETCH_SIZE"]) * 1024.0
+        write = sum(cs["WRITE_SIZE"]) / len(cs["WRITE_SIZE"]) * 1024.0
+        ent = {"fetch_size_bytes_raw": fetch, "write_size_bytes": write,
+               "hbm_bytes_per_launch": 2.0 * fetch + write,
+               "source": f"profiles/{tag}_pmc.csv: 2 x FETCH_SIZE (gfx950 tallies 128-B requests at 64 B) + WRITE_SIZE, KiB -> bytes"}
+        if "TCC_HIT_sum" in cs:
+            h = sum(cs["TCC_HIT_sum"]) / len(cs["TCC_HIT_sum"]); m = sum(cs["TCC_MISS_sum"]) / len(cs["TCC_MISS_sum"])
+            ent["l2_hit_rate"] = h / (h + m) if h + m else None
+        summary[config][nm] = ent
+json.dump(summary, open(summary_path, "w"), indent=1, sort_keys=True)
+for r in rows:
+    print(r["kernel"], r["calls"], r["avg_us"])
+print(json.dumps(summary[config], indent=1))
