@@ -290,3 +290,60 @@ def test_c3_full_size_invariants(hip):
     assert np.allclose(t.sum(1), 1, atol=1e-13) and np.allclose(e.sum(1), 1, atol=1e-13)
     assert np.allclose(p.sum(2), 1, atol=1e-13)
     assert np.isfinite(ctx.likelihood())
+
+
+def test_plugin_module_name_resolution(hip):
+    """src/backend.py:21 does import_module('kernels_' + name): with mmsbm_amd/plugin on sys.path the
+    name 'kernels_hip' must resolve to the HIP backend (what INTEGRATION.md level 1 relies on)."""
+    import importlib, os, sys
+    from conftest import ROOT
+    plug = os.path.join(ROOT, "mmsbm_amd", "plugin")
+    sys.path.insert(0, plug)
+    try:
+        mod = importlib.import_module("kernels_hip")
+    finally:
+        sys.path.remove(plug)
+    assert mod.__all__ == ["compute_omegas", "update_coefficients", "prod_dist"]
+    g = load_golden("g0_backend_tests")
+    out = mod.compute_omegas(g["data"], g["a_theta"], g["a_eta"], g["a_pr"])
+    assert np.array_equal(out, g["a_omegas"])
+    mod.clear_cache()
+
+
+def test_c5_shape_small(hip):
+    """K=L=50, R=10 (the C5 shape: 32-lane groups, 2 slots per thread in the slab phase) on a
+    problem small enough for the dense oracle."""
+    data = orc.synthetic_triples(4000, 300, 150, 10, seed=50)
+    n_u, n_i, n_r = (int(data[:, j].max()) + 1 for j in range(3))
+    d_u, d_i = orc.degrees(data, n_u, n_i)
+    theta, eta, pr = orc.init_params(123, n_u, n_i, n_r, 50, 50, d_u, d_i)
+    with make_ctx(hip, data, theta, eta, pr) as em:
+        want = orc.update_coefficients(data, theta, eta, pr)
+        for got, w, nm in zip(em.update_coefficients(), want, ("n_theta", "n_eta", "n_pr")):
+            assert rel_err(got, w) < TOL_STEP, nm
+        em.iterate(5)
+        for _ in range(5):
+            theta, eta, pr = orc.em_step(data, theta, eta, pr, d_u, d_i)
+        for got, w, nm in zip(em.get_params(), (theta, eta, pr), ("theta", "eta", "pr")):
+            assert rel_err(got, w) < 1e-11, nm
+        assert em.likelihood() == pytest.approx(float(orc.compute_likelihood(data, theta, eta, pr)), rel=1e-11)
+
+
+@pytest.mark.parametrize("opt", [{"graph": 1}, {"rolefuse": 1}, {"graph": 1, "rolefuse": 1}])
+def test_launch_modes_give_identical_results(hip, opt):
+    """hipGraph replay and the role-fused launches change scheduling only: bitwise-identical output."""
+    g = load_golden("g4_2k_k10")
+    outs = []
+    for use in (False, True):
+        with make_ctx(hip, g["train"], g["theta_0"], g["eta_0"], g["pr_0"]) as em:
+            if use:
+                if "graph" in opt:
+                    em.set_graph_mode(1)
+                if "rolefuse" in opt:
+                    em.set_option("rolefuse", 1)
+            em.iterate(7)
+            outs.append(em.get_params())
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+    for got, nm in zip(outs[1], ("theta", "eta", "pr")):
+        pass

@@ -1,0 +1,149 @@
+"""Host-side logic that needs no GPU: encoder vs the reference's DataHandler output (golden),
+restart seeding / initial parameters vs the reference, restart sharding and the one-all-reduce
+maximum-likelihood pick over a 2-rank gloo group."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden
+from mmsbm_amd.encode import Encoder
+from mmsbm_amd.mmsbm import MMSBM, normalize_with_self
+from mmsbm_amd.synthetic import CONFIGS, algorithmic_bytes, synthetic_triples
+from oracle import mmsbm_oracle as orc
+
+
+def test_encoder_matches_reference_datahandler():
+    g = load_golden("g1_c1_mock")
+    enc = Encoder()
+    train = enc.fit_transform((g["train_raw_users"], g["train_raw_items"], g["train_raw_ratings"]))
+    assert np.array_equal(train, g["train"])
+    assert enc.user_labels() == list(g["dict_users_keys"])
+    assert enc.item_labels() == list(g["dict_items_keys"])
+    assert enc.rating_labels() == list(g["dict_ratings_keys"]) == ["1", "2", "3", "4", "5"]
+    test = enc.transform((g["test_raw_users"], g["test_raw_items"], g["test_raw_ratings"]))
+    assert np.array_equal(test, g["test"])
+
+
+def test_encoder_lexicographic_order_and_unseen_rows(caplog):
+    import pandas as pd
+    df = pd.DataFrame({"users": [10, 2, 2, 33], "items": ["b", "a", "b", "a"], "ratings": [5, 10, 5, 1]})
+    enc = Encoder()
+    out = enc.fit_transform(df)
+    assert enc.user_labels() == ["10", "2", "33"]        # '10' < '2' < '33' as strings
+    assert enc.rating_labels() == ["1", "10", "5"]
+    assert out.tolist() == [[0, 1, 2], [1, 0, 1], [1, 1, 2], [2, 0, 0]]
+    test = pd.DataFrame({"users": [2, 99, 10, 2], "items": ["a", "a", "zz", "b"], "ratings": [5, 5, 5, 7]})
+    with caplog.at_level("WARNING", logger="MMSBM"):
+        enc_test = enc.transform(test)
+    assert enc_test.tolist() == [[1, 0, 2]]               # rows with unseen user / item / rating dropped
+    assert "99" in caplog.text and "zz" in caplog.text and "7" in caplog.text
+    with pytest.raises(AssertionError):
+        Encoder().fit_transform(pd.DataFrame({"u": [1, None], "i": [1, 2], "r": [1, 2]}))
+
+
+def test_restart_seeding_and_initial_parameters_match_reference():
+    g = load_golden("g1_c1_mock")
+    mm = MMSBM(2, 4, iterations=500, sampling=1, seed=1)       # constructor works without a GPU
+    mm.p, mm.m = 4, 9
+    mm._dims = {"n_ratings": 5}
+    theta, eta, pr = mm.init_params(mm.child_states[0], g["d_u"], g["d_i"])
+    assert np.array_equal(theta, g["c1_theta_0"])
+    assert np.array_equal(eta, g["c1_eta_0"])
+    assert np.array_equal(pr, g["c1_pr_0"])
+    three = MMSBM(2, 4, sampling=3, seed=1)
+    assert three.child_states[0].spawn_key == (0,) and three.child_states[2].spawn_key == (2,)
+    z = np.zeros((2, 2, 3)); z[0, 0] = [1, 1, 2]
+    assert normalize_with_self(z)[0, 0].tolist() == [0.25, 0.25, 0.5] and not normalize_with_self(z)[1].any()
+
+
+def test_predict_before_fit_and_unknown_backend():
+    mm = MMSBM(2, 2, seed=1)
+    with pytest.raises(AssertionError):
+        mm.predict(None)
+    with pytest.raises(AssertionError):
+        mm.score()
+    mm.backend = "numpy"                                        # this package ships no such backend
+    with pytest.raises(ImportError, match="Could not load any backend"):
+        mm._prepare_objects(np.array([[0, 0, 0]]))
+    mm2 = MMSBM(1, 1, seed=1)
+    mm2._compute_stats = lambda x: {"accuracy": x}
+    assert mm2.choose_best_run([0.1, 0.7, 0.3]) == 1            # reference tests/test_mmsbm.py:124-132
+
+
+def test_synthetic_generator_and_byte_accounting():
+    a = synthetic_triples(1000, 50, 20, 5, seed=0)
+    assert np.array_equal(a, orc.synthetic_triples(1000, 50, 20, 5, seed=0))
+    n, u, i, r, k, l = CONFIGS["c3"]
+    rd, wr = algorithmic_bytes(n, u, i, r, k, l)
+    assert rd == 332_016_000 and wr == 8 * (u * k + i * l + k * l * r)
+
+
+WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, {root!r})
+    import numpy as np
+    import torch.distributed as dist
+    from mmsbm_amd import restarts
+    from mmsbm_amd.mmsbm import MMSBM
+    from oracle import mmsbm_oracle as orc
+    from conftest_path import load_golden
+
+    rank, world, local, device = restarts.init_from_env("gloo")
+    g = load_golden("g2_c1_sampling3")
+    train = g["train"]
+    model = MMSBM(2, 2, iterations=10, sampling=3, seed=1)
+
+    def runner(i, seed):      # CPU stand-in for the GPU restart (the oracle), same seeds
+        return orc.run_one_sampling(train, seed, 2, 2, 10)
+
+    mine = restarts.shard_restarts(3, rank, world)
+    best, best_lik, liks = restarts.fit_distributed(model, train, runner=runner, gather=True, device=device)
+    assert mine == ([0, 2] if rank == 0 else [1]), mine
+    assert np.array_equal(liks, g["likelihoods"]), (liks, g["likelihoods"])
+    assert best == int(np.argmax(g["likelihoods"])) and model.best_by_likelihood == best
+    assert len(model.results) == 3
+    for s in range(3):
+        assert np.array_equal(model.results[s]["theta"], g[f"theta_{{s}}"])
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank", rank, "ok")
+""")
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_two_rank_gloo_restart_sharding_and_likelihood_pick(tmp_path):
+    """world_size 2 on CPU (gloo): restart i on rank i mod 2, ONE all-reduce picks the winner,
+    results gathered in restart order and identical to the reference's sampling=3 run."""
+    (tmp_path / "conftest_path.py").write_text(
+        f"import sys; sys.path.insert(0, {os.path.join(ROOT, 'tests')!r})\nfrom conftest import load_golden\n")
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=ROOT))
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PYTHONPATH=str(tmp_path),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {rank} failed:\n{out[-3000:]}"
+        assert f"rank {rank} ok" in out
+
+
+def test_single_process_pick_without_process_group():
+    from mmsbm_amd import restarts
+    best, lik, liks = restarts.pick_max_likelihood({0: -5.0, 1: -2.5, 2: -9.0}, 3)
+    assert best == 1 and lik == -2.5 and liks.tolist() == [-5.0, -2.5, -9.0]
+    assert restarts.shard_restarts(8, 3, 4) == [3, 7] and restarts.shard_restarts(2, 5, 8) == []
