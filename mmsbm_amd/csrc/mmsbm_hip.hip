@@ -139,12 +139,26 @@ __device__ __forceinline__ void store_vec(double *__restrict__ p, const double (
 //   user segments: fixed = theta, gath = A, out = theta * acc / d_u   (src/mmsbm.py:248)
 //   pair segments: fixed = A,     gath = theta, out = C = acc
 // ======================================================================================
+// A table of rows that are GATHERED by index (theta, A).  A 160-byte row (K = 20) straddles two
+// 128-byte cache lines; the table is therefore kept as a "main" part of whole 128-byte lines
+// (mw = 16 * floor(Kp/16) doubles per row, line aligned) plus a compact "tail" part
+// (tw = Kp - mw doubles per row), so a gather misses on one line of the big main part and
+// hits the small, cache-resident tail part.  mw == row width and tw == 0 describes a plain table.
+struct RowTab {
+  double *base;       // main part: row r at base + r * mw
+  size_t tail_off;    // tail part: row r at base + tail_off + r * tw
+  int mw, tw;
+};
+__device__ __forceinline__ double *rowtab_ptr(const RowTab &t, size_t row, int off) {
+  return off < t.mw ? t.base + row * t.mw + off : t.base + t.tail_off + row * t.tw + (off - t.mw);
+}
+
 struct SegArgs {
-  const double *fixed;
-  const double *gath;
+  RowTab fixed;
+  RowTab gath;
   const int32_t *off;
   const int32_t *idx;
-  double *out;
+  RowTab out;
   int32_t nseg;
   int32_t mode;  // 0: out = acc   1: out = fixed*acc/max(len,1)   2: out = fixed*acc
 };
@@ -159,7 +173,7 @@ __device__ __forceinline__ void seg_body(const SegArgs &a, int seg, int dp) {
   double f[VEC], acc[VEC];
 #pragma unroll
   for (int v = 0; v < VEC; ++v) acc[v] = 0.0;
-  load_vec<VEC>(a.fixed + static_cast<size_t>(seg) * dp + lane_off, f);
+  load_vec<VEC>(rowtab_ptr(a.fixed, seg, lane_off), f);
   if (!act) {
 #pragma unroll
     for (int v = 0; v < VEC; ++v) f[v] = 0.0;
@@ -168,6 +182,11 @@ __device__ __forceinline__ void seg_body(const SegArgs &a, int seg, int dp) {
   // Every lane of the group fetches one index of the segment (one coalesced load per G
   // triples); the indices are then broadcast inside the group with ds_bpermute, so the
   // dependent chain is offsets -> indices -> rows instead of one index load per batch.
+  // this lane's part of every gathered row: main or tail, fixed for the whole kernel
+  const bool g_main = lane_off < a.gath.mw;
+  const double *gbase = g_main ? a.gath.base + lane_off
+                               : a.gath.base + a.gath.tail_off + (lane_off - a.gath.mw);
+  const size_t gstride = g_main ? a.gath.mw : a.gath.tw;
   const int beg = a.off[seg], end = a.off[seg + 1];
   for (int c0 = beg; c0 < end; c0 += G) {
     const int cnt = min(G, end - c0);
@@ -177,7 +196,7 @@ __device__ __forceinline__ void seg_body(const SegArgs &a, int seg, int dp) {
 #pragma unroll
       for (int b = 0; b < B; ++b) {
         const int id = __shfl(mine, min(n + b, cnt - 1), G);
-        load_vec<VEC>(a.gath + static_cast<size_t>(id) * dp + lane_off, g[b]);
+        load_vec<VEC>(gbase + static_cast<size_t>(id) * gstride, g[b]);
       }
 #pragma unroll
       for (int b = 0; b < B; ++b) {
@@ -207,7 +226,7 @@ __device__ __forceinline__ void seg_body(const SegArgs &a, int seg, int dp) {
 #pragma unroll
     for (int v = 0; v < VEC; ++v) o[v] = f[v] * acc[v];
   }
-  store_vec<VEC>(a.out + static_cast<size_t>(seg) * dp + lane_off, o);
+  store_vec<VEC>(rowtab_ptr(a.out, seg, lane_off), o);
 }
 
 // blocks [0, blocks_a) work on segment set `sa`, the rest on `sb`
@@ -373,6 +392,8 @@ struct PairBlockArgs {
   const double *tiles; const double *in_tab; const double *e_tab; const int32_t *pair_item;
   const mmsbm::Chunk *chunks; double *out; double *partial;
   int din, dinp, doutp, spb, nsub, abl;
+  int out_mw;           // output rows: main width (== doutp: plain table) ...
+  size_t out_tail_off;  // ... and where the tail part starts (RowTab layout)
 };
 
 template <bool GATHER, bool DO_S, int NACC>
@@ -526,10 +547,21 @@ __device__ __forceinline__ void pair_block_body(const PairBlockArgs &pa,
     }
     __syncthreads();
     if (!(abl & 16)) {  // the unit's 64 output rows are contiguous in memory: flat coalesced copy
-      double *dst = out + static_cast<size_t>(q0) * doutp;
       const int total = np * doutp;
-      for (int t = tid * 2; t < total; t += kBlock * 2)
-        *reinterpret_cast<double2 *>(dst + t) = *reinterpret_cast<const double2 *>(tout + t);
+      if (pa.out_mw == doutp) {
+        double *dst = out + static_cast<size_t>(q0) * doutp;
+        for (int t = tid * 2; t < total; t += kBlock * 2)
+          *reinterpret_cast<double2 *>(dst + t) = *reinterpret_cast<const double2 *>(tout + t);
+      } else {  // RowTab output (A): main lines and tail rows are each contiguous for the unit
+        const int mw = pa.out_mw, tw = doutp - mw;
+        double *dmain = out + static_cast<size_t>(q0) * mw;
+        double *dtail = out + pa.out_tail_off + static_cast<size_t>(q0) * tw;
+        for (int t = tid * 2; t < total; t += kBlock * 2) {
+          const int pr = t / doutp, j = t - pr * doutp;
+          double *dst = j < mw ? dmain + pr * mw + j : dtail + pr * tw + (j - mw);
+          *reinterpret_cast<double2 *>(dst) = *reinterpret_cast<const double2 *>(tout + t);
+        }
+      }
     }
   }
   if (DO_S) {
@@ -885,25 +917,25 @@ __global__ __launch_bounds__(kRedThreads) void p_update_kernel(
 // src/expectation_maximization.py:157-167.  One thread per triple (original order).
 __global__ __launch_bounds__(kBlock) void likelihood_kernel(
     const int32_t *__restrict__ tu, const int32_t *__restrict__ ti,
-    const int32_t *__restrict__ tr, const double *__restrict__ theta,
+    const int32_t *__restrict__ tr, RowTab theta,
     const double *__restrict__ eta, const double *__restrict__ p, double *__restrict__ block_out,
     int64_t n_obs, int k_groups, int l_groups, int kp, int lp) {
   __shared__ double red[kBlock];
   double total = 0.0;
   for (int64_t n = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; n < n_obs;
        n += static_cast<int64_t>(gridDim.x) * kBlock) {
-    const double *th = theta + static_cast<size_t>(tu[n]) * kp;
+    const size_t urow = static_cast<size_t>(tu[n]);
     const double *et = eta + static_cast<size_t>(ti[n]) * lp;
     const double *pr = p + static_cast<size_t>(tr[n]) * kp * lp;
     double s = 0.0;
     for (int k = 0; k < k_groups; ++k) {
-      const double tk = th[k];
+      const double tk = *rowtab_ptr(theta, urow, k);
       for (int l = 0; l < l_groups; ++l) s += (tk * et[l]) * pr[k * lp + l];
     }
     const double ls = log(fmax(s, kEps));
     double acc = 0.0;
     for (int k = 0; k < k_groups; ++k) {
-      const double tk = th[k];
+      const double tk = *rowtab_ptr(theta, urow, k);
       for (int l = 0; l < l_groups; ++l) {
         const double w = fmax((tk * et[l]) * pr[k * lp + l], kEps);
         acc += w * log(w) - w * ls;
@@ -923,19 +955,19 @@ __global__ __launch_bounds__(kBlock) void likelihood_kernel(
 // src/kernels_numpy.py:86-96.  One thread per (pair, rating).
 __global__ __launch_bounds__(kBlock) void prod_dist_kernel(
     const int32_t *__restrict__ pu, const int32_t *__restrict__ pi,
-    const double *__restrict__ theta, const double *__restrict__ eta,
+    RowTab theta, const double *__restrict__ eta,
     const double *__restrict__ p, double *__restrict__ out, int64_t n_pairs, int n_ratings,
     int k_groups, int l_groups, int kp, int lp) {
   const int64_t e = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
   if (e >= n_pairs * n_ratings) return;
   const int64_t m = e / n_ratings;
   const int r = static_cast<int>(e % n_ratings);
-  const double *th = theta + static_cast<size_t>(pu[m]) * kp;
+  const size_t urow = static_cast<size_t>(pu[m]);
   const double *et = eta + static_cast<size_t>(pi[m]) * lp;
   const double *pr = p + static_cast<size_t>(r) * kp * lp;
   double acc = 0.0;
   for (int k = 0; k < k_groups; ++k) {
-    const double tk = th[k];
+    const double tk = *rowtab_ptr(theta, urow, k);
     double inner = 0.0;
     for (int l = 0; l < l_groups; ++l) inner = fma(et[l], pr[k * lp + l], inner);
     acc = fma(tk, inner, acc);
@@ -947,7 +979,7 @@ __global__ __launch_bounds__(kBlock) void prod_dist_kernel(
 // internal (k, l) indices (they differ from (L, 1) when the sides are swapped).
 __global__ __launch_bounds__(kBlock) void omegas_kernel(
     const int32_t *__restrict__ tu, const int32_t *__restrict__ ti,
-    const int32_t *__restrict__ tr, const double *__restrict__ theta,
+    const int32_t *__restrict__ tr, RowTab theta,
     const double *__restrict__ eta, const double *__restrict__ p, double *__restrict__ out,
     int64_t n_elems, int k_groups, int l_groups, int kp, int lp, int sk, int sl) {
   const int64_t e = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
@@ -956,7 +988,7 @@ __global__ __launch_bounds__(kBlock) void omegas_kernel(
   const int64_t n = e / kl;
   const int rem = static_cast<int>(e % kl);
   const int k = rem / l_groups, l = rem % l_groups;
-  const double v = (theta[static_cast<size_t>(tu[n]) * kp + k] *
+  const double v = (*rowtab_ptr(theta, static_cast<size_t>(tu[n]), k) *
                     eta[static_cast<size_t>(ti[n]) * lp + l]) *
                    p[static_cast<size_t>(tr[n]) * kp * lp + k * lp + l];
   out[n * kl + static_cast<int64_t>(k) * sk + static_cast<int64_t>(l) * sl] = v;
@@ -1043,6 +1075,7 @@ struct mmsbm_hip_ctx {
   int code_k = 0, code_l = 0, nacc = 1;
   int ablate = 0;           // tuning aid (mmsbm_hip_time_stage): phases pair_block skips
   bool fused = false;       // pair_block path (else: pair_matvec + p_partial fallback)
+  bool split_rows = false;  // theta and A kept as 128-byte main lines + tail rows (RowTab)
   int pb_spb = kBlock, pb_nacc = 1, pb_nsub = 1;  // pair_block S phase: threads per slot-grid copy, slots per thread
   bool rolefuse = false;    // user segments ride as filler blocks inside the dense launches
   float fill_frac[3] = {0.55f, 0.20f, 0.25f};  // share of the user segments per dense launch
@@ -1163,25 +1196,39 @@ void launch_group_matvec(mmsbm_hip_ctx *c, const double *tiles, const double *in
 // ---- the stages of one EM iteration ---------------------------------------------------------
 // commit: parameters advance (theta, eta, p normalised, A refreshed); otherwise the
 // un-normalised numerators are left in the "next" buffers / npr.
+// split (main/tail) tables: theta and A when the fused kernels are in use; plain otherwise
+RowTab plain_tab(double *base, int width) { return RowTab{base, 0, width, 0}; }
+RowTab gather_tab(const mmsbm_hip_ctx *c, double *base, size_t rows) {
+  int mw = c->split_rows ? (c->kp / 16) * 16 : c->kp;
+  if (mw == 0) mw = c->kp;
+  return RowTab{base, rows * static_cast<size_t>(mw), mw, c->kp - mw};
+}
+RowTab theta_tab(const mmsbm_hip_ctx *c, int slot) {
+  return gather_tab(c, c->theta[slot].ptr, static_cast<size_t>(c->n_users));
+}
+RowTab a_tab(const mmsbm_hip_ctx *c, int slot) {
+  return gather_tab(c, c->atab[slot].ptr, static_cast<size_t>(c->n_pairs));
+}
+
 SegArgs seg_pairs_args(const mmsbm_hip_ctx *c) {  // C = sum over a pair's triples
-  return SegArgs{c->atab[c->cur].ptr, c->theta[c->cur].ptr, c->pair_off.ptr, c->pair_user.ptr,
-                 c->ctab.ptr,         c->n_pairs,            0};
+  return SegArgs{a_tab(c, c->cur), theta_tab(c, c->cur), c->pair_off.ptr, c->pair_user.ptr,
+                 plain_tab(c->ctab.ptr, c->kp), c->n_pairs, 0};
 }
 SegArgs seg_users_args(const mmsbm_hip_ctx *c, bool commit, int seg_end) {  // theta_new
-  return SegArgs{c->theta[c->cur].ptr,     c->atab[c->cur].ptr, c->user_off.ptr, c->user_pair.ptr,
-                 c->theta[c->cur ^ 1].ptr, seg_end,             commit ? 1 : 2};
+  return SegArgs{theta_tab(c, c->cur),     a_tab(c, c->cur), c->user_off.ptr, c->user_pair.ptr,
+                 theta_tab(c, c->cur ^ 1), seg_end,          commit ? 1 : 2};
 }
 PairBlockArgs pair_block_t_args(const mmsbm_hip_ctx *c) {
   return PairBlockArgs{c->p[c->cur].ptr, c->ctab.ptr,        c->eta[c->cur].ptr, c->pair_item.ptr,
                        c->mv_chunks.ptr, c->ttab.ptr,        c->partial.ptr,     c->k,
                        c->kp,            c->lp,              c->pb_spb,          c->pb_nsub,
-                       c->ablate};
+                       c->ablate,        c->lp,              0};
 }
 PairBlockArgs pair_block_a_args(const mmsbm_hip_ctx *c, int param_slot, int a_slot) {
   return PairBlockArgs{c->pt[param_slot].ptr, c->eta[param_slot].ptr, nullptr, c->pair_item.ptr,
                        c->mv_chunks.ptr,      c->atab[a_slot].ptr,    nullptr, c->l,
                        c->lp,                 c->kp,                  kBlock,  1,
-                       c->ablate};
+                       c->ablate,             a_tab(c, a_slot).mw,    a_tab(c, a_slot).tail_off};
 }
 EtaPArgs eta_p_args(const mmsbm_hip_ctx *c, bool commit, int cols_per_block) {
   const int cur = c->cur, nxt = cur ^ 1;
@@ -1434,24 +1481,37 @@ void require_params(const mmsbm_hip_ctx *c) {
 }
 
 // host (rows, d) row-major  <->  device (rows, dp) zero-padded
-void upload_rows(mmsbm_hip_ctx *c, double *dev, const double *host, int rows, int d, int dp) {
-  if (d == dp) {
-    HIP_CHECK(hipMemcpyAsync(dev, host, sizeof(double) * rows * d, hipMemcpyHostToDevice,
+// host (rows, d) row-major  <->  device RowTab (rows, dp) zero-padded, main + tail parts
+void upload_rows(mmsbm_hip_ctx *c, const RowTab &t, const double *host, int rows, int d) {
+  const int dp = t.mw + t.tw;
+  if (d == dp && t.tw == 0) {
+    HIP_CHECK(hipMemcpyAsync(t.base, host, sizeof(double) * rows * d, hipMemcpyHostToDevice,
                              c->stream));
-  } else {
-    HIP_CHECK(hipMemsetAsync(dev, 0, sizeof(double) * rows * dp, c->stream));
-    HIP_CHECK(hipMemcpy2DAsync(dev, sizeof(double) * dp, host, sizeof(double) * d,
-                               sizeof(double) * d, rows, hipMemcpyHostToDevice, c->stream));
+    return;
   }
+  HIP_CHECK(hipMemsetAsync(t.base, 0, sizeof(double) * rows * dp, c->stream));
+  const int wm = std::min(d, t.mw);
+  HIP_CHECK(hipMemcpy2DAsync(t.base, sizeof(double) * t.mw, host, sizeof(double) * d,
+                             sizeof(double) * wm, rows, hipMemcpyHostToDevice, c->stream));
+  if (t.tw > 0 && d > t.mw)
+    HIP_CHECK(hipMemcpy2DAsync(t.base + t.tail_off, sizeof(double) * t.tw, host + t.mw,
+                               sizeof(double) * d, sizeof(double) * (d - t.mw), rows,
+                               hipMemcpyHostToDevice, c->stream));
 }
-void download_rows(mmsbm_hip_ctx *c, double *host, const double *dev, int rows, int d, int dp) {
-  if (d == dp) {
-    HIP_CHECK(hipMemcpyAsync(host, dev, sizeof(double) * rows * d, hipMemcpyDeviceToHost,
+void download_rows(mmsbm_hip_ctx *c, double *host, const RowTab &t, int rows, int d) {
+  const int dp = t.mw + t.tw;
+  if (d == dp && t.tw == 0) {
+    HIP_CHECK(hipMemcpyAsync(host, t.base, sizeof(double) * rows * d, hipMemcpyDeviceToHost,
                              c->stream));
-  } else {
-    HIP_CHECK(hipMemcpy2DAsync(host, sizeof(double) * d, dev, sizeof(double) * dp,
-                               sizeof(double) * d, rows, hipMemcpyDeviceToHost, c->stream));
+    return;
   }
+  const int wm = std::min(d, t.mw);
+  HIP_CHECK(hipMemcpy2DAsync(host, sizeof(double) * d, t.base, sizeof(double) * t.mw,
+                             sizeof(double) * wm, rows, hipMemcpyDeviceToHost, c->stream));
+  if (t.tw > 0 && d > t.mw)
+    HIP_CHECK(hipMemcpy2DAsync(host + t.mw, sizeof(double) * d, t.base + t.tail_off,
+                               sizeof(double) * t.tw, sizeof(double) * (d - t.mw), rows,
+                               hipMemcpyDeviceToHost, c->stream));
 }
 
 // device p layout [R][kp][lp] (internal k, l)  <->  host pr (K, L, R) external
@@ -1589,6 +1649,7 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
     c->lds_a = pair_block_lds(c->lp, c->kp, false);
     c->fused = c->lds_t <= kLdsMax && c->lds_a <= kLdsMax;
     if (c->pb_nacc > 8) c->fused = false;
+    c->split_rows = c->fused;  // the fallback mat-vec writes plain A rows
     c->rolefuse = false;  // measured slower at C3 (the filler inherits the dense roles' VGPR/LDS
                           // footprint); kept as a tuning option, see mmsbm_hip_set_option
     if (matvec_gpb(c->kp, c->lp, group_lanes(c->code_l)) < 1 ||
@@ -1701,8 +1762,8 @@ int mmsbm_hip_set_params(mmsbm_hip_ctx *ctx, const double *theta, const double *
     const double *it = ctx->swapped ? eta : theta;  // internal theta rows = internal users
     const double *ie = ctx->swapped ? theta : eta;
     const int cur = ctx->cur;
-    upload_rows(ctx, ctx->theta[cur].ptr, it, ctx->n_users, ctx->k, ctx->kp);
-    upload_rows(ctx, ctx->eta[cur].ptr, ie, ctx->n_items, ctx->l, ctx->lp);
+    upload_rows(ctx, theta_tab(ctx, cur), it, ctx->n_users, ctx->k);
+    upload_rows(ctx, plain_tab(ctx->eta[cur].ptr, ctx->lp), ie, ctx->n_items, ctx->l);
     std::vector<double> p, pt;
     p_host_to_dev(ctx, pr, p, pt);
     HIP_CHECK(hipMemcpyAsync(ctx->p[cur].ptr, p.data(), sizeof(double) * p.size(),
@@ -1722,8 +1783,8 @@ int mmsbm_hip_get_params(mmsbm_hip_ctx *ctx, double *theta, double *eta, double 
     double *it = ctx->swapped ? eta : theta;
     double *ie = ctx->swapped ? theta : eta;
     const int cur = ctx->cur;
-    if (it) download_rows(ctx, it, ctx->theta[cur].ptr, ctx->n_users, ctx->k, ctx->kp);
-    if (ie) download_rows(ctx, ie, ctx->eta[cur].ptr, ctx->n_items, ctx->l, ctx->lp);
+    if (it) download_rows(ctx, it, theta_tab(ctx, cur), ctx->n_users, ctx->k);
+    if (ie) download_rows(ctx, ie, plain_tab(ctx->eta[cur].ptr, ctx->lp), ctx->n_items, ctx->l);
     std::vector<double> p;
     if (pr) {
       p.resize(ctx->p[cur].count);
@@ -1761,8 +1822,8 @@ int mmsbm_hip_update_coefficients(mmsbm_hip_ctx *ctx, double *n_theta, double *n
     const int nxt = ctx->cur ^ 1;
     double *it = ctx->swapped ? n_eta : n_theta;
     double *ie = ctx->swapped ? n_theta : n_eta;
-    if (it) download_rows(ctx, it, ctx->theta[nxt].ptr, ctx->n_users, ctx->k, ctx->kp);
-    if (ie) download_rows(ctx, ie, ctx->eta[nxt].ptr, ctx->n_items, ctx->l, ctx->lp);
+    if (it) download_rows(ctx, it, theta_tab(ctx, nxt), ctx->n_users, ctx->k);
+    if (ie) download_rows(ctx, ie, plain_tab(ctx->eta[nxt].ptr, ctx->lp), ctx->n_items, ctx->l);
     std::vector<double> p;
     if (n_pr) {
       p.resize(ctx->npr.count);
@@ -1783,7 +1844,7 @@ int mmsbm_hip_likelihood(mmsbm_hip_ctx *ctx, double *out) {
     int nb = static_cast<int>(std::min<int64_t>((ctx->n_obs + kBlock - 1) / kBlock, 4096));
     nb = std::max(nb, 1);
     likelihood_kernel<<<nb, kBlock, 0, ctx->stream>>>(
-        ctx->orig_u.ptr, ctx->orig_i.ptr, ctx->orig_r.ptr, ctx->theta[cur].ptr,
+        ctx->orig_u.ptr, ctx->orig_i.ptr, ctx->orig_r.ptr, theta_tab(ctx, cur),
         ctx->eta[cur].ptr, ctx->p[cur].ptr, ctx->lik_part.ptr, ctx->n_obs, ctx->k, ctx->l,
         ctx->kp, ctx->lp);
     HIP_CHECK(hipGetLastError());
@@ -1818,7 +1879,7 @@ int mmsbm_hip_compute_omegas(mmsbm_hip_ctx *ctx, double *out, int64_t capacity_e
     const int sl = ctx->swapped ? ctx->k : 1;
     const int64_t nb = (n_elems + kBlock - 1) / kBlock;
     omegas_kernel<<<static_cast<unsigned>(nb), kBlock, 0, ctx->stream>>>(
-        ctx->orig_u.ptr, ctx->orig_i.ptr, ctx->orig_r.ptr, ctx->theta[cur].ptr,
+        ctx->orig_u.ptr, ctx->orig_i.ptr, ctx->orig_r.ptr, theta_tab(ctx, cur),
         ctx->eta[cur].ptr, ctx->p[cur].ptr, dev.ptr, n_elems, ctx->k, ctx->l, ctx->kp, ctx->lp,
         sk, sl);
     HIP_CHECK(hipGetLastError());
@@ -1852,7 +1913,7 @@ int mmsbm_hip_prod_dist(mmsbm_hip_ctx *ctx, int64_t n_pairs, const int32_t *user
     const int cur = ctx->cur;
     const int64_t nb = (n_elems + kBlock - 1) / kBlock;
     prod_dist_kernel<<<static_cast<unsigned>(nb), kBlock, 0, ctx->stream>>>(
-        du.ptr, di.ptr, ctx->theta[cur].ptr, ctx->eta[cur].ptr, ctx->p[cur].ptr, dout.ptr,
+        du.ptr, di.ptr, theta_tab(ctx, cur), ctx->eta[cur].ptr, ctx->p[cur].ptr, dout.ptr,
         n_pairs, ctx->n_ratings, ctx->k, ctx->l, ctx->kp, ctx->lp);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipMemcpyAsync(out, dout.ptr, sizeof(double) * n_elems, hipMemcpyDeviceToHost, ctx->stream));
