@@ -798,17 +798,36 @@ __device__ __forceinline__ void p_update_block(
     }
     __syncthreads();
     if (ty == 0 && ok) {
-      for (int j = 0; j < nr; ++j) {
-        double tot = red[j][0][tx];
 #pragma unroll
-        for (int i = 1; i < 8; ++i) tot += red[j][i][tx];
-        const size_t e = static_cast<size_t>(r0 + j) * kl + col;
-        const double raw = p_old[e] * tot;
-        npr[e] = raw;
-        tot_all += raw;
+      for (int j = 0; j < kRedGroup; ++j) {
+        if (j < nr) {
+          double tot = red[j][0][tx];
+#pragma unroll
+          for (int i = 1; i < 8; ++i) tot += red[j][i][tx];
+          const size_t e = static_cast<size_t>(r0 + j) * kl + col;
+          const double raw = p_old[e] * tot;
+          npr[e] = raw;
+          tot_all += raw;
+          s[j] = raw;  // stays in registers for the single-group case below
+        }
       }
     }
     __syncthreads();
+    if (n_ratings <= kRedGroup) {  // common case: normalise straight from registers
+      if (ty == 0 && ok && normalize) {
+        const double den = (tot_all == 0.0) ? 1.0 : tot_all;
+        const int k = col / lp, l = col % lp;
+#pragma unroll
+        for (int j = 0; j < kRedGroup; ++j) {
+          if (j < nr) {
+            const double v = s[j] / den;
+            p_new[static_cast<size_t>(j) * kl + col] = v;
+            pt_new[static_cast<size_t>(j) * kl + static_cast<size_t>(l) * kp + k] = v;
+          }
+        }
+      }
+      return;
+    }
   }
   if (ty == 0 && ok && normalize) {
     const double den = (tot_all == 0.0) ? 1.0 : tot_all;
@@ -832,7 +851,7 @@ __device__ __forceinline__ void item_sum_block(
     const int32_t *__restrict__ item_pairs, const int32_t *__restrict__ item_deg,
     const double *__restrict__ eta, double *__restrict__ eta_new, int n_items, int lp,
     int normalize) {
-  constexpr int B = 4;
+  constexpr int B = 8;
   const int it = block * (static_cast<int>(blockDim.x) / G) + threadIdx.x / G;
   const int gl = threadIdx.x % G;
   if (it >= n_items || gl * VEC >= lp) return;

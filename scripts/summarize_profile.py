@@ -22,7 +22,8 @@ def short(name):
             return nm
     return None
 
-stats = glob.glob(os.path.join(src, f"prof_{tag}_trace", "*", "*_kernel_stats.csv"))
+newest = lambda pat: sorted(glob.glob(pat), key=os.path.getmtime)[-1:]
+stats = newest(os.path.join(src, f"prof_{tag}_trace", "*", "*_kernel_stats.csv"))
 rows = []
 if stats:
     for r in csv.DictReader(open(stats[0])):
@@ -37,7 +38,7 @@ if stats:
 
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for part in ("fetch", "write", "l2", "sq"):
-    for f in glob.glob(os.path.join(src, f"prof_{tag}_{part}", "*", "*_counter_collection.csv")):
+    for f in newest(os.path.join(src, f"prof_{tag}_{part}", "*", "*_counter_collection.csv")):
         for r in csv.DictReader(open(f)):
             nm = short(r["Kernel_Name"])
             if nm:
