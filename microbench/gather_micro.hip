@@ -156,6 +156,62 @@ __global__ __launch_bounds__(256) void gather_flat(const double* __restrict__ fi
   if (act) *reinterpret_cast<double2*>(out + (size_t)(grp % nseg) * 20 + lo) = acc;
 }
 
+// P2: like P1 split, but every group works on TWO segments at once (seg 2g and 2g+1) so the
+// offset -> index -> row chains of the two overlap.
+template <int B>
+__global__ __launch_bounds__(256) void gather_p2(const double* __restrict__ fixed, const double* __restrict__ tab,
+                                                 const double* __restrict__ tail, const int* __restrict__ off,
+                                                 const int* __restrict__ idx, double* __restrict__ out, int nseg,
+                                                 int stride, int k) {
+  const int grp = blockIdx.x * 16 + threadIdx.x / 16, gl = threadIdx.x % 16;
+  const int sA = grp * 2, sB = grp * 2 + 1;
+  if (sA >= nseg) return;
+  const bool hasB = sB < nseg;
+  const bool act = gl * 2 < k;
+  const int lo = act ? gl * 2 : 0;
+  const double* gbase = (lo < 16) ? tab + lo : tail + (lo - 16);
+  const size_t gstride = (lo < 16) ? 16 : 4;
+  int beg[2], end[2];
+  beg[0] = off[sA]; end[0] = off[sA + 1]; beg[1] = hasB ? off[sB] : 0; end[1] = hasB ? off[sB + 1] : 0;
+  double2 f[2], acc[2];
+  f[0] = *reinterpret_cast<const double2*>(fixed + (size_t)sA * 20 + lo);
+  f[1] = *reinterpret_cast<const double2*>(fixed + (size_t)(hasB ? sB : sA) * 20 + lo);
+  if (!act) { f[0].x = f[0].y = f[1].x = f[1].y = 0; }
+  acc[0].x = acc[0].y = acc[1].x = acc[1].y = 0;
+  int mine[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) mine[s] = (end[s] > beg[s]) ? idx[beg[s] + min(gl, end[s] - beg[s] - 1)] : 0;  // segments <= 16 here
+  const int cnt0 = end[0] - beg[0], cnt1 = end[1] - beg[1];
+  const int cmax = max(cnt0, cnt1);
+  for (int n = 0; n < cmax; n += B) {
+    double2 g[2][B];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int cnt = s ? cnt1 : cnt0;
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+        const int id = __shfl(mine[s], min(n + b, max(cnt - 1, 0)), 16);
+        g[s][b] = *reinterpret_cast<const double2*>(gbase + (size_t)id * gstride);
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int cnt = s ? cnt1 : cnt0;
+#pragma unroll
+      for (int b = 0; b < B; ++b) if (n + b < cnt) {
+        double part = fma(g[s][b].x, f[s].x, g[s][b].y * f[s].y);
+        const double sm = sum16(part);
+        const double w = 1.0 / fmax(sm, 2.2e-16);
+        acc[s].x = fma(g[s][b].x, w, acc[s].x); acc[s].y = fma(g[s][b].y, w, acc[s].y);
+      }
+    }
+  }
+  if (act) {
+    *reinterpret_cast<double2*>(out + (size_t)sA * 20 + lo) = acc[0];
+    if (hasB) *reinterpret_cast<double2*>(out + (size_t)sB * 20 + lo) = acc[1];
+  }
+}
+
 int main() {
   const int nseg = 100000, deg = 10, rows = 100000, k = 20;
   const int n = nseg * deg;
@@ -208,6 +264,11 @@ int main() {
   run("P1 packed B=4 pipelined", gather_p1<0, 4, true>, 20, 20);
   run("P1 packed B=6 pipelined", gather_p1<0, 6, true>, 20, 20);
   run("P1 split B=4", gather_p1<1, 4, false>, 16, 20);
+  grid_override = (nseg / 2 + 15) / 16;
+  run("P2 split two segments per group B=4", gather_p2<4>, 16, 20);
+  run("P2 split two segments per group B=6", gather_p2<6>, 16, 20);
+  run("P2 split two segments per group B=10", gather_p2<10>, 16, 20);
+  grid_override = 0;
   run("P1 split B=8", gather_p1<1, 8, false>, 16, 20);
   run("P1 split B=12", gather_p1<1, 12, false>, 16, 20);
   run("P1 split B=16", gather_p1<1, 16, false>, 16, 20);

@@ -188,14 +188,17 @@ __device__ __forceinline__ void seg_body(const SegArgs &a, int seg, int dp) {
                                : a.gath.base + a.gath.tail_off + (lane_off - a.gath.mw);
   const size_t gstride = g_main ? a.gath.mw : a.gath.tw;
   const int beg = a.off[seg], end = a.off[seg + 1];
-  for (int c0 = beg; c0 < end; c0 += G) {
-    const int cnt = min(G, end - c0);
-    const int mine = a.idx[c0 + min(gl, cnt - 1)];
+  constexpr int CH = (G < 16) ? 2 * G : G;  // indices fetched per chunk (two per lane in small groups)
+  for (int c0 = beg; c0 < end; c0 += CH) {
+    const int cnt = min(CH, end - c0);
+    const int mine0 = a.idx[c0 + min(gl, cnt - 1)];
+    const int mine1 = (CH > G) ? a.idx[c0 + min(G + gl, cnt - 1)] : 0;
     for (int n = 0; n < cnt; n += B) {
       double g[B][VEC];
 #pragma unroll
       for (int b = 0; b < B; ++b) {
-        const int id = __shfl(mine, min(n + b, cnt - 1), G);
+        const int j = min(n + b, cnt - 1);
+        const int id = __shfl((CH > G && j >= G) ? mine1 : mine0, j, G);
         load_vec<VEC>(gbase + static_cast<size_t>(id) * gstride, g[b]);
       }
 #pragma unroll
@@ -1023,28 +1026,28 @@ int pad_dim(int d) {  // multiples of 4: 32-byte row granules, whole chunks of 4
 }
 
 // (G, VEC) instantiation for a padded row length: code 0..6
+// Four doubles (32 bytes) per lane: fewer lanes per row means more rows per wave instruction,
+// i.e. less vector-ALU work (dot product, DPP reduction, division) per triple.
 int group_code(int dp) {
-  if (dp <= 8) return 0;    // G=4  VEC=2
-  if (dp <= 16) return 1;   // G=8  VEC=2
-  if (dp <= 32) return 2;   // G=16 VEC=2
-  if (dp <= 64) return 3;   // G=32 VEC=2
-  if (dp <= 128) return 4;  // G=64 VEC=2
-  if (dp <= 256) return 5;  // G=64 VEC=4
-  return 6;                 // G=64 VEC=8
+  if (dp <= 16) return 0;   // G=4  VEC=4
+  if (dp <= 32) return 1;   // G=8  VEC=4
+  if (dp <= 64) return 2;   // G=16 VEC=4
+  if (dp <= 128) return 3;  // G=32 VEC=4
+  if (dp <= 256) return 4;  // G=64 VEC=4
+  return 5;                 // G=64 VEC=8
 }
 int group_lanes(int code) {
-  static const int g[7] = {4, 8, 16, 32, 64, 64, 64};
+  static const int g[6] = {4, 8, 16, 32, 64, 64};
   return g[code];
 }
 
 #define DISPATCH_GV(code, CALL)                                   \
   switch (code) {                                                 \
-    case 0: CALL(4, 2); break;                                    \
-    case 1: CALL(8, 2); break;                                    \
-    case 2: CALL(16, 2); break;                                   \
-    case 3: CALL(32, 2); break;                                   \
-    case 4: CALL(64, 2); break;                                   \
-    case 5: CALL(64, 4); break;                                   \
+    case 0: CALL(4, 4); break;                                    \
+    case 1: CALL(8, 4); break;                                    \
+    case 2: CALL(16, 4); break;                                   \
+    case 3: CALL(32, 4); break;                                   \
+    case 4: CALL(64, 4); break;                                   \
     default: CALL(64, 8); break;                                  \
   }
 
@@ -1395,10 +1398,10 @@ void launch_fused_eta_p(mmsbm_hip_ctx *c, const SegArgs &fill, int seg0, int nfi
   const int nb_i = (c->n_items + per - 1) / per;
   const int grid = a.nb_p + nb_i + nfill;
   switch (c->code_l) {
-    case 0: eta_p_fill_kernel<4, 2, G, V><<<grid, kBlock, 0, c->stream>>>(a, nb_i, fill, seg0, c->kp); break;
-    case 1: eta_p_fill_kernel<8, 2, G, V><<<grid, kBlock, 0, c->stream>>>(a, nb_i, fill, seg0, c->kp); break;
-    case 2: eta_p_fill_kernel<16, 2, G, V><<<grid, kBlock, 0, c->stream>>>(a, nb_i, fill, seg0, c->kp); break;
-    default: eta_p_fill_kernel<32, 2, G, V><<<grid, kBlock, 0, c->stream>>>(a, nb_i, fill, seg0, c->kp); break;
+    case 0: eta_p_fill_kernel<4, 4, G, V><<<grid, kBlock, 0, c->stream>>>(a, nb_i, fill, seg0, c->kp); break;
+    case 1: eta_p_fill_kernel<8, 4, G, V><<<grid, kBlock, 0, c->stream>>>(a, nb_i, fill, seg0, c->kp); break;
+    case 2: eta_p_fill_kernel<16, 4, G, V><<<grid, kBlock, 0, c->stream>>>(a, nb_i, fill, seg0, c->kp); break;
+    default: eta_p_fill_kernel<32, 4, G, V><<<grid, kBlock, 0, c->stream>>>(a, nb_i, fill, seg0, c->kp); break;
   }
 }
 template <int G, int V>
@@ -1413,10 +1416,10 @@ void launch_fused_dense_a(mmsbm_hip_ctx *c, const SegArgs &fill, int seg0, int n
 
 #define DISPATCH_SMALL_GV(code, FN, ...)                          \
   switch (code) {                                                 \
-    case 0: FN<4, 2>(__VA_ARGS__); break;                         \
-    case 1: FN<8, 2>(__VA_ARGS__); break;                         \
-    case 2: FN<16, 2>(__VA_ARGS__); break;                        \
-    default: FN<32, 2>(__VA_ARGS__); break;                       \
+    case 0: FN<4, 4>(__VA_ARGS__); break;                         \
+    case 1: FN<8, 4>(__VA_ARGS__); break;                         \
+    case 2: FN<16, 4>(__VA_ARGS__); break;                        \
+    default: FN<32, 4>(__VA_ARGS__); break;                       \
   }
 
 //   launch 0 : pair segments (C)

@@ -256,5 +256,20 @@ def edge():
     save("edge_cases", **out)
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and not os.environ.get("MMSBM_GOLDEN_ONLY"):
     g0(); g1_g3(); g4(); g5(); edge()
+
+
+def g6_cv():
+    """The reference's cv_fit test case (tests/test_mmsbm.py:30-34,57-61): folds=2 on mock_data(1)."""
+    df1 = mock_frame(1)
+    mm = MMSBM(2, 2, iterations=10, seed=1, backend="numpy")
+    acc = mm.cv_fit(df1.copy(), folds=2)
+    out = {"accuracies": np.array(acc, dtype=np.float64)}
+    out.update(frame_cols(df1, "raw"))
+    out["best_prediction_matrix"] = mm.prediction_matrix
+    save("g6_cv_fit", **out)
+
+
+if __name__ == "__main__" and os.environ.get("MMSBM_GOLDEN_ONLY", "g6") == "g6":
+    g6_cv()

@@ -347,3 +347,15 @@ def test_launch_modes_give_identical_results(hip, opt):
             outs.append(em.get_params())
     for a, b in zip(*outs):
         assert np.array_equal(a, b)
+
+
+def test_cv_fit_matches_reference(hip):
+    """The reference's cv_fit test case (tests/test_mmsbm.py:30-34,57-61): folds=2, accuracies 0.125, 0.16."""
+    import pandas as pd
+    g = load_golden("g6_cv_fit")
+    df = pd.DataFrame({"users": g["raw_users"], "items": g["raw_items"], "ratings": g["raw_ratings"]})
+    mm = hip.MMSBM(2, 2, iterations=10, seed=1)
+    acc = mm.cv_fit(df, folds=2)
+    assert acc == pytest.approx(g["accuracies"].tolist(), rel=1e-9)
+    assert acc[0] == pytest.approx(0.125, 0.01) and acc[1] == pytest.approx(0.16, 0.01)
+    assert np.allclose(mm.prediction_matrix, g["best_prediction_matrix"], rtol=1e-8, atol=1e-12)
