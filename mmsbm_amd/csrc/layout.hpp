@@ -69,13 +69,34 @@ inline void build_layout(int64_t n_obs, int32_t n_users, int32_t n_items, int32_
   L.n_obs = n_obs; L.n_users = n_users; L.n_items = n_items; L.n_ratings = n_ratings;
 
   // ---- sort by (rating, item, user) -------------------------------------------------
+  // Two stable counting sorts (user, then pair key) when the key space is small enough --
+  // O(N + U + R*I) -- else a comparison sort.
   struct Key { uint64_t pk; uint32_t u; };
   std::vector<Key> keys(static_cast<size_t>(n_obs));
-  for (int64_t n = 0; n < n_obs; ++n)
-    keys[n] = Key{uint64_t(rating[n]) * uint64_t(n_items) + uint64_t(item[n]), uint32_t(user[n])};
-  std::sort(keys.begin(), keys.end(), [](const Key &a, const Key &b) {
-    return a.pk != b.pk ? a.pk < b.pk : a.u < b.u;
-  });
+  const uint64_t key_space = uint64_t(n_ratings) * uint64_t(n_items);
+  if (key_space <= (uint64_t(1) << 26)) {
+    std::vector<uint32_t> by_user(static_cast<size_t>(n_obs));
+    {
+      std::vector<int64_t> cnt(size_t(n_users) + 1, 0);
+      for (int64_t n = 0; n < n_obs; ++n) cnt[size_t(user[n]) + 1]++;
+      for (int u = 0; u < n_users; ++u) cnt[u + 1] += cnt[u];
+      for (int64_t n = 0; n < n_obs; ++n) by_user[size_t(cnt[user[n]]++)] = uint32_t(n);
+    }
+    std::vector<int64_t> cnt(size_t(key_space) + 1, 0);
+    for (int64_t n = 0; n < n_obs; ++n) cnt[size_t(rating[n]) * n_items + item[n] + 1]++;
+    for (uint64_t k = 0; k < key_space; ++k) cnt[k + 1] += cnt[k];
+    for (int64_t j = 0; j < n_obs; ++j) {
+      const uint32_t n = by_user[size_t(j)];
+      const uint64_t pk = uint64_t(rating[n]) * uint64_t(n_items) + uint64_t(item[n]);
+      keys[size_t(cnt[pk]++)] = Key{pk, uint32_t(user[n])};
+    }
+  } else {
+    for (int64_t n = 0; n < n_obs; ++n)
+      keys[n] = Key{uint64_t(rating[n]) * uint64_t(n_items) + uint64_t(item[n]), uint32_t(user[n])};
+    std::sort(keys.begin(), keys.end(), [](const Key &a, const Key &b) {
+      return a.pk != b.pk ? a.pk < b.pk : a.u < b.u;
+    });
+  }
 
   L.pair_user.resize(n_obs);
   L.pair_off.clear(); L.pair_item.clear();

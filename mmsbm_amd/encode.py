@@ -13,15 +13,15 @@ import numpy as np
 
 
 def _columns(data):
-    """Three python-object columns from a DataFrame, an (N,3) array or a 3-tuple."""
+    """Three columns (typed arrays where possible) from a DataFrame, an (N,3) array or a 3-tuple."""
     if hasattr(data, "iloc"):  # pandas
-        return [data.iloc[:, j].tolist() for j in range(3)], list(data.columns[:3])
+        return [data.iloc[:, j].to_numpy() for j in range(3)], list(data.columns[:3])
     if isinstance(data, (tuple, list)) and len(data) == 3 and not np.isscalar(data[0]):
-        return [list(np.asarray(c).tolist()) for c in data], ["users", "items", "ratings"]
-    arr = np.asarray(data, dtype=object)
+        return [np.asarray(c) for c in data], ["users", "items", "ratings"]
+    arr = np.asarray(data)
     if arr.ndim != 2 or arr.shape[1] < 3:
         raise ValueError("expected three columns: users, items, ratings")
-    return [arr[:, j].tolist() for j in range(3)], ["users", "items", "ratings"]
+    return [arr[:, j] for j in range(3)], ["users", "items", "ratings"]
 
 
 def _as_str(col):
@@ -29,6 +29,26 @@ def _as_str(col):
         if v is None or (isinstance(v, float) and v != v):
             raise AssertionError("Data contains missing values. Aborting.")  # data_handler.py:24
     return np.array([str(v) for v in col], dtype=object).astype(str) if len(col) else np.array([], dtype=str)
+
+
+def _factorize_as_str(col):
+    """(ids, labels): labels = sorted distinct str(value); ids[n] = rank of str(col[n]).
+
+    Hash-factorises the raw values first (pandas, O(N)) and stringifies only the distinct
+    ones, so a million-row column costs milliseconds instead of a Python call per cell."""
+    import pandas as pd
+
+    if len(col) == 0:
+        return np.zeros(0, dtype=np.int64), np.array([], dtype=str)
+    col = np.asarray(col)
+    if col.dtype.kind in "US":  # fixed-width numpy strings hash slowly: go through object
+        col = col.astype(object)
+    codes, uniq = pd.factorize(col, use_na_sentinel=True)
+    if (codes < 0).any():
+        raise AssertionError("Data contains missing values. Aborting.")  # data_handler.py:24
+    as_str = np.array([str(v) for v in uniq.tolist()], dtype=object).astype(str)
+    labels, inv = np.unique(as_str, return_inverse=True)  # distinct raw values may share a string
+    return inv[codes].astype(np.int64), labels
 
 
 class Encoder:
@@ -41,27 +61,27 @@ class Encoder:
         cols, _ = _columns(data)
         self.labels, out = [], []
         for col in cols:
-            s = _as_str(col)
-            uniq, inv = np.unique(s, return_inverse=True) if len(s) else (s, np.array([], dtype=np.int64))
+            ids, uniq = _factorize_as_str(col)
             self.labels.append(uniq)
-            out.append(inv.astype(np.int64))
+            out.append(ids)
         return np.stack(out, axis=1) if len(out[0]) else np.zeros((0, 3), dtype=np.int64)
 
     def transform(self, data, logger=None):
         if self.labels is None:
             raise AssertionError("encoder has not seen training data")
         cols, names = _columns(data)
-        strs = [_as_str(c) for c in cols]
-        keep = np.ones(len(strs[0]), dtype=bool)
+        keep = np.ones(len(cols[0]), dtype=bool)
         ids = []
         log = logger or logging.getLogger("MMSBM")
-        for name, s, lab in zip(("users", "items", "ratings"), strs, self.labels):
-            pos = np.searchsorted(lab, s)
-            pos = np.minimum(pos, max(len(lab) - 1, 0))
-            hit = lab[pos] == s if len(lab) else np.zeros(len(s), dtype=bool)
+        for name, col, lab in zip(("users", "items", "ratings"), cols, self.labels):
+            codes, test_labels = _factorize_as_str(col)          # this frame's own dictionary
+            pos_l = np.searchsorted(lab, test_labels)
+            pos_l = np.minimum(pos_l, max(len(lab) - 1, 0))
+            hit_l = lab[pos_l] == test_labels if len(lab) else np.zeros(len(test_labels), dtype=bool)
+            pos, hit = pos_l[codes], hit_l[codes]
             # the reference filters column after column; a row only counts as "unseen" for a
             # column if it survived the previous ones (data_handler.py:119-127)
-            missing = sorted(set(s[keep & ~hit].tolist()))
+            missing = sorted(set(test_labels[np.unique(codes[keep & ~hit])].tolist()))
             if missing:
                 log.warning(f"The {name} {', '.join(missing)} are in the test set but weren't in "
                             f"the train set so I'll remove them.")
