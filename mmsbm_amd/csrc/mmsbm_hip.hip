@@ -974,6 +974,80 @@ __global__ __launch_bounds__(kBlock) void likelihood_kernel(
   if (threadIdx.x == 0) block_out[blockIdx.x] = red[0];
 }
 
+// Faster form of the same sum for the usual sizes: one thread per triple in PAIR order, a
+// workgroup per unit of <= 64 pairs of one rating.  Each thread parks its theta row and its
+// pair's eta row in LDS (transposed: conflict-free column reads), the rating tile is
+// lane-uniform and comes through scalar loads.  Element-wise formula and association order
+// are the reference's; only the order of the outer sum differs.
+constexpr int kLikThreads = 128;
+
+__global__ __launch_bounds__(kLikThreads) void likelihood_units_kernel(
+    const mmsbm::Chunk *__restrict__ units, const int32_t *__restrict__ pair_off,
+    const int32_t *__restrict__ pair_user, const int32_t *__restrict__ pair_item, RowTab theta,
+    const double *__restrict__ eta, const double *__restrict__ p, double *__restrict__ block_out,
+    int k_groups, int l_groups, int kp, int lp) {
+  extern __shared__ double lds[];
+  double *ths = lds;                                          // [kp][kLikThreads]
+  double *ets = lds + static_cast<size_t>(kp) * kLikThreads;  // [lp][kLikThreads]
+  __shared__ int32_t poff[kUnitPairs + 1];
+  __shared__ double red[kLikThreads];
+  const mmsbm::Chunk ch = units[blockIdx.x];
+  const int tid = threadIdx.x;
+  const int npairs = ch.q_end - ch.q_begin;
+  if (tid <= npairs) poff[tid] = pair_off[ch.q_begin + tid];
+  __syncthreads();
+  typedef const double __attribute__((address_space(4))) * const_tile_ptr;
+  const const_tile_ptr tile = (const_tile_ptr)(reinterpret_cast<uintptr_t>(
+      p + static_cast<size_t>(ch.rating) * kp * lp));
+  const int t0 = poff[0], t1 = poff[npairs];
+  double total = 0.0;
+  for (int base = t0; base < t1; base += kLikThreads) {
+    const int n = base + tid;
+    const bool have = n < t1;
+    int lo = 0, hi = npairs;  // pair of triple n: last q with poff[q] <= n
+    const int nn = have ? n : t1 - 1;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (poff[mid] <= nn) lo = mid; else hi = mid;
+    }
+    const size_t urow = static_cast<size_t>(pair_user[nn]);
+    const double *erow = eta + static_cast<size_t>(pair_item[ch.q_begin + lo]) * lp;
+    for (int k = 0; k < kp; k += 2) {
+      const double2 v = *reinterpret_cast<const double2 *>(rowtab_ptr(theta, urow, k));
+      ths[k * kLikThreads + tid] = v.x;
+      ths[(k + 1) * kLikThreads + tid] = v.y;
+    }
+    for (int l = 0; l < lp; l += 2) {
+      const double2 v = *reinterpret_cast<const double2 *>(erow + l);
+      ets[l * kLikThreads + tid] = v.x;
+      ets[(l + 1) * kLikThreads + tid] = v.y;
+    }
+    // own column only: no workgroup barrier needed between the writes above and the reads below
+    double s = 0.0;
+    for (int k = 0; k < k_groups; ++k) {
+      const double tk = ths[k * kLikThreads + tid];
+      for (int l = 0; l < l_groups; ++l) s += (tk * ets[l * kLikThreads + tid]) * tile[k * lp + l];
+    }
+    const double ls = log(fmax(s, kEps));
+    double acc = 0.0;
+    for (int k = 0; k < k_groups; ++k) {
+      const double tk = ths[k * kLikThreads + tid];
+      for (int l = 0; l < l_groups; ++l) {
+        const double w = fmax((tk * ets[l * kLikThreads + tid]) * tile[k * lp + l], kEps);
+        acc += w * log(w) - w * ls;
+      }
+    }
+    if (have) total += acc;
+  }
+  red[tid] = total;
+  __syncthreads();
+  for (int h = kLikThreads / 2; h > 0; h >>= 1) {
+    if (tid < h) red[tid] += red[tid + h];
+    __syncthreads();
+  }
+  if (tid == 0) block_out[blockIdx.x] = red[0];
+}
+
 // src/kernels_numpy.py:86-96.  One thread per (pair, rating).
 __global__ __launch_bounds__(kBlock) void prod_dist_kernel(
     const int32_t *__restrict__ pu, const int32_t *__restrict__ pi,
@@ -1863,12 +1937,23 @@ int mmsbm_hip_likelihood(mmsbm_hip_ctx *ctx, double *out) {
     if (!out) throw std::invalid_argument("null out");
     use_device(ctx);
     const int cur = ctx->cur;
-    int nb = static_cast<int>(std::min<int64_t>((ctx->n_obs + kBlock - 1) / kBlock, 4096));
-    nb = std::max(nb, 1);
-    likelihood_kernel<<<nb, kBlock, 0, ctx->stream>>>(
-        ctx->orig_u.ptr, ctx->orig_i.ptr, ctx->orig_r.ptr, theta_tab(ctx, cur),
-        ctx->eta[cur].ptr, ctx->p[cur].ptr, ctx->lik_part.ptr, ctx->n_obs, ctx->k, ctx->l,
-        ctx->kp, ctx->lp);
+    int nb;
+    const size_t lik_lds = static_cast<size_t>(ctx->kp + ctx->lp) * kLikThreads * sizeof(double);
+    if (lik_lds <= kLdsBudget - 2048 && !ctx->lay.mv_chunks.empty()) {
+      nb = static_cast<int>(ctx->lay.mv_chunks.size());
+      if (ctx->lik_part.count < static_cast<size_t>(nb)) ctx->lik_part.alloc(nb);
+      likelihood_units_kernel<<<nb, kLikThreads, lik_lds, ctx->stream>>>(
+          ctx->mv_chunks.ptr, ctx->pair_off.ptr, ctx->pair_user.ptr, ctx->pair_item.ptr,
+          theta_tab(ctx, cur), ctx->eta[cur].ptr, ctx->p[cur].ptr, ctx->lik_part.ptr, ctx->k, ctx->l,
+          ctx->kp, ctx->lp);
+    } else {
+      nb = static_cast<int>(std::min<int64_t>((ctx->n_obs + kBlock - 1) / kBlock, 4096));
+      nb = std::max(nb, 1);
+      likelihood_kernel<<<nb, kBlock, 0, ctx->stream>>>(
+          ctx->orig_u.ptr, ctx->orig_i.ptr, ctx->orig_r.ptr, theta_tab(ctx, cur),
+          ctx->eta[cur].ptr, ctx->p[cur].ptr, ctx->lik_part.ptr, ctx->n_obs, ctx->k, ctx->l,
+          ctx->kp, ctx->lp);
+    }
     HIP_CHECK(hipGetLastError());
     std::vector<double> part(nb);
     HIP_CHECK(hipMemcpyAsync(part.data(), ctx->lik_part.ptr, sizeof(double) * nb,
