@@ -359,3 +359,36 @@ def test_cv_fit_matches_reference(hip):
     assert acc == pytest.approx(g["accuracies"].tolist(), rel=1e-9)
     assert acc[0] == pytest.approx(0.125, 0.01) and acc[1] == pytest.approx(0.16, 0.01)
     assert np.allclose(mm.prediction_matrix, g["best_prediction_matrix"], rtol=1e-8, atol=1e-12)
+
+
+def test_c_abi_error_paths(hip):
+    """Status codes + last_error instead of exceptions across the ABI; nothing silently succeeds."""
+    from mmsbm_amd import _lib
+    from mmsbm_amd.core import HipEM
+    good = np.array([[0, 0, 0], [1, 1, 1], [1, 0, 1]], dtype=np.int64)
+    with pytest.raises(_lib.HipLibraryError) as e:
+        HipEM(np.array([[0, 0, 0], [7, 0, 0]]), 2, 2, n_users=2, n_items=1, n_ratings=1)
+    assert e.value.code == _lib.E_INVALID and "out of range" in e.value.message
+    with pytest.raises(_lib.HipLibraryError) as e:
+        HipEM(good, 600, 2)
+    assert e.value.code == _lib.E_UNSUPPORTED
+    with pytest.raises(_lib.HipLibraryError) as e:
+        HipEM(good, 2, 2, device=99)
+    assert e.value.code == _lib.E_INVALID
+    with HipEM(good, 2, 3) as em:
+        with pytest.raises(_lib.HipLibraryError) as e:
+            em.iterate(1)                                   # no parameters yet
+        assert e.value.code == _lib.E_INVALID and "set_params" in e.value.message
+        with pytest.raises(ValueError):
+            em.set_params(np.ones((2, 2)), np.ones((2, 2)), np.ones((2, 3, 2)))   # eta has L=2, not 3
+        em.set_params(np.full((2, 2), 0.5), np.full((2, 3), 1 / 3), np.full((2, 3, 2), 0.5))
+        with pytest.raises(_lib.HipLibraryError) as e:
+            em.prod_dist(np.array([[0, 5]]))                # unknown item
+        assert e.value.code == _lib.E_INVALID
+        import ctypes as C
+        buf = np.empty(4)
+        rc = _lib.load().mmsbm_hip_compute_omegas(em._h, buf.ctypes.data_as(C.POINTER(C.c_double)), 4)
+        assert rc == _lib.E_TOOLARGE and b"larger" in _lib.load().mmsbm_hip_last_error()
+        assert em.prod_dist(np.zeros((0, 2), dtype=np.int64)).shape == (0, 2)
+        em.iterate(0)
+        assert np.isfinite(em.likelihood())
