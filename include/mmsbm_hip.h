@@ -137,7 +137,10 @@ int mmsbm_hip_set_graph_mode(mmsbm_hip_ctx *ctx, int enabled);
 /* The sorted CSR-style layout create() uploads, exposed so it can be checked on a
  * machine without a GPU.  which: 0 pair_off, 1 pair_user, 2 pair_item, 3 rating_off,
  * 4 user_off, 5 user_pair, 6 item_off, 7 item_pairs, 8 item_deg, 9 chunk_off,
- * 10 chunks (rating, q_begin, q_end, 0 per chunk).  Pass out == NULL to query count. */
+ * and arrays of 4-int records: 10 chunks and 11 mv_chunks (rating, q_begin, q_end, 0),
+ * 12 / 13 work items of the pair / user segments (segment, begin, end, partial slot or -1;
+ * empty when no segment is longer than 64 triples), 14 / 15 split segments (segment, first
+ * partial slot, pieces, 0).  Pass out == NULL to query count. */
 typedef struct mmsbm_hip_layout mmsbm_hip_layout;
 int mmsbm_hip_layout_build(int64_t n_obs, int32_t n_users, int32_t n_items,
                            int32_t n_ratings, const int32_t *user, const int32_t *item,

@@ -179,7 +179,8 @@ def build_layout(data, n_users, n_items, n_ratings, target_chunks=1024):
     _lib.call("mmsbm_hip_layout_build", len(u), int(n_users), int(n_items), int(n_ratings),
               _p(u, C.c_int32), _p(i, C.c_int32), _p(r, C.c_int32), int(target_chunks), C.byref(h))
     names = ["pair_off", "pair_user", "pair_item", "rating_off", "user_off", "user_pair",
-             "item_off", "item_pairs", "item_deg", "chunk_off", "chunks"]
+             "item_off", "item_pairs", "item_deg", "chunk_off", "chunks", "mv_chunks",
+             "pair_items", "user_items", "pair_splits", "user_splits"]
     out = {}
     try:
         for which, nm in enumerate(names):
@@ -189,7 +190,7 @@ def build_layout(data, n_users, n_items, n_ratings, target_chunks=1024):
             if cnt.value:
                 _lib.call("mmsbm_hip_layout_array", h, which, _p(arr, C.c_int32), arr.size,
                           C.byref(cnt))
-            out[nm] = arr.reshape(-1, 4) if nm == "chunks" else arr
+            out[nm] = arr.reshape(-1, 4) if which >= 10 else arr
     finally:
         _lib.call("mmsbm_hip_layout_free", h)
     return out

@@ -24,6 +24,44 @@ struct Chunk {  // one workgroup's share of the pairs of ONE rating
   int32_t rating, q_begin, q_end, pad;
 };
 
+// A long segment (a heavy user, a popular (item, rating) pair) is cut into work items of at
+// most kMaxItemLen triples so that no group of lanes walks it alone; the items' partial sums
+// are combined afterwards in item order (deterministic).
+struct WorkItem {
+  int32_t seg, begin, end, part;  // part = slot of the partial row, or -1: the item IS the segment
+};
+struct SplitSeg {
+  int32_t seg, first_part, n_parts, pad;
+};
+constexpr int32_t kMaxItemLen = 64;
+
+struct WorkList {  // empty items == no segment is longer than kMaxItemLen: use the segments as they are
+  std::vector<WorkItem> items;
+  std::vector<SplitSeg> splits;
+  int32_t n_parts = 0;
+};
+
+inline void build_worklist(const std::vector<int32_t> &off, WorkList &w) {
+  w = WorkList();
+  const int32_t nseg = int32_t(off.size()) - 1;
+  bool any = false;
+  for (int32_t s = 0; s < nseg && !any; ++s) any = off[s + 1] - off[s] > kMaxItemLen;
+  if (!any) return;
+  for (int32_t s = 0; s < nseg; ++s) {
+    const int32_t len = off[s + 1] - off[s];
+    if (len <= kMaxItemLen) {
+      w.items.push_back(WorkItem{s, off[s], off[s + 1], -1});
+      continue;
+    }
+    const int32_t parts = (len + kMaxItemLen - 1) / kMaxItemLen;
+    w.splits.push_back(SplitSeg{s, w.n_parts, parts, 0});
+    for (int32_t j = 0; j < parts; ++j)
+      w.items.push_back(WorkItem{s, off[s] + j * kMaxItemLen,
+                                 std::min(off[s] + (j + 1) * kMaxItemLen, off[s + 1]), w.n_parts + j});
+    w.n_parts += parts;
+  }
+}
+
 struct Layout {
   int64_t n_obs = 0;
   int32_t n_users = 0, n_items = 0, n_ratings = 0, n_pairs = 0;
@@ -46,6 +84,7 @@ struct Layout {
   // fixed-size (<= kMvChunkPairs) rating-homogeneous chunks for the lane-per-pair mat-vecs
   std::vector<Chunk> mv_chunks;
   std::vector<int32_t> mv_chunk_off;  // n_ratings+1
+  WorkList pair_work, user_work;      // only filled when some segment is long
 };
 
 constexpr int32_t kMvChunkPairs = 64;  // one 64-pair unit per workgroup
@@ -159,6 +198,8 @@ inline void build_layout(int64_t n_obs, int32_t n_users, int32_t n_items, int32_
           Chunk{r, q, std::min<int32_t>(q + kMvChunkPairs, L.rating_off[r + 1]), 0});
     L.mv_chunk_off[r + 1] = int32_t(L.mv_chunks.size());
   }
+  build_worklist(L.pair_off, L.pair_work);
+  build_worklist(L.user_off, L.user_work);
 }
 
 }  // namespace mmsbm

@@ -159,14 +159,24 @@ struct SegArgs {
   const int32_t *off;
   const int32_t *idx;
   RowTab out;
-  int32_t nseg;
+  int32_t nseg;  // number of work units: segments, or work items when `items` is set
   int32_t mode;  // 0: out = acc   1: out = fixed*acc/max(len,1)   2: out = fixed*acc
+  const mmsbm::WorkItem *items;  // null: unit w is segment w.  Else unit w is a piece of a segment
+  double *parts;                 // [n_parts][dp] partial rows of the split segments
 };
 
 template <int G, int VEC, int B>
-__device__ __forceinline__ void seg_body(const SegArgs &a, int seg, int dp) {
+__device__ __forceinline__ void seg_body(const SegArgs &a, int unit, int dp) {
   const int gl = threadIdx.x % G;
-  if (seg >= a.nseg) return;  // whole groups leave together
+  if (unit >= a.nseg) return;  // whole groups leave together
+  int seg = unit, beg, end, part = -1;
+  if (a.items) {
+    const mmsbm::WorkItem it = a.items[unit];
+    seg = it.seg; beg = it.begin; end = it.end; part = it.part;
+  } else {
+    beg = a.off[unit];
+    end = a.off[unit + 1];
+  }
   const bool act = gl * VEC < dp;
   const int lane_off = act ? gl * VEC : 0;
 
@@ -187,7 +197,6 @@ __device__ __forceinline__ void seg_body(const SegArgs &a, int seg, int dp) {
   const double *gbase = g_main ? a.gath.base + lane_off
                                : a.gath.base + a.gath.tail_off + (lane_off - a.gath.mw);
   const size_t gstride = g_main ? a.gath.mw : a.gath.tw;
-  const int beg = a.off[seg], end = a.off[seg + 1];
   constexpr int CH = (G < 16) ? 2 * G : G;  // indices fetched per chunk (two per lane in small groups)
   for (int c0 = beg; c0 < end; c0 += CH) {
     const int cnt = min(CH, end - c0);
@@ -217,6 +226,10 @@ __device__ __forceinline__ void seg_body(const SegArgs &a, int seg, int dp) {
   }
 
   if (!act) return;
+  if (part >= 0) {  // a piece of a long segment: raw partial sum, finished by seg_combine_kernel
+    store_vec<VEC>(a.parts + static_cast<size_t>(part) * dp + lane_off, acc);
+    return;
+  }
   double o[VEC];
   if (a.mode == 0) {
 #pragma unroll
@@ -239,6 +252,63 @@ __global__ __launch_bounds__(kBlock) void seg_pass_kernel(SegArgs sa, SegArgs sb
   const bool first = static_cast<int>(blockIdx.x) < blocks_a;
   const int blk = first ? blockIdx.x : blockIdx.x - blocks_a;
   seg_body<G, VEC, B>(first ? sa : sb, blk * (kBlock / G) + threadIdx.x / G, dp);
+}
+
+// Long segments: add the pieces' partial rows in piece order and apply the epilogue.
+struct CombineArgs {
+  const mmsbm::SplitSeg *splits;
+  const double *parts;
+  const int32_t *off;
+  RowTab fixed, out;
+  int32_t n_splits, mode;
+};
+
+// One workgroup per split segment: its kBlock/G groups add the pieces j = g, g + NG, ... (four
+// loads in flight), the per-group sums meet in LDS and are added in group order.
+template <int G, int VEC>
+__global__ __launch_bounds__(kBlock) void seg_combine_kernel(CombineArgs ca, CombineArgs cb,
+                                                             int blocks_a, int dp) {
+  extern __shared__ double lds[];  // [kBlock / G][dp]
+  constexpr int NG = kBlock / G;
+  const bool first = static_cast<int>(blockIdx.x) < blocks_a;
+  const CombineArgs &a = first ? ca : cb;
+  const int w = first ? blockIdx.x : blockIdx.x - blocks_a;
+  const int grp = threadIdx.x / G, gl = threadIdx.x % G;
+  const bool act = gl * VEC < dp;
+  const int lane_off = act ? gl * VEC : 0;
+  const mmsbm::SplitSeg sp = a.splits[w];
+  double acc[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) acc[v] = 0.0;
+  for (int j0 = grp; j0 < sp.n_parts; j0 += NG * 4) {
+    double t[4][VEC];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      load_vec<VEC>(a.parts + static_cast<size_t>(sp.first_part + min(j0 + i * NG, sp.n_parts - 1)) * dp +
+                        lane_off, t[i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (j0 + i * NG < sp.n_parts) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] += t[i][v];
+      }
+  }
+  if (act) store_vec<VEC>(lds + grp * dp + lane_off, acc);
+  __syncthreads();
+  if (grp != 0 || !act) return;
+  for (int g = 1; g < NG; ++g) {
+    double t[VEC];
+    load_vec<VEC>(lds + g * dp + lane_off, t);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v] += t[v];
+  }
+  double f[VEC], o[VEC];
+  load_vec<VEC>(rowtab_ptr(a.fixed, sp.seg, lane_off), f);
+  const double d = static_cast<double>(max(a.off[sp.seg + 1] - a.off[sp.seg], 1));
+#pragma unroll
+  for (int v = 0; v < VEC; ++v)
+    o[v] = a.mode == 0 ? acc[v] : (a.mode == 1 ? (f[v] * acc[v]) / d : f[v] * acc[v]);
+  store_vec<VEC>(rowtab_ptr(a.out, sp.seg, lane_off), o);
 }
 
 // ======================================================================================
@@ -1180,6 +1250,9 @@ struct mmsbm_hip_ctx {
   DevBuf<int32_t> pair_off, pair_user, pair_item, user_off, user_pair, item_off, item_pairs,
       item_deg, chunk_off, mv_chunk_off, orig_u, orig_i, orig_r;
   DevBuf<mmsbm::Chunk> chunks, mv_chunks;
+  DevBuf<mmsbm::WorkItem> pair_items, user_items;   // only when some segment is long
+  DevBuf<mmsbm::SplitSeg> pair_splits, user_splits;
+  DevBuf<double> pair_parts, user_parts;
   DevBuf<double> theta[2], eta[2], p[2], pt[2], atab[2], ctab, ttab, partial, npr, lik_part;
   int cur = 0;
   bool have_params = false;
@@ -1307,12 +1380,19 @@ RowTab a_tab(const mmsbm_hip_ctx *c, int slot) {
 }
 
 SegArgs seg_pairs_args(const mmsbm_hip_ctx *c) {  // C = sum over a pair's triples
+  const bool it = !c->lay.pair_work.items.empty();
   return SegArgs{a_tab(c, c->cur), theta_tab(c, c->cur), c->pair_off.ptr, c->pair_user.ptr,
-                 plain_tab(c->ctab.ptr, c->kp), c->n_pairs, 0};
+                 plain_tab(c->ctab.ptr, c->kp),
+                 it ? static_cast<int32_t>(c->lay.pair_work.items.size()) : c->n_pairs, 0,
+                 it ? c->pair_items.ptr : nullptr, c->pair_parts.ptr};
 }
 SegArgs seg_users_args(const mmsbm_hip_ctx *c, bool commit, int seg_end) {  // theta_new
+  const bool it = !c->lay.user_work.items.empty();
   return SegArgs{theta_tab(c, c->cur),     a_tab(c, c->cur), c->user_off.ptr, c->user_pair.ptr,
-                 theta_tab(c, c->cur ^ 1), seg_end,          commit ? 1 : 2};
+                 theta_tab(c, c->cur ^ 1),
+                 it ? static_cast<int32_t>(c->lay.user_work.items.size()) : seg_end,
+                 commit ? 1 : 2,
+                 it ? c->user_items.ptr : nullptr, c->user_parts.ptr};
 }
 PairBlockArgs pair_block_t_args(const mmsbm_hip_ctx *c) {
   return PairBlockArgs{c->p[c->cur].ptr, c->ctab.ptr,        c->eta[c->cur].ptr, c->pair_item.ptr,
@@ -1344,11 +1424,25 @@ void stage_seg(mmsbm_hip_ctx *c, bool commit, bool with_users) {
   LaunchScope ls(c, K_SEG);
   const SegArgs sp = seg_pairs_args(c), su = seg_users_args(c, commit, c->n_users);
   const int per = kBlock / group_lanes(c->code_k);
-  const int bp = (c->n_pairs + per - 1) / per;
-  const int bu = with_users ? (c->n_users + per - 1) / per : 0;
+  const int bp = (sp.nseg + per - 1) / per;
+  const int bu = with_users ? (su.nseg + per - 1) / per : 0;
   if (bp + bu > 0) {
 #define CALL(G, V) \
   seg_pass_kernel<G, V, 4><<<bp + bu, kBlock, 0, c->stream>>>(sp, su, bp, c->kp)
+    DISPATCH_GV(c->code_k, CALL);
+#undef CALL
+  }
+  // long segments were processed in pieces: add the pieces up (fixed order) and finish them
+  const int nsp = static_cast<int>(c->lay.pair_work.splits.size());
+  const int nsu = with_users ? static_cast<int>(c->lay.user_work.splits.size()) : 0;
+  if (nsp + nsu > 0) {
+    const CombineArgs cp{c->pair_splits.ptr, c->pair_parts.ptr, c->pair_off.ptr, sp.fixed, sp.out, nsp,
+                         sp.mode};
+    const CombineArgs cu{c->user_splits.ptr, c->user_parts.ptr, c->user_off.ptr, su.fixed, su.out, nsu,
+                         su.mode};
+    const size_t lds = static_cast<size_t>(per) * c->kp * sizeof(double);
+#define CALL(G, V) \
+  seg_combine_kernel<G, V><<<nsp + nsu, kBlock, lds, c->stream>>>(cp, cu, nsp, c->kp)
     DISPATCH_GV(c->code_k, CALL);
 #undef CALL
   }
@@ -1782,6 +1876,10 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
     c->chunks.upload(c->lay.chunks, s);
     c->mv_chunks.upload(c->lay.mv_chunks, s);
     c->mv_chunk_off.upload(c->lay.mv_chunk_off, s);
+    c->pair_items.upload(c->lay.pair_work.items, s);
+    c->user_items.upload(c->lay.user_work.items, s);
+    c->pair_splits.upload(c->lay.pair_work.splits, s);
+    c->user_splits.upload(c->lay.user_work.splits, s);
     {
       std::vector<int32_t> tmp;
       tmp.assign(iu, iu + n_obs); c->orig_u.upload(tmp, s);
@@ -1812,6 +1910,8 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
     c->partial.alloc(std::max<size_t>(std::max<size_t>(c->n_chunks, c->lay.mv_chunks.size()), 1) *
                      c->kp * c->lp);
     c->npr.alloc(klr);
+    c->pair_parts.alloc(static_cast<size_t>(c->lay.pair_work.n_parts) * c->kp);
+    c->user_parts.alloc(static_cast<size_t>(c->lay.user_work.n_parts) * c->kp);
     c->lik_part.alloc(4096);
     HIP_CHECK(hipStreamSynchronize(s));
     *out = c.release();
@@ -2140,7 +2240,7 @@ int mmsbm_hip_set_option(mmsbm_hip_ctx *ctx, const char *name, double value) {
     const std::string key(name);
     if (key == "rolefuse") {
       ctx->rolefuse = value != 0.0 && ctx->fused && ctx->code_k <= 3 && ctx->code_l <= 3 &&
-                      ctx->pb_nacc <= 2;
+                      ctx->pb_nacc <= 2 && ctx->lay.user_work.items.empty();
     } else if (key == "fill0" || key == "fill1" || key == "fill2") {
       if (value < 0.0 || value > 1.0) throw std::invalid_argument("fill share must be in [0, 1]");
       ctx->fill_frac[key[4] - '0'] = static_cast<float>(value);
@@ -2183,7 +2283,8 @@ int mmsbm_hip_layout_free(mmsbm_hip_layout *h) {
 }
 
 // which: 0 pair_off 1 pair_user 2 pair_item 3 rating_off 4 user_off 5 user_pair 6 item_off
-//        7 item_pairs 8 item_deg 9 chunk_off 10 chunks (4 ints each)
+//        7 item_pairs 8 item_deg 9 chunk_off; 4-int records: 10 chunks 11 mv_chunks
+//        12 pair work items 13 user work items 14 pair splits 15 user splits
 int mmsbm_hip_layout_array(const mmsbm_hip_layout *h, int which, int32_t *out, int64_t capacity,
                            int64_t *count) {
   return guarded([&] {
@@ -2201,14 +2302,24 @@ int mmsbm_hip_layout_array(const mmsbm_hip_layout *h, int which, int32_t *out, i
       case 7: v = &L.item_pairs; break;
       case 8: v = &L.item_deg; break;
       case 9: v = &L.chunk_off; break;
-      case 10: break;
+      case 10: case 11: case 12: case 13: case 14: case 15: break;
       default: throw std::invalid_argument("unknown layout array");
     }
-    if (which == 10) {
-      *count = static_cast<int64_t>(L.chunks.size()) * 4;
-      if (out) {
+    if (which >= 10) {  // arrays of 4-int records
+      const void *src = nullptr;
+      size_t n = 0;
+      switch (which) {
+        case 10: src = L.chunks.data(); n = L.chunks.size(); break;
+        case 11: src = L.mv_chunks.data(); n = L.mv_chunks.size(); break;
+        case 12: src = L.pair_work.items.data(); n = L.pair_work.items.size(); break;
+        case 13: src = L.user_work.items.data(); n = L.user_work.items.size(); break;
+        case 14: src = L.pair_work.splits.data(); n = L.pair_work.splits.size(); break;
+        default: src = L.user_work.splits.data(); n = L.user_work.splits.size(); break;
+      }
+      *count = static_cast<int64_t>(n) * 4;
+      if (out && n) {
         if (capacity < *count) throw ApiError(MMSBM_E_TOOLARGE, "buffer too small");
-        std::memcpy(out, L.chunks.data(), sizeof(int32_t) * *count);
+        std::memcpy(out, src, sizeof(int32_t) * *count);
       }
       return;
     }

@@ -392,3 +392,34 @@ def test_c_abi_error_paths(hip):
         assert em.prod_dist(np.zeros((0, 2), dtype=np.int64)).shape == (0, 2)
         em.iterate(0)
         assert np.isfinite(em.likelihood())
+
+
+def test_heavy_tailed_degrees_split_segments(hip):
+    """Zipf-like degrees (one user with ~40 % of the rows, one pair with ~10 %): the long segments
+    run as work items + ordered combine; results still match the oracle and are reproducible."""
+    rng = np.random.default_rng(21)
+    n = 30000
+    u = np.where(rng.random(n) < 0.4, 5, (rng.zipf(1.3, n) - 1) % 2000)
+    i = np.where(rng.random(n) < 0.3, 2, rng.integers(0, 300, n))
+    data = np.stack([u, i, rng.integers(0, 5, n)], axis=1).astype(np.int64)
+    data[:, 0] = np.unique(data[:, 0], return_inverse=True)[1]
+    data[:, 1] = np.unique(data[:, 1], return_inverse=True)[1]
+    n_u, n_i, n_r, k, l = int(data[:, 0].max()) + 1, int(data[:, 1].max()) + 1, 5, 20, 12
+    d_u, d_i = orc.degrees(data, n_u, n_i)
+    assert d_u.max() > 5000
+    theta, eta, pr = orc.init_params(77, n_u, n_i, n_r, k, l, d_u, d_i)
+    outs = []
+    for _ in range(2):
+        with make_ctx(hip, data, theta, eta, pr) as em:
+            want = orc.update_coefficients(data, theta, eta, pr)
+            for got, w, nm in zip(em.update_coefficients(), want, ("n_theta", "n_eta", "n_pr")):
+                assert rel_err(got, w) < TOL_STEP, nm
+            em.iterate(4)
+            outs.append(em.get_params())
+    t, e, p = theta, eta, pr
+    for _ in range(4):
+        t, e, p = orc.em_step(data, t, e, p, d_u, d_i)
+    for got, w, nm in zip(outs[0], (t, e, p), ("theta", "eta", "pr")):
+        assert rel_err(got, w) < 1e-11, nm
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)

@@ -108,3 +108,33 @@ def test_factorised_form_edge_cases():
             # 'tiny': the reference's (theta*eta)*p underflows to exactly 0 where the factorised
             # theta*(p.eta) keeps a denormal ~1e-315 -- an absolute floor far below any tolerance
             assert np.allclose(a, want, rtol=1e-12, atol=1e-300), (tag, nm)
+
+
+def test_long_segments_become_work_items():
+    """Heavy users / popular pairs are cut into pieces of <= 64 triples, combined in piece order."""
+    rng = np.random.default_rng(9)
+    n = 5000
+    u = np.where(rng.random(n) < 0.4, 3, rng.integers(0, 300, n))      # user 3 holds ~40 % of the rows
+    i = np.where(rng.random(n) < 0.3, 1, rng.integers(0, 40, n))
+    data = np.stack([u, i, rng.integers(0, 3, n)], axis=1).astype(np.int64)
+    lay = build_layout(data, 300, 40, 3)
+    for which, off in (("user", lay["user_off"]), ("pair", lay["pair_off"])):
+        items, splits = lay[f"{which}_items"], lay[f"{which}_splits"]
+        lens = np.diff(off)
+        assert lens.max() > 64 and len(items) > len(lens)
+        assert np.all(items[:, 2] - items[:, 1] <= 64) and np.all(items[:, 2] > items[:, 1])
+        # the items tile every non-empty segment exactly, in order
+        cover = np.zeros(off[-1], dtype=int)
+        for seg, b, e, part in items:
+            assert off[seg] <= b < e <= off[seg + 1]
+            cover[b:e] += 1
+            assert (part >= 0) == (lens[seg] > 64)
+        assert np.all(cover == 1)
+        assert sorted(splits[:, 0].tolist()) == np.nonzero(lens > 64)[0].tolist()
+        for seg, first, cnt, _ in splits:
+            assert cnt == -(-lens[seg] // 64)
+            mine = items[items[:, 0] == seg]
+            assert mine[:, 3].tolist() == list(range(first, first + cnt))
+    # uniform data: no items at all (segments are used as they are)
+    flat = build_layout(random_triples(rng, 3000, 400, 50, 4), 400, 50, 4)
+    assert len(flat["user_items"]) == 0 and len(flat["pair_splits"]) == 0
