@@ -469,7 +469,7 @@ struct PairBlockArgs {
   size_t out_tail_off;  // ... and where the tail part starts (RowTab layout)
 };
 
-template <bool GATHER, bool DO_S, int NACC>
+template <bool GATHER, bool DO_S, int NACC, bool TLDS>
 __device__ __forceinline__ void pair_block_body(const PairBlockArgs &pa,
                                                 const double *__restrict__ tiles, int block) {
   const double *__restrict__ in_tab = pa.in_tab;
@@ -498,6 +498,14 @@ __device__ __forceinline__ void pair_block_body(const PairBlockArgs &pa,
   typedef const double __attribute__((address_space(4))) * const_tile_ptr;
   const const_tile_ptr gtile = (const_tile_ptr)(reinterpret_cast<uintptr_t>(
       tiles + static_cast<size_t>(ch.rating) * dinp * doutp));
+  // Tiles too big for the scalar cache (TLDS) are staged in LDS once per workgroup instead and
+  // read with broadcast ds_read_b128; the unit loop's first barrier orders this staging.
+  double *tile_l = es + static_cast<size_t>(kUnitPairs) * doutp;  // [dinp][doutp], TLDS only
+  if (TLDS) {
+    const double *src = tiles + static_cast<size_t>(ch.rating) * dinp * doutp;
+    for (int t = tid * 2; t < dinp * doutp; t += kBlock * 2)
+      *reinterpret_cast<double2 *>(tile_l + t) = *reinterpret_cast<const double2 *>(src + t);
+  }
   // S slots (DO_S): a slot is a 2 (k) x 4 (l) register tile; `spb` threads form one copy of
   // the K x L slot grid and the block's nsub copies split each unit's pairs.
   const int nslot = (dinp >> 1) * nch;
@@ -601,9 +609,14 @@ __device__ __forceinline__ void pair_block_body(const PairBlockArgs &pa,
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           x[i] = cst[(d + i) * CS + lane];
-          const const_tile_ptr row = gtile + static_cast<size_t>(d + i) * doutp + c * 4;  // uniform
-          m0[i].x = row[0]; m0[i].y = row[1];
-          m1[i].x = row[2]; m1[i].y = row[3];
+          if (TLDS) {
+            m0[i] = *reinterpret_cast<const double2 *>(tile_l + (d + i) * doutp + c * 4);
+            m1[i] = *reinterpret_cast<const double2 *>(tile_l + (d + i) * doutp + c * 4 + 2);
+          } else {
+            const const_tile_ptr row = gtile + static_cast<size_t>(d + i) * doutp + c * 4;  // uniform
+            m0[i].x = row[0]; m0[i].y = row[1];
+            m1[i].x = row[2]; m1[i].y = row[3];
+          }
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -672,10 +685,10 @@ __device__ __forceinline__ void pair_block_body(const PairBlockArgs &pa,
   }
 }
 
-template <bool GATHER, bool DO_S, int NACC>
+template <bool GATHER, bool DO_S, int NACC, bool TLDS>
 __global__ __launch_bounds__(kBlock) void pair_block_kernel(PairBlockArgs pa,
                                                             const double *__restrict__ tiles) {
-  pair_block_body<GATHER, DO_S, NACC>(pa, tiles, blockIdx.x);
+  pair_block_body<GATHER, DO_S, NACC, TLDS>(pa, tiles, blockIdx.x);
 }
 
 // Role-fused form: the first nb_dense blocks are pair_block units, the rest are filler --
@@ -687,7 +700,7 @@ __global__ __launch_bounds__(kBlock) void pair_block_fill_kernel(PairBlockArgs p
                                                                  int nb_dense, SegArgs fill,
                                                                  int fill_seg0, int dp) {
   if (static_cast<int>(blockIdx.x) < nb_dense)
-    pair_block_body<GATHER, DO_S, NACC>(pa, tiles, blockIdx.x);
+    pair_block_body<GATHER, DO_S, NACC, false>(pa, tiles, blockIdx.x);
   else
     seg_body<G, VEC, 4>(fill, fill_seg0 + (blockIdx.x - nb_dense) * (kBlock / G) + threadIdx.x / G,
                         dp);
@@ -1335,9 +1348,14 @@ int lane_matvec_waves(int dinp, int doutp) {
 constexpr size_t kLdsMax = 160 * 1024;  // with hipFuncAttributeMaxDynamicSharedMemorySize
 
 // dynamic LDS of pair_block: transposed rows + output rows (shared with the eta rows)
+constexpr size_t kScalarTileBytes = 8 * 1024;  // larger tiles thrash the scalar cache: stage in LDS
+bool tile_in_lds(int dinp, int doutp) {
+  return static_cast<size_t>(dinp) * doutp * sizeof(double) > kScalarTileBytes;
+}
 size_t pair_block_lds(int dinp, int doutp, bool with_s) {
   (void)with_s;  // the eta rows and the output rows share one region
-  const size_t d = static_cast<size_t>(dinp) * (kUnitPairs + 1) + static_cast<size_t>(kUnitPairs) * doutp;
+  const size_t d = static_cast<size_t>(dinp) * (kUnitPairs + 1) + static_cast<size_t>(kUnitPairs) * doutp +
+                   (tile_in_lds(dinp, doutp) ? static_cast<size_t>(dinp) * doutp : 0);
   return std::max(d, static_cast<size_t>(kBlock) * 8) * sizeof(double);  // >= hand-over area of S
 }
 
@@ -1458,8 +1476,13 @@ void stage_dense(mmsbm_hip_ctx *c) {  // T = P^T C  and the K x L slabs for p
     const PairBlockArgs pa = pair_block_t_args(c);
 #define PB(N)                                                                               \
   do {                                                                                      \
-    allow_big_lds(pair_block_kernel<false, true, N>, c->lds_t);                             \
-    pair_block_kernel<false, true, N><<<nb, kBlock, c->lds_t, c->stream>>>(pa, pa.tiles);   \
+    if (tile_in_lds(c->kp, c->lp)) {                                                        \
+      allow_big_lds(pair_block_kernel<false, true, N, true>, c->lds_t);                     \
+      pair_block_kernel<false, true, N, true><<<nb, kBlock, c->lds_t, c->stream>>>(pa, pa.tiles); \
+    } else {                                                                                \
+      allow_big_lds(pair_block_kernel<false, true, N, false>, c->lds_t);                    \
+      pair_block_kernel<false, true, N, false><<<nb, kBlock, c->lds_t, c->stream>>>(pa, pa.tiles); \
+    }                                                                                       \
   } while (0)
     switch (c->pb_nacc) {
       case 1: PB(1); break;
@@ -1514,9 +1537,14 @@ void stage_matvec_a(mmsbm_hip_ctx *c, int slot, int a_slot) {
   LaunchScope ls(c, K_MATVEC_A);
   if (c->fused) {
     const int nb = static_cast<int>(c->lay.mv_chunks.size());
-    allow_big_lds(pair_block_kernel<true, false, 1>, c->lds_a);
     const PairBlockArgs pa = pair_block_a_args(c, slot, a_slot);
-    pair_block_kernel<true, false, 1><<<nb, kBlock, c->lds_a, c->stream>>>(pa, pa.tiles);
+    if (tile_in_lds(c->lp, c->kp)) {
+      allow_big_lds(pair_block_kernel<true, false, 1, true>, c->lds_a);
+      pair_block_kernel<true, false, 1, true><<<nb, kBlock, c->lds_a, c->stream>>>(pa, pa.tiles);
+    } else {
+      allow_big_lds(pair_block_kernel<true, false, 1, false>, c->lds_a);
+      pair_block_kernel<true, false, 1, false><<<nb, kBlock, c->lds_a, c->stream>>>(pa, pa.tiles);
+    }
   } else {
     launch_group_matvec(c, c->pt[slot].ptr, c->eta[slot].ptr, c->pair_item.ptr,
                         c->atab[a_slot].ptr, c->l, c->lp, c->kp, c->code_k);
@@ -2240,7 +2268,8 @@ int mmsbm_hip_set_option(mmsbm_hip_ctx *ctx, const char *name, double value) {
     const std::string key(name);
     if (key == "rolefuse") {
       ctx->rolefuse = value != 0.0 && ctx->fused && ctx->code_k <= 3 && ctx->code_l <= 3 &&
-                      ctx->pb_nacc <= 2 && ctx->lay.user_work.items.empty();
+                      ctx->pb_nacc <= 2 && ctx->lay.user_work.items.empty() &&
+                      !tile_in_lds(ctx->kp, ctx->lp);
     } else if (key == "fill0" || key == "fill1" || key == "fill2") {
       if (value < 0.0 || value > 1.0) throw std::invalid_argument("fill share must be in [0, 1]");
       ctx->fill_frac[key[4] - '0'] = static_cast<float>(value);
