@@ -15,8 +15,9 @@ dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
 
 def short(name):
-    for key, nm in (("seg_pass_kernel", "seg_pass_kernel"), ("pair_block_kernel<false", "pair_block(T+S)|user-fill"),
-                    ("pair_block_kernel<true", "pair_block(A)|user-fill"), ("eta_p_kernel", "eta_p|user-fill"),
+    for key, nm in (("seg_pass_kernel", "seg_pass_kernel"), ("pair_block_kernel<false", "pair_block_kernel(T+S)"),
+                    ("pair_block_kernel<true", "pair_block_kernel(A)"), ("eta_p_kernel", "eta_p_kernel"),
+                    ("seg_combine_kernel", "seg_combine_kernel"), ("likelihood_units_kernel", "likelihood_units_kernel"),
                     ("likelihood_kernel", "likelihood_kernel"), ("prod_dist_kernel", "prod_dist_kernel")):
         if key in name:
             return nm
