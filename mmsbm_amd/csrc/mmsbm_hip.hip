@@ -1234,10 +1234,10 @@ struct DevBuf {
 };
 
 enum KernelId { K_SEG = 0, K_DENSE, K_ETAP, K_MATVEC_A, K_COUNT };
-// With role fusion (the normal path) launch 0 holds the pair segments only and launches 1-3
-// carry slices of the user segments as filler blocks next to their dense blocks.
-const char *const kKernelNames[K_COUNT] = {"seg_pass_kernel", "pair_block(T+S)|user-fill",
-                                           "eta_p|user-fill", "pair_block(A)|user-fill"};
+// The four launches of an iteration (with the "rolefuse" option launches 1-3 also carry
+// slices of the user segments as filler blocks).
+const char *const kKernelNames[K_COUNT] = {"seg_pass_kernel", "pair_block_kernel(T+S)",
+                                           "eta_p_kernel", "pair_block_kernel(A)"};
 
 }  // namespace
 
