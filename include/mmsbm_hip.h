@@ -125,9 +125,8 @@ int mmsbm_hip_kernel_bytes(const mmsbm_hip_ctx *ctx, int index, int64_t *bytes_r
  * stage's outputs overwrite scratch/next buffers: call set_params again before trusting the
  * context's state. */
 int mmsbm_hip_time_stage(mmsbm_hip_ctx *ctx, int stage, int reps, float *mean_us);
-/* Tuning knobs (defaults are right for normal use): "rolefuse" 0/1 = run the user segments as
- * filler blocks inside the three dense launches (default 1 when K, L <= 64); "fill0", "fill1",
- * "fill2" = share of the user segments given to each of those launches. */
+/* Named tuning knobs (defaults are right for normal use); currently "graph" 0/1, the same
+ * switch as mmsbm_hip_set_graph_mode. */
 int mmsbm_hip_set_option(mmsbm_hip_ctx *ctx, const char *name, double value);
 /* How em_iterate launches: 0 (default) = eager launches on the context's stream; 1 = replay
  * a captured hipGraph of two iterations. */

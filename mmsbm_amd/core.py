@@ -164,7 +164,7 @@ class HipEM:
         return float(us.value)
 
     def set_option(self, name, value):
-        """Tuning knob of the library ("rolefuse", "fill0".."fill2")."""
+        """Named tuning knob of the library (currently "graph")."""
         _lib.call("mmsbm_hip_set_option", self._h, name.encode(), float(value))
 
     def set_graph_mode(self, mode):

@@ -691,21 +691,6 @@ __global__ __launch_bounds__(kBlock) void pair_block_kernel(PairBlockArgs pa,
   pair_block_body<GATHER, DO_S, NACC, TLDS>(pa, tiles, blockIdx.x);
 }
 
-// Role-fused form: the first nb_dense blocks are pair_block units, the rest are filler --
-// a slice of the user segments of seg_pass (bandwidth-bound, no LDS), so that the
-// LDS/latency-bound dense stage and the gather pass share the machine inside ONE launch.
-template <bool GATHER, bool DO_S, int NACC, int G, int VEC>
-__global__ __launch_bounds__(kBlock) void pair_block_fill_kernel(PairBlockArgs pa,
-                                                                 const double *__restrict__ tiles,
-                                                                 int nb_dense, SegArgs fill,
-                                                                 int fill_seg0, int dp) {
-  if (static_cast<int>(blockIdx.x) < nb_dense)
-    pair_block_body<GATHER, DO_S, NACC, false>(pa, tiles, blockIdx.x);
-  else
-    seg_body<G, VEC, 4>(fill, fill_seg0 + (blockIdx.x - nb_dense) * (kBlock / G) + threadIdx.x / G,
-                        dp);
-}
-
 // ======================================================================================
 // kernel 2: p_partial -- per chunk of pairs of one rating, the K x L partial sum
 //   S[k,l] = sum_{q in chunk} C[q,k] * eta[item(q), l]
@@ -823,7 +808,6 @@ __global__ __launch_bounds__(kBlock) void p_partial_kernel(
 // ======================================================================================
 constexpr int kRedCols = 16, kRedRows = 64, kRedGroup = 6;  // ratings per LDS pass
 constexpr int kRedThreads = kRedCols * kRedRows, kRedBatch = 4;
-constexpr int kRedRowsSmall = kBlock / kRedCols;  // the 256-thread form used inside fused launches
 
 template <int ROWS>
 __device__ __forceinline__ void p_update_block(
@@ -987,22 +971,6 @@ __global__ __launch_bounds__(kRedThreads) void eta_p_kernel(EtaPArgs a) {
   else
     item_sum_block<G, VEC>(blockIdx.x - a.nb_p, a.ttab, a.item_off, a.item_pairs, a.item_deg,
                            a.eta, a.eta_new, a.n_items, a.lp, a.normalize);
-}
-
-// Role-fused, 256-thread form: [p_update | item_sum | filler user segments of seg_pass]
-template <int G2, int VEC2, int G, int VEC>
-__global__ __launch_bounds__(kBlock) void eta_p_fill_kernel(EtaPArgs a, int nb_i, SegArgs fill,
-                                                            int fill_seg0, int dp) {
-  __shared__ double red[kRedGroup][kRedRowsSmall][kRedCols];
-  const int b = blockIdx.x;
-  if (b < a.nb_p)
-    p_update_block<kRedRowsSmall>(red, b, a.partial, a.chunk_off, a.p_old, a.p_new, a.pt_new, a.npr,
-                                  a.n_ratings, a.kp, a.lp, a.normalize);
-  else if (b < a.nb_p + nb_i)
-    item_sum_block<G2, VEC2>(b - a.nb_p, a.ttab, a.item_off, a.item_pairs, a.item_deg, a.eta,
-                             a.eta_new, a.n_items, a.lp, a.normalize);
-  else
-    seg_body<G, VEC, 4>(fill, fill_seg0 + (b - a.nb_p - nb_i) * (kBlock / G) + threadIdx.x / G, dp);
 }
 
 // stand-alone forms (fallback path for shapes the fused kernels do not cover)
@@ -1234,8 +1202,7 @@ struct DevBuf {
 };
 
 enum KernelId { K_SEG = 0, K_DENSE, K_ETAP, K_MATVEC_A, K_COUNT };
-// The four launches of an iteration (with the "rolefuse" option launches 1-3 also carry
-// slices of the user segments as filler blocks).
+// The four launches of an iteration.
 const char *const kKernelNames[K_COUNT] = {"seg_pass_kernel", "pair_block_kernel(T+S)",
                                            "eta_p_kernel", "pair_block_kernel(A)"};
 
@@ -1256,8 +1223,6 @@ struct mmsbm_hip_ctx {
   bool fused = false;       // pair_block path (else: pair_matvec + p_partial fallback)
   bool split_rows = false;  // theta and A kept as 128-byte main lines + tail rows (RowTab)
   int pb_spb = kBlock, pb_nacc = 1, pb_nsub = 1;  // pair_block S phase: threads per slot-grid copy, slots per thread
-  bool rolefuse = false;    // user segments ride as filler blocks inside the dense launches
-  float fill_frac[3] = {0.55f, 0.20f, 0.25f};  // share of the user segments per dense launch
   size_t lds_t = 0, lds_a = 0;
   mmsbm::Layout lay;  // host copy (degrees, sizes)
   DevBuf<int32_t> pair_off, pair_user, pair_item, user_off, user_pair, item_off, item_pairs,
@@ -1552,107 +1517,7 @@ void stage_matvec_a(mmsbm_hip_ctx *c, int slot, int a_slot) {
   ls.done();
 }
 
-// ---- role-fused launches (commit iterations, small K and L) ---------------------------------------
-struct FillPlan {  // user-segment slices [u[j], u[j+1]) for dense launches j = 0, 1, 2
-  int u[4];
-  int blocks[3];
-};
-FillPlan fill_plan(const mmsbm_hip_ctx *c) {
-  FillPlan f;
-  const int per = kBlock / group_lanes(c->code_k);
-  const int n = c->n_users;
-  float acc = 0.f;
-  f.u[0] = 0;
-  for (int j = 0; j < 3; ++j) {
-    acc += c->fill_frac[j];
-    int e = (j == 2) ? n : static_cast<int>(static_cast<double>(n) * acc);
-    e = std::min(n, (e + per - 1) / per * per);
-    f.u[j + 1] = std::max(e, f.u[j]);
-    f.blocks[j] = (f.u[j + 1] - f.u[j] + per - 1) / per;
-  }
-  return f;
-}
-
-template <int G, int V>
-void launch_fused_dense_t(mmsbm_hip_ctx *c, const SegArgs &fill, int seg0, int nfill) {
-  const int nb = static_cast<int>(c->lay.mv_chunks.size());
-  const PairBlockArgs pa = pair_block_t_args(c);
-  if (c->pb_nacc == 1) {
-    allow_big_lds(pair_block_fill_kernel<false, true, 1, G, V>, c->lds_t);
-    pair_block_fill_kernel<false, true, 1, G, V><<<nb + nfill, kBlock, c->lds_t, c->stream>>>(
-        pa, pa.tiles, nb, fill, seg0, c->kp);
-  } else {
-    allow_big_lds(pair_block_fill_kernel<false, true, 2, G, V>, c->lds_t);
-    pair_block_fill_kernel<false, true, 2, G, V><<<nb + nfill, kBlock, c->lds_t, c->stream>>>(
-        pa, pa.tiles, nb, fill, seg0, c->kp);
-  }
-}
-template <int G, int V>
-void launch_fused_eta_p(mmsbm_hip_ctx *c, const SegArgs &fill, int seg0, int nfill) {
-  const EtaPArgs a = eta_p_args(c, true, kRedCols);
-  const int per = kBlock / group_lanes(c->code_l);
-  const int nb_i = (c->n_items + per - 1) / per;
-  const int grid = a.nb_p + nb_i + nfill;
-  switch (c->code_l) {
-    case 0: eta_p_fill_kernel<4, 4, G, V><<<grid, kBlock, 0, c->stream>>>(a, nb_i, fill, seg0, c->kp); break;
-    case 1: eta_p_fill_kernel<8, 4, G, V><<<grid, kBlock, 0, c->stream>>>(a, nb_i, fill, seg0, c->kp); break;
-    case 2: eta_p_fill_kernel<16, 4, G, V><<<grid, kBlock, 0, c->stream>>>(a, nb_i, fill, seg0, c->kp); break;
-    default: eta_p_fill_kernel<32, 4, G, V><<<grid, kBlock, 0, c->stream>>>(a, nb_i, fill, seg0, c->kp); break;
-  }
-}
-template <int G, int V>
-void launch_fused_dense_a(mmsbm_hip_ctx *c, const SegArgs &fill, int seg0, int nfill) {
-  const int nb = static_cast<int>(c->lay.mv_chunks.size());
-  const int nxt = c->cur ^ 1;
-  allow_big_lds(pair_block_fill_kernel<true, false, 1, G, V>, c->lds_a);
-  const PairBlockArgs pa = pair_block_a_args(c, nxt, nxt);
-  pair_block_fill_kernel<true, false, 1, G, V><<<nb + nfill, kBlock, c->lds_a, c->stream>>>(
-      pa, pa.tiles, nb, fill, seg0, c->kp);
-}
-
-#define DISPATCH_SMALL_GV(code, FN, ...)                          \
-  switch (code) {                                                 \
-    case 0: FN<4, 4>(__VA_ARGS__); break;                         \
-    case 1: FN<8, 4>(__VA_ARGS__); break;                         \
-    case 2: FN<16, 4>(__VA_ARGS__); break;                        \
-    default: FN<32, 4>(__VA_ARGS__); break;                       \
-  }
-
-//   launch 0 : pair segments (C)
-//   launch 1 : [T mat-vec + p slabs | user segments, slice 0]
-//   launch 2 : [p_update | item_sum | user segments, slice 1]
-//   launch 3 : [A mat-vec (new eta, new p) -> atab[next] | user segments, slice 2]
-// The user segments read theta[cur] and atab[cur] only, so they may run beside any of the
-// dense stages; atab is double-buffered because launch 3 writes the next A while they read.
-void launch_iteration_rolefused(mmsbm_hip_ctx *c) {
-  const FillPlan f = fill_plan(c);
-  stage_seg(c, true, false);
-  {
-    LaunchScope ls(c, K_DENSE);
-    const SegArgs fill = seg_users_args(c, true, f.u[1]);
-    DISPATCH_SMALL_GV(c->code_k, launch_fused_dense_t, c, fill, f.u[0], f.blocks[0]);
-    ls.done();
-  }
-  {
-    LaunchScope ls(c, K_ETAP);
-    const SegArgs fill = seg_users_args(c, true, f.u[2]);
-    DISPATCH_SMALL_GV(c->code_k, launch_fused_eta_p, c, fill, f.u[1], f.blocks[1]);
-    ls.done();
-  }
-  {
-    LaunchScope ls(c, K_MATVEC_A);
-    const SegArgs fill = seg_users_args(c, true, f.u[3]);
-    DISPATCH_SMALL_GV(c->code_k, launch_fused_dense_a, c, fill, f.u[2], f.blocks[2]);
-    ls.done();
-  }
-  c->cur ^= 1;
-}
-
 void launch_iteration(mmsbm_hip_ctx *c, bool commit) {
-  if (commit && c->rolefuse && c->n_chunks > 0) {
-    launch_iteration_rolefused(c);
-    return;
-  }
   stage_seg(c, commit, true);
   stage_dense(c);
   stage_eta_p(c, commit);
@@ -1868,8 +1733,6 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
     c->fused = c->lds_t <= kLdsMax && c->lds_a <= kLdsMax;
     if (c->pb_nacc > 8) c->fused = false;
     c->split_rows = c->fused;  // the fallback mat-vec writes plain A rows
-    c->rolefuse = false;  // measured slower at C3 (the filler inherits the dense roles' VGPR/LDS
-                          // footprint); kept as a tuning option, see mmsbm_hip_set_option
     if (matvec_gpb(c->kp, c->lp, group_lanes(c->code_l)) < 1 ||
         matvec_gpb(c->lp, c->kp, group_lanes(c->code_k)) < 1)
       throw ApiError(MMSBM_E_UNSUPPORTED, "K*L tile does not fit the 64 KiB LDS budget");
@@ -2240,7 +2103,7 @@ int mmsbm_hip_time_stage(mmsbm_hip_ctx *ctx, int stage, int reps, float *mean_us
     use_device(ctx);
     auto one = [&] {
       switch (stage) {
-        case K_SEG: stage_seg(ctx, true, !ctx->rolefuse); break;
+        case K_SEG: stage_seg(ctx, true, true); break;
         case K_DENSE: stage_dense(ctx); break;
         case K_ETAP: stage_eta_p(ctx, true); break;
         default: stage_matvec_a(ctx, ctx->cur, ctx->cur ^ 1); break;
@@ -2266,13 +2129,8 @@ int mmsbm_hip_set_option(mmsbm_hip_ctx *ctx, const char *name, double value) {
   return guarded([&] {
     if (!ctx || !name) throw std::invalid_argument("null argument");
     const std::string key(name);
-    if (key == "rolefuse") {
-      ctx->rolefuse = value != 0.0 && ctx->fused && ctx->code_k <= 3 && ctx->code_l <= 3 &&
-                      ctx->pb_nacc <= 2 && ctx->lay.user_work.items.empty() &&
-                      !tile_in_lds(ctx->kp, ctx->lp);
-    } else if (key == "fill0" || key == "fill1" || key == "fill2") {
-      if (value < 0.0 || value > 1.0) throw std::invalid_argument("fill share must be in [0, 1]");
-      ctx->fill_frac[key[4] - '0'] = static_cast<float>(value);
+    if (key == "graph") {
+      ctx->graph_mode = value != 0.0;
     } else {
       throw std::invalid_argument("unknown option: " + key);
     }

@@ -1,0 +1,19 @@
+"""Iterations/s of the reference's per-iteration contract (kernels_hip.update_coefficients + the three
+host normalisations of src/mmsbm.py:244-250): theta/eta/p cross PCIe both ways on every call."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from mmsbm_amd import kernels_hip, MMSBM
+from mmsbm_amd.mmsbm import normalize_with_self
+from mmsbm_amd.synthetic import CONFIGS, synthetic_triples
+n, u, i, r, k, l = CONFIGS[sys.argv[1] if len(sys.argv) > 1 else "c3"]
+train = synthetic_triples(n, u, i, r, 0)
+mm = MMSBM(k, l, seed=0); mm.p, mm.m = int(train[:, 0].max()), int(train[:, 1].max()); mm._dims = {"n_ratings": r}
+d_u = np.bincount(train[:, 0]); d_i = np.bincount(train[:, 1])
+theta, eta, pr = mm.init_params(mm.child_states[0], d_u, d_i)
+for it in range(13):
+    if it == 3: t0 = time.perf_counter()
+    n_t, n_e, n_p = kernels_hip.update_coefficients(train, theta, eta, pr)
+    theta, eta, pr = n_t / d_u[:, None], n_e / d_i[:, None], normalize_with_self(n_p)
+dt = (time.perf_counter() - t0) / 10
+print(f"level-1 contract: {dt * 1e3:.2f} ms per iteration = {1 / dt:.1f} it/s (PCIe + host normalisation inclusive)")

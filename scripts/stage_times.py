@@ -25,8 +25,6 @@ ctx.set_params(*mm.init_params(mm.child_states[0], d_u, d_i))
 def best(n=200, reps=3):
     ctx.iterate(10)
     return min(ctx.time_iterations(n) for _ in range(reps)) * 1000.0 / n
-for rf in (0, 1):
-    ctx.set_option("rolefuse", rf)
-    for mode, nm in ((0, "eager"), (1, "graph")):
-        ctx.set_graph_mode(mode)
-        print(f"iteration, rolefuse={rf} {nm:6s} {best():8.2f} us")
+for mode, nm in ((0, "eager"), (1, "graph")):
+    ctx.set_graph_mode(mode)
+    print(f"iteration, {nm:6s} {best():8.2f} us")
