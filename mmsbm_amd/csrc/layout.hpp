@@ -87,7 +87,19 @@ struct Layout {
   WorkList pair_work, user_work;      // only filled when some segment is long
 };
 
-constexpr int32_t kMvChunkPairs = 64;  // one 64-pair unit per workgroup
+constexpr int32_t kMvChunkPairs = 64;  // default: one 64-pair unit per workgroup
+
+// (Re)build the pair_block work list with `pairs` pairs per workgroup (a multiple of 64).  More
+// pairs per workgroup = fewer K x L slabs, which matters once a slab is large (big K*L).
+inline void build_mv_chunks(Layout &L, int32_t pairs) {
+  L.mv_chunks.clear();
+  L.mv_chunk_off.assign(size_t(L.n_ratings) + 1, 0);
+  for (int r = 0; r < L.n_ratings; ++r) {
+    for (int32_t q = L.rating_off[r]; q < L.rating_off[r + 1]; q += pairs)
+      L.mv_chunks.push_back(Chunk{r, q, std::min<int32_t>(q + pairs, L.rating_off[r + 1]), 0});
+    L.mv_chunk_off[r + 1] = int32_t(L.mv_chunks.size());
+  }
+}
 
 inline void build_layout(int64_t n_obs, int32_t n_users, int32_t n_items, int32_t n_ratings,
                          const int32_t *user, const int32_t *item, const int32_t *rating,
@@ -188,16 +200,12 @@ inline void build_layout(int64_t n_obs, int32_t n_users, int32_t n_items, int32_
   cp = (cp + 15) / 16 * 16;
   L.chunk_pairs = cp;
   L.chunk_off.assign(size_t(n_ratings) + 1, 0);
-  L.mv_chunk_off.assign(size_t(n_ratings) + 1, 0);
   for (int r = 0; r < n_ratings; ++r) {
     for (int32_t q = L.rating_off[r]; q < L.rating_off[r + 1]; q += cp)
       L.chunks.push_back(Chunk{r, q, std::min<int32_t>(q + cp, L.rating_off[r + 1]), 0});
     L.chunk_off[r + 1] = int32_t(L.chunks.size());
-    for (int32_t q = L.rating_off[r]; q < L.rating_off[r + 1]; q += kMvChunkPairs)
-      L.mv_chunks.push_back(
-          Chunk{r, q, std::min<int32_t>(q + kMvChunkPairs, L.rating_off[r + 1]), 0});
-    L.mv_chunk_off[r + 1] = int32_t(L.mv_chunks.size());
   }
+  build_mv_chunks(L, kMvChunkPairs);
   build_worklist(L.pair_off, L.pair_work);
   build_worklist(L.user_off, L.user_work);
 }

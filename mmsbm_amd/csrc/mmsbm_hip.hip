@@ -1749,6 +1749,8 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
         mmsbm::build_layout(n_obs, c->n_users, c->n_items, n_ratings, iu, ii, rating, target, c->lay);
       }
     }
+    // big K x L tiles: four 64-pair units per pair_block workgroup (4x fewer slabs to write + add)
+    if (c->kp * c->lp > 1024) mmsbm::build_mv_chunks(c->lay, 4 * mmsbm::kMvChunkPairs);
     c->n_pairs = c->lay.n_pairs;
     c->n_chunks = static_cast<int>(c->lay.chunks.size());
 
