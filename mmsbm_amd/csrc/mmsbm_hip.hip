@@ -489,6 +489,7 @@ __device__ __forceinline__ void pair_block_body(const PairBlockArgs &pa,
   __shared__ int32_t rowid[kUnitPairs];
   const mmsbm::Chunk ch = pa.chunks[block];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int nthr = blockDim.x;  // 256..512: one wave per chunk of 4 outputs when the row is short
   const int nch = doutp >> 2;
 
   // The rating's tile is the same for every lane: it is read through the scalar cache
@@ -503,7 +504,7 @@ __device__ __forceinline__ void pair_block_body(const PairBlockArgs &pa,
   double *tile_l = es + static_cast<size_t>(kUnitPairs) * doutp;  // [dinp][doutp], TLDS only
   if (TLDS) {
     const double *src = tiles + static_cast<size_t>(ch.rating) * dinp * doutp;
-    for (int t = tid * 2; t < dinp * doutp; t += kBlock * 2)
+    for (int t = tid * 2; t < dinp * doutp; t += nthr * 2)
       *reinterpret_cast<double2 *>(tile_l + t) = *reinterpret_cast<const double2 *>(src + t);
   }
   // S slots (DO_S): a slot is a 2 (k) x 4 (l) register tile; `spb` threads form one copy of
@@ -531,12 +532,12 @@ __device__ __forceinline__ void pair_block_body(const PairBlockArgs &pa,
     }
     if (!(abl & 1)) {  // input rows -> cst (transposed).  Two double2 per thread in flight.
       const int total = np * dinp;
-      for (int t0 = tid * 2; t0 < total; t0 += kBlock * 4) {
+      for (int t0 = tid * 2; t0 < total; t0 += nthr * 4) {
         double2 v[2];
         int pr[2], d[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          const int t = min(t0 + j * kBlock * 2, total - 2);
+          const int t = min(t0 + j * nthr * 2, total - 2);
           pr[j] = t / dinp;
           d[j] = t - pr[j] * dinp;
           const size_t row = GATHER ? static_cast<size_t>(rowid[pr[j]]) : static_cast<size_t>(q0 + pr[j]);
@@ -544,31 +545,31 @@ __device__ __forceinline__ void pair_block_body(const PairBlockArgs &pa,
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          if (t0 + j * kBlock * 2 < total) {
+          if (t0 + j * nthr * 2 < total) {
             cst[d[j] * CS + pr[j]] = v[j].x;
             cst[(d[j] + 1) * CS + pr[j]] = v[j].y;
           }
         }
       }
       if (np < kUnitPairs)  // ragged tail of a rating: zero the missing columns
-        for (int t = tid; t < (kUnitPairs - np) * dinp; t += kBlock)
+        for (int t = tid; t < (kUnitPairs - np) * dinp; t += nthr)
           cst[(t / (kUnitPairs - np)) * CS + np + t % (kUnitPairs - np)] = 0.0;
     }
     if (DO_S && !GATHER) __syncthreads();  // item ids visible
     if (DO_S && !(abl & 2)) {  // gathered eta rows -> es (row-major)
       const int total = np * doutp;
-      for (int t0 = tid * 2; t0 < total; t0 += kBlock * 4) {
+      for (int t0 = tid * 2; t0 < total; t0 += nthr * 4) {
         double2 v[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          const int t = min(t0 + j * kBlock * 2, total - 2);
+          const int t = min(t0 + j * nthr * 2, total - 2);
           const int pr = t / doutp;
           v[j] = *reinterpret_cast<const double2 *>(
               e_tab + static_cast<size_t>(rowid[pr]) * doutp + (t - pr * doutp));
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          const int t = t0 + j * kBlock * 2;
+          const int t = t0 + j * nthr * 2;
           if (t < total) *reinterpret_cast<double2 *>(es + t) = v[j];
         }
       }
@@ -599,7 +600,7 @@ __device__ __forceinline__ void pair_block_body(const PairBlockArgs &pa,
     }
     // ---- mat-vec: lane = pair, wave = output chunk ------------------------------------------
     // (readfirstlane: tell the compiler the wave index is uniform so the tile loads scalarise)
-    for (int c = __builtin_amdgcn_readfirstlane(wave); c < nch && !(abl & 8); c += kBlock / 64) {
+    for (int c = __builtin_amdgcn_readfirstlane(wave); c < nch && !(abl & 8); c += nthr / 64) {
       double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
       // rows d >= din of the tile and of the inputs are zero padding, dinp is a multiple of 4:
       // four rows' operands are fetched from LDS before any of them is used
@@ -636,13 +637,13 @@ __device__ __forceinline__ void pair_block_body(const PairBlockArgs &pa,
       const int total = np * doutp;
       if (pa.out_mw == doutp) {
         double *dst = out + static_cast<size_t>(q0) * doutp;
-        for (int t = tid * 2; t < total; t += kBlock * 2)
+        for (int t = tid * 2; t < total; t += nthr * 2)
           *reinterpret_cast<double2 *>(dst + t) = *reinterpret_cast<const double2 *>(tout + t);
       } else {  // RowTab output (A): main lines and tail rows are each contiguous for the unit
         const int mw = pa.out_mw, tw = doutp - mw;
         double *dmain = out + static_cast<size_t>(q0) * mw;
         double *dtail = out + pa.out_tail_off + static_cast<size_t>(q0) * tw;
-        for (int t = tid * 2; t < total; t += kBlock * 2) {
+        for (int t = tid * 2; t < total; t += nthr * 2) {
           const int pr = t / doutp, j = t - pr * doutp;
           double *dst = j < mw ? dmain + pr * mw + j : dtail + pr * tw + (j - mw);
           *reinterpret_cast<double2 *>(dst) = *reinterpret_cast<const double2 *>(tout + t);
@@ -685,8 +686,10 @@ __device__ __forceinline__ void pair_block_body(const PairBlockArgs &pa,
   }
 }
 
+constexpr int kPairBlockMax = 512;
+
 template <bool GATHER, bool DO_S, int NACC, bool TLDS>
-__global__ __launch_bounds__(kBlock) void pair_block_kernel(PairBlockArgs pa,
+__global__ __launch_bounds__(kPairBlockMax) void pair_block_kernel(PairBlockArgs pa,
                                                             const double *__restrict__ tiles) {
   pair_block_body<GATHER, DO_S, NACC, TLDS>(pa, tiles, blockIdx.x);
 }
@@ -1040,7 +1043,7 @@ __global__ __launch_bounds__(kLikThreads) void likelihood_units_kernel(
   extern __shared__ double lds[];
   double *ths = lds;                                          // [kp][kLikThreads]
   double *ets = lds + static_cast<size_t>(kp) * kLikThreads;  // [lp][kLikThreads]
-  __shared__ int32_t poff[kUnitPairs + 1];
+  __shared__ int32_t poff[kUnitPairs + 4];  // (+4: keeps the dynamic LDS base 16-byte aligned)
   __shared__ double red[kLikThreads];
   const mmsbm::Chunk ch = units[blockIdx.x];
   const int tid = threadIdx.x;
@@ -1222,6 +1225,7 @@ struct mmsbm_hip_ctx {
   int ablate = 0;           // tuning aid (mmsbm_hip_time_stage): phases pair_block skips
   bool fused = false;       // pair_block path (else: pair_matvec + p_partial fallback)
   bool split_rows = false;  // theta and A kept as 128-byte main lines + tail rows (RowTab)
+  int pb_threads_t = kBlock, pb_threads_a = kBlock;  // pair_block workgroup sizes (T+S mode, A mode)
   int pb_spb = kBlock, pb_nacc = 1, pb_nsub = 1;  // pair_block S phase: threads per slot-grid copy, slots per thread
   size_t lds_t = 0, lds_a = 0;
   mmsbm::Layout lay;  // host copy (degrees, sizes)
@@ -1321,7 +1325,7 @@ size_t pair_block_lds(int dinp, int doutp, bool with_s) {
   (void)with_s;  // the eta rows and the output rows share one region
   const size_t d = static_cast<size_t>(dinp) * (kUnitPairs + 1) + static_cast<size_t>(kUnitPairs) * doutp +
                    (tile_in_lds(dinp, doutp) ? static_cast<size_t>(dinp) * doutp : 0);
-  return std::max(d, static_cast<size_t>(kBlock) * 8) * sizeof(double);  // >= hand-over area of S
+  return std::max(d, static_cast<size_t>(kPairBlockMax) * 8) * sizeof(double);  // >= hand-over area of S
 }
 
 template <class K>
@@ -1443,10 +1447,10 @@ void stage_dense(mmsbm_hip_ctx *c) {  // T = P^T C  and the K x L slabs for p
   do {                                                                                      \
     if (tile_in_lds(c->kp, c->lp)) {                                                        \
       allow_big_lds(pair_block_kernel<false, true, N, true>, c->lds_t);                     \
-      pair_block_kernel<false, true, N, true><<<nb, kBlock, c->lds_t, c->stream>>>(pa, pa.tiles); \
+      pair_block_kernel<false, true, N, true><<<nb, c->pb_threads_t, c->lds_t, c->stream>>>(pa, pa.tiles); \
     } else {                                                                                \
       allow_big_lds(pair_block_kernel<false, true, N, false>, c->lds_t);                    \
-      pair_block_kernel<false, true, N, false><<<nb, kBlock, c->lds_t, c->stream>>>(pa, pa.tiles); \
+      pair_block_kernel<false, true, N, false><<<nb, c->pb_threads_t, c->lds_t, c->stream>>>(pa, pa.tiles); \
     }                                                                                       \
   } while (0)
     switch (c->pb_nacc) {
@@ -1505,10 +1509,10 @@ void stage_matvec_a(mmsbm_hip_ctx *c, int slot, int a_slot) {
     const PairBlockArgs pa = pair_block_a_args(c, slot, a_slot);
     if (tile_in_lds(c->lp, c->kp)) {
       allow_big_lds(pair_block_kernel<true, false, 1, true>, c->lds_a);
-      pair_block_kernel<true, false, 1, true><<<nb, kBlock, c->lds_a, c->stream>>>(pa, pa.tiles);
+      pair_block_kernel<true, false, 1, true><<<nb, c->pb_threads_a, c->lds_a, c->stream>>>(pa, pa.tiles);
     } else {
       allow_big_lds(pair_block_kernel<true, false, 1, false>, c->lds_a);
-      pair_block_kernel<true, false, 1, false><<<nb, kBlock, c->lds_a, c->stream>>>(pa, pa.tiles);
+      pair_block_kernel<true, false, 1, false><<<nb, c->pb_threads_a, c->lds_a, c->stream>>>(pa, pa.tiles);
     }
   } else {
     launch_group_matvec(c, c->pt[slot].ptr, c->eta[slot].ptr, c->pair_item.ptr,
@@ -1720,13 +1724,19 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
       c->nacc = n;
     }
     {
+      // four waves share the chunks of 4 outputs of a short row; long rows get up to 8 waves
+      // (measured: 320 threads do not beat 256 at L = 20, 512 beat 256 by 15 % at L = 50)
+      auto threads_for = [](int nch) { return 64 * (nch <= 6 ? 4 : std::min(nch, kPairBlockMax / 64)); };
+      c->pb_threads_t = threads_for(c->lp / 4);
+      c->pb_threads_a = threads_for(c->kp / 4);
+      const int nthr = c->pb_threads_t;
       const int nslot = (c->kp / 2) * (c->lp / 4);
-      if (nslot <= kBlock / 2) {
+      if (nslot <= nthr / 2) {
         c->pb_spb = nslot; c->pb_nacc = 1;
         const int room = (c->kp * (kUnitPairs + 1) + kUnitPairs * c->lp) / (nslot * 8);  // hand-over area
-        c->pb_nsub = std::max(1, std::min(std::min(kBlock / nslot, 8), 1 + room));
+        c->pb_nsub = std::max(1, std::min(std::min(nthr / nslot, 8), 1 + room));
       }
-      else { c->pb_spb = kBlock; int n = 1; while (n * kBlock < nslot) n *= 2; c->pb_nacc = n; }
+      else { c->pb_spb = nthr; int n = 1; while (n * nthr < nslot) n *= 2; c->pb_nacc = n; }
     }
     c->lds_t = pair_block_lds(c->kp, c->lp, true);
     c->lds_a = pair_block_lds(c->lp, c->kp, false);

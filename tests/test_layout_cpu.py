@@ -122,7 +122,7 @@ def test_long_segments_become_work_items():
         items, splits = lay[f"{which}_items"], lay[f"{which}_splits"]
         lens = np.diff(off)
         assert lens.max() > 64 and len(items) > len(lens)
-        assert np.all(items[:, 2] - items[:, 1] <= 64) and np.all(items[:, 2] > items[:, 1])
+        assert np.all(items[:, 2] - items[:, 1] <= 64) and np.all(items[:, 2] >= items[:, 1])
         # the items tile every non-empty segment exactly, in order
         cover = np.zeros(off[-1], dtype=int)
         for seg, b, e, part in items:
