@@ -469,7 +469,7 @@ struct PairBlockArgs {
   size_t out_tail_off;  // ... and where the tail part starts (RowTab layout)
 };
 
-template <bool GATHER, bool DO_S, int NACC, bool TLDS>
+template <bool GATHER, bool DO_S, int NACC, bool TLDS, int NT>
 __device__ __forceinline__ void pair_block_body(const PairBlockArgs &pa,
                                                 const double *__restrict__ tiles, int block) {
   const double *__restrict__ in_tab = pa.in_tab;
@@ -489,7 +489,7 @@ __device__ __forceinline__ void pair_block_body(const PairBlockArgs &pa,
   __shared__ int32_t rowid[kUnitPairs];
   const mmsbm::Chunk ch = pa.chunks[block];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int nthr = blockDim.x;  // 256..512: one wave per chunk of 4 outputs when the row is short
+  constexpr int nthr = NT;  // 256, or 512 for long rows (more waves to share the output chunks)
   const int nch = doutp >> 2;
 
   // The rating's tile is the same for every lane: it is read through the scalar cache
@@ -688,10 +688,10 @@ __device__ __forceinline__ void pair_block_body(const PairBlockArgs &pa,
 
 constexpr int kPairBlockMax = 512;
 
-template <bool GATHER, bool DO_S, int NACC, bool TLDS>
-__global__ __launch_bounds__(kPairBlockMax) void pair_block_kernel(PairBlockArgs pa,
-                                                            const double *__restrict__ tiles) {
-  pair_block_body<GATHER, DO_S, NACC, TLDS>(pa, tiles, blockIdx.x);
+template <bool GATHER, bool DO_S, int NACC, bool TLDS, int NT>
+__global__ __launch_bounds__(NT) void pair_block_kernel(PairBlockArgs pa,
+                                                        const double *__restrict__ tiles) {
+  pair_block_body<GATHER, DO_S, NACC, TLDS, NT>(pa, tiles, blockIdx.x);
 }
 
 // ======================================================================================
@@ -1325,7 +1325,7 @@ size_t pair_block_lds(int dinp, int doutp, bool with_s) {
   (void)with_s;  // the eta rows and the output rows share one region
   const size_t d = static_cast<size_t>(dinp) * (kUnitPairs + 1) + static_cast<size_t>(kUnitPairs) * doutp +
                    (tile_in_lds(dinp, doutp) ? static_cast<size_t>(dinp) * doutp : 0);
-  return std::max(d, static_cast<size_t>(kPairBlockMax) * 8) * sizeof(double);  // >= hand-over area of S
+  return d * sizeof(double);  // the S hand-over area reuses it (create() bounds the copies by it)
 }
 
 template <class K>
@@ -1443,15 +1443,18 @@ void stage_dense(mmsbm_hip_ctx *c) {  // T = P^T C  and the K x L slabs for p
     LaunchScope ls(c, K_DENSE);
     const int nb = static_cast<int>(c->lay.mv_chunks.size());
     const PairBlockArgs pa = pair_block_t_args(c);
+#define PB_GO(N, TL, NT)                                                                    \
+  do {                                                                                      \
+    allow_big_lds(pair_block_kernel<false, true, N, TL, NT>, c->lds_t);                     \
+    pair_block_kernel<false, true, N, TL, NT><<<nb, NT, c->lds_t, c->stream>>>(pa, pa.tiles); \
+  } while (0)
 #define PB(N)                                                                               \
   do {                                                                                      \
-    if (tile_in_lds(c->kp, c->lp)) {                                                        \
-      allow_big_lds(pair_block_kernel<false, true, N, true>, c->lds_t);                     \
-      pair_block_kernel<false, true, N, true><<<nb, c->pb_threads_t, c->lds_t, c->stream>>>(pa, pa.tiles); \
-    } else {                                                                                \
-      allow_big_lds(pair_block_kernel<false, true, N, false>, c->lds_t);                    \
-      pair_block_kernel<false, true, N, false><<<nb, c->pb_threads_t, c->lds_t, c->stream>>>(pa, pa.tiles); \
-    }                                                                                       \
+    const bool tl = tile_in_lds(c->kp, c->lp), big = c->pb_threads_t > kBlock;              \
+    if (tl && big) PB_GO(N, true, kPairBlockMax);                                           \
+    else if (tl) PB_GO(N, true, kBlock);                                                    \
+    else if (big) PB_GO(N, false, kPairBlockMax);                                           \
+    else PB_GO(N, false, kBlock);                                                           \
   } while (0)
     switch (c->pb_nacc) {
       case 1: PB(1); break;
@@ -1460,6 +1463,7 @@ void stage_dense(mmsbm_hip_ctx *c) {  // T = P^T C  and the K x L slabs for p
       default: PB(8); break;
     }
 #undef PB
+#undef PB_GO
     ls.done();
     return;
   }
@@ -1507,13 +1511,17 @@ void stage_matvec_a(mmsbm_hip_ctx *c, int slot, int a_slot) {
   if (c->fused) {
     const int nb = static_cast<int>(c->lay.mv_chunks.size());
     const PairBlockArgs pa = pair_block_a_args(c, slot, a_slot);
-    if (tile_in_lds(c->lp, c->kp)) {
-      allow_big_lds(pair_block_kernel<true, false, 1, true>, c->lds_a);
-      pair_block_kernel<true, false, 1, true><<<nb, c->pb_threads_a, c->lds_a, c->stream>>>(pa, pa.tiles);
-    } else {
-      allow_big_lds(pair_block_kernel<true, false, 1, false>, c->lds_a);
-      pair_block_kernel<true, false, 1, false><<<nb, c->pb_threads_a, c->lds_a, c->stream>>>(pa, pa.tiles);
-    }
+#define PA_GO(TL, NT)                                                                       \
+  do {                                                                                      \
+    allow_big_lds(pair_block_kernel<true, false, 1, TL, NT>, c->lds_a);                     \
+    pair_block_kernel<true, false, 1, TL, NT><<<nb, NT, c->lds_a, c->stream>>>(pa, pa.tiles); \
+  } while (0)
+    const bool tl = tile_in_lds(c->lp, c->kp), big = c->pb_threads_a > kBlock;
+    if (tl && big) PA_GO(true, kPairBlockMax);
+    else if (tl) PA_GO(true, kBlock);
+    else if (big) PA_GO(false, kPairBlockMax);
+    else PA_GO(false, kBlock);
+#undef PA_GO
   } else {
     launch_group_matvec(c, c->pt[slot].ptr, c->eta[slot].ptr, c->pair_item.ptr,
                         c->atab[a_slot].ptr, c->l, c->lp, c->kp, c->code_k);
@@ -1726,7 +1734,7 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
     {
       // four waves share the chunks of 4 outputs of a short row; long rows get up to 8 waves
       // (measured: 320 threads do not beat 256 at L = 20, 512 beat 256 by 15 % at L = 50)
-      auto threads_for = [](int nch) { return 64 * (nch <= 6 ? 4 : std::min(nch, kPairBlockMax / 64)); };
+      auto threads_for = [](int nch) { return nch <= 6 ? kBlock : kPairBlockMax; };
       c->pb_threads_t = threads_for(c->lp / 4);
       c->pb_threads_a = threads_for(c->kp / 4);
       const int nthr = c->pb_threads_t;
