@@ -469,7 +469,7 @@ struct PairBlockArgs {
   size_t out_tail_off;  // ... and where the tail part starts (RowTab layout)
 };
 
-template <bool GATHER, bool DO_S, int NACC, bool TLDS, int NT>
+template <bool GATHER, bool DO_S, int NACC, bool TLDS, int NT, int KT>
 __device__ __forceinline__ void pair_block_body(const PairBlockArgs &pa,
                                                 const double *__restrict__ tiles, int block) {
   const double *__restrict__ in_tab = pa.in_tab;
@@ -477,7 +477,7 @@ __device__ __forceinline__ void pair_block_body(const PairBlockArgs &pa,
   const int32_t *__restrict__ pair_item = pa.pair_item;
   double *__restrict__ out = pa.out;
   double *__restrict__ partial = pa.partial;
-  const int din = pa.din, dinp = pa.dinp, doutp = pa.doutp, spb = pa.spb, abl = pa.abl;
+  const int dinp = pa.dinp, doutp = pa.doutp, spb = pa.spb, abl = pa.abl;  // (rows >= din are zero)
   const int nsub = pa.nsub;
   // abl: tuning aid, normally 0 -- bit0 rows, bit1 eta rows, bit2 S, bit3 mat-vec, bit4 output
   // copy, bit5 slab store, bit6 tile staging are skipped when set
@@ -507,20 +507,22 @@ __device__ __forceinline__ void pair_block_body(const PairBlockArgs &pa,
     for (int t = tid * 2; t < dinp * doutp; t += nthr * 2)
       *reinterpret_cast<double2 *>(tile_l + t) = *reinterpret_cast<const double2 *>(src + t);
   }
-  // S slots (DO_S): a slot is a 2 (k) x 4 (l) register tile; `spb` threads form one copy of
+  // S slots (DO_S): a slot is a KT (k) x 4 (l) register tile (KT = 4: 16 FMAs per 4 + 2 LDS
+  // reads; KT = 2 keeps more copies busy when K x L is small); `spb` threads form one copy of
   // the K x L slot grid and the block's nsub copies split each unit's pairs.
-  const int nslot = (dinp >> 1) * nch;
+  constexpr int TV = KT * 4;
+  const int nslot = (dinp / KT) * nch;
   const int sub = tid / spb, slot0 = tid % spb;
   const bool s_active = sub < nsub;
   int coff[NACC], eoff[NACC];
-  double acc[NACC][8];
+  double acc[NACC][TV];
 #pragma unroll
   for (int a = 0; a < NACC; ++a) {
     const int o = min(slot0 + a * spb, nslot - 1);
-    coff[a] = (o / nch) * 2 * CS;
+    coff[a] = (o / nch) * KT * CS;
     eoff[a] = (o % nch) * 4;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[a][j] = 0.0;
+    for (int j = 0; j < TV; ++j) acc[a][j] = 0.0;
   }
 
   for (int q0 = ch.q_begin; q0 < ch.q_end; q0 += kUnitPairs) {
@@ -582,17 +584,18 @@ __device__ __forceinline__ void pair_block_body(const PairBlockArgs &pa,
         for (int j = sub; j < np; j += nsub) {
 #pragma unroll
           for (int a = 0; a < NACC; ++a) {
-            const double c0 = cst[coff[a] + j], c1 = cst[coff[a] + CS + j];
+            double cv[KT];
+#pragma unroll
+            for (int i = 0; i < KT; ++i) cv[i] = cst[coff[a] + i * CS + j];
             const double2 e0 = *reinterpret_cast<const double2 *>(es + j * doutp + eoff[a]);
             const double2 e1 = *reinterpret_cast<const double2 *>(es + j * doutp + eoff[a] + 2);
-            acc[a][0] = fma(c0, e0.x, acc[a][0]);
-            acc[a][1] = fma(c0, e0.y, acc[a][1]);
-            acc[a][2] = fma(c0, e1.x, acc[a][2]);
-            acc[a][3] = fma(c0, e1.y, acc[a][3]);
-            acc[a][4] = fma(c1, e0.x, acc[a][4]);
-            acc[a][5] = fma(c1, e0.y, acc[a][5]);
-            acc[a][6] = fma(c1, e1.x, acc[a][6]);
-            acc[a][7] = fma(c1, e1.y, acc[a][7]);
+#pragma unroll
+            for (int i = 0; i < KT; ++i) {
+              acc[a][4 * i + 0] = fma(cv[i], e0.x, acc[a][4 * i + 0]);
+              acc[a][4 * i + 1] = fma(cv[i], e0.y, acc[a][4 * i + 1]);
+              acc[a][4 * i + 2] = fma(cv[i], e1.x, acc[a][4 * i + 2]);
+              acc[a][4 * i + 3] = fma(cv[i], e1.y, acc[a][4 * i + 3]);
+            }
           }
         }
       }
@@ -656,14 +659,14 @@ __device__ __forceinline__ void pair_block_body(const PairBlockArgs &pa,
       __syncthreads();
       if (s_active && sub > 0 && slot0 < nslot) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j)  // [value][copy][slot]: consecutive lanes, consecutive words
+        for (int j = 0; j < TV; ++j)  // [value][copy][slot]: consecutive lanes, consecutive words
           lds[(j * (nsub - 1) + sub - 1) * nslot + slot0] = acc[0][j];
       }
       __syncthreads();
       if (sub == 0 && slot0 < nslot) {
         for (int o = 1; o < nsub; ++o)
 #pragma unroll
-          for (int j = 0; j < 8; ++j) acc[0][j] += lds[(j * (nsub - 1) + o - 1) * nslot + slot0];
+          for (int j = 0; j < TV; ++j) acc[0][j] += lds[(j * (nsub - 1) + o - 1) * nslot + slot0];
       }
     }
     if (sub == 0 && !(abl & 32)) {
@@ -672,9 +675,9 @@ __device__ __forceinline__ void pair_block_body(const PairBlockArgs &pa,
       for (int a = 0; a < NACC; ++a) {
         const int o = slot0 + a * spb;
         if (o < nslot) {
-          double *cell = dst + (o / nch) * 2 * doutp + eoff[a];
+          double *cell = dst + (o / nch) * KT * doutp + eoff[a];
 #pragma unroll
-          for (int h = 0; h < 2; ++h) {
+          for (int h = 0; h < KT; ++h) {
             double2 x, y;
             x.x = acc[a][4 * h]; x.y = acc[a][4 * h + 1]; y.x = acc[a][4 * h + 2]; y.y = acc[a][4 * h + 3];
             *reinterpret_cast<double2 *>(cell + h * doutp) = x;
@@ -688,10 +691,10 @@ __device__ __forceinline__ void pair_block_body(const PairBlockArgs &pa,
 
 constexpr int kPairBlockMax = 512;
 
-template <bool GATHER, bool DO_S, int NACC, bool TLDS, int NT>
+template <bool GATHER, bool DO_S, int NACC, bool TLDS, int NT, int KT>
 __global__ __launch_bounds__(NT) void pair_block_kernel(PairBlockArgs pa,
                                                         const double *__restrict__ tiles) {
-  pair_block_body<GATHER, DO_S, NACC, TLDS, NT>(pa, tiles, blockIdx.x);
+  pair_block_body<GATHER, DO_S, NACC, TLDS, NT, KT>(pa, tiles, blockIdx.x);
 }
 
 // ======================================================================================
@@ -1226,6 +1229,7 @@ struct mmsbm_hip_ctx {
   bool fused = false;       // pair_block path (else: pair_matvec + p_partial fallback)
   bool split_rows = false;  // theta and A kept as 128-byte main lines + tail rows (RowTab)
   int pb_threads_t = kBlock, pb_threads_a = kBlock;  // pair_block workgroup sizes (T+S mode, A mode)
+  int pb_kt = 4;  // pair_block S phase: k-rows per register tile (2 when K x L is small)
   int pb_spb = kBlock, pb_nacc = 1, pb_nsub = 1;  // pair_block S phase: threads per slot-grid copy, slots per thread
   size_t lds_t = 0, lds_a = 0;
   mmsbm::Layout lay;  // host copy (degrees, sizes)
@@ -1443,10 +1447,14 @@ void stage_dense(mmsbm_hip_ctx *c) {  // T = P^T C  and the K x L slabs for p
     LaunchScope ls(c, K_DENSE);
     const int nb = static_cast<int>(c->lay.mv_chunks.size());
     const PairBlockArgs pa = pair_block_t_args(c);
+#define PB_KT(N, TL, NT, KT)                                                                \
+  do {                                                                                      \
+    allow_big_lds(pair_block_kernel<false, true, N, TL, NT, KT>, c->lds_t);                 \
+    pair_block_kernel<false, true, N, TL, NT, KT><<<nb, NT, c->lds_t, c->stream>>>(pa, pa.tiles); \
+  } while (0)
 #define PB_GO(N, TL, NT)                                                                    \
   do {                                                                                      \
-    allow_big_lds(pair_block_kernel<false, true, N, TL, NT>, c->lds_t);                     \
-    pair_block_kernel<false, true, N, TL, NT><<<nb, NT, c->lds_t, c->stream>>>(pa, pa.tiles); \
+    if (c->pb_kt == 2) PB_KT(N, TL, NT, 2); else PB_KT(N, TL, NT, 4);                        \
   } while (0)
 #define PB(N)                                                                               \
   do {                                                                                      \
@@ -1459,11 +1467,11 @@ void stage_dense(mmsbm_hip_ctx *c) {  // T = P^T C  and the K x L slabs for p
     switch (c->pb_nacc) {
       case 1: PB(1); break;
       case 2: PB(2); break;
-      case 4: PB(4); break;
-      default: PB(8); break;
+      default: PB(4); break;
     }
 #undef PB
 #undef PB_GO
+#undef PB_KT
     ls.done();
     return;
   }
@@ -1513,8 +1521,8 @@ void stage_matvec_a(mmsbm_hip_ctx *c, int slot, int a_slot) {
     const PairBlockArgs pa = pair_block_a_args(c, slot, a_slot);
 #define PA_GO(TL, NT)                                                                       \
   do {                                                                                      \
-    allow_big_lds(pair_block_kernel<true, false, 1, TL, NT>, c->lds_a);                     \
-    pair_block_kernel<true, false, 1, TL, NT><<<nb, NT, c->lds_a, c->stream>>>(pa, pa.tiles); \
+    allow_big_lds(pair_block_kernel<true, false, 1, TL, NT, 4>, c->lds_a);                  \
+    pair_block_kernel<true, false, 1, TL, NT, 4><<<nb, NT, c->lds_a, c->stream>>>(pa, pa.tiles); \
   } while (0)
     const bool tl = tile_in_lds(c->lp, c->kp), big = c->pb_threads_a > kBlock;
     if (tl && big) PA_GO(true, kPairBlockMax);
@@ -1738,10 +1746,12 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
       c->pb_threads_t = threads_for(c->lp / 4);
       c->pb_threads_a = threads_for(c->kp / 4);
       const int nthr = c->pb_threads_t;
-      const int nslot = (c->kp / 2) * (c->lp / 4);
+      c->pb_kt = ((c->kp / 2) * (c->lp / 4) <= kBlock / 2) ? 2 : 4;
+      const int nslot = (c->kp / c->pb_kt) * (c->lp / 4);
       if (nslot <= nthr / 2) {
         c->pb_spb = nslot; c->pb_nacc = 1;
-        const int room = (c->kp * (kUnitPairs + 1) + kUnitPairs * c->lp) / (nslot * 8);  // hand-over area
+        const int room = (c->kp * (kUnitPairs + 1) + kUnitPairs * c->lp) /
+                         (nslot * 4 * c->pb_kt);  // hand-over area
         c->pb_nsub = std::max(1, std::min(std::min(nthr / nslot, 8), 1 + room));
       }
       else { c->pb_spb = nthr; int n = 1; while (n * nthr < nslot) n *= 2; c->pb_nacc = n; }
@@ -1749,7 +1759,7 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
     c->lds_t = pair_block_lds(c->kp, c->lp, true);
     c->lds_a = pair_block_lds(c->lp, c->kp, false);
     c->fused = c->lds_t <= kLdsMax && c->lds_a <= kLdsMax;
-    if (c->pb_nacc > 8) c->fused = false;
+    if (c->pb_nacc > 4) c->fused = false;
     c->split_rows = c->fused;  // the fallback mat-vec writes plain A rows
     if (matvec_gpb(c->kp, c->lp, group_lanes(c->code_l)) < 1 ||
         matvec_gpb(c->lp, c->kp, group_lanes(c->code_k)) < 1)
