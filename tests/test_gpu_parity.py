@@ -449,3 +449,35 @@ def test_c5_full_size_invariants(hip):
     assert np.allclose(t.sum(1), 1, atol=1e-13) and np.allclose(e.sum(1), 1, atol=1e-13)
     assert np.allclose(p.sum(2), 1, atol=1e-13)
     assert np.isfinite(ctx.likelihood())
+
+
+def test_randomised_shapes_against_oracle(hip):
+    """40 seeded random problems (K, L in 1..48, R in 1..12, uniform or skewed degrees, either side
+    paired with the ratings): numerators after one step and parameters after 3 iterations."""
+    rng = np.random.default_rng(2024)
+    for trial in range(40):
+        k, l, r = int(rng.integers(1, 49)), int(rng.integers(1, 49)), int(rng.integers(1, 13))
+        n_u, n_i = int(rng.integers(1, 400)), int(rng.integers(1, 200))
+        n = int(rng.integers(1, 4000))
+        u = rng.integers(0, n_u, n); i = rng.integers(0, n_i, n)
+        if trial % 4 == 1:
+            u = np.where(rng.random(n) < 0.5, 0, u)
+        if trial % 4 == 2:
+            i = np.where(rng.random(n) < 0.5, n_i - 1, i)
+        data = np.stack([u, i, rng.integers(0, r, n)], axis=1).astype(np.int64)
+        theta = rng.random((n_u, k)); eta = rng.random((n_i, l))
+        pr = orc.normalize_with_self(rng.random((k, l, r)))
+        d_u = np.maximum(np.bincount(u, minlength=n_u), 1); d_i = np.maximum(np.bincount(i, minlength=n_i), 1)
+        tag = (trial, k, l, r, n_u, n_i, n)
+        with make_ctx(hip, data, theta, eta, pr, swap_sides=int(trial % 3 == 0)) as em:
+            want = orc.update_coefficients(data, theta, eta, pr)
+            for got, w, nm in zip(em.update_coefficients(), want, ("n_theta", "n_eta", "n_pr")):
+                assert rel_err(got, w) < TOL_STEP, (tag, nm)
+            em.iterate(3)
+            t, e, p = theta, eta, pr
+            for _ in range(3):
+                t, e, p = orc.em_step(data, t, e, p, d_u, d_i)
+            for got, w, nm in zip(em.get_params(), (t, e, p), ("theta", "eta", "pr")):
+                assert rel_err(got, w) < 1e-10, (tag, nm)
+            lik, lik_o = em.likelihood(), float(orc.compute_likelihood(data, t, e, p))
+            assert lik == pytest.approx(lik_o, rel=1e-10, abs=1e-12), tag
