@@ -59,3 +59,29 @@ def test_product_code_never_touches_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src.replace("the oracle", ""), f
+
+
+def _build_demo(tmp_path):
+    import shutil, subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    exe = tmp_path / "abi_demo"
+    lib_dir = os.path.join(ROOT, "mmsbm_amd")
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-O2",
+           "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "abi_demo.c"),
+           "-o", str(exe), "-L" + lib_dir, "-lmmsbm_hip", "-Wl,-rpath," + lib_dir,
+           "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr[-3000:]
+    return exe
+
+
+def test_header_is_plain_c99_and_demo_links(tmp_path):
+    """include/mmsbm_hip.h compiles as pedantic C99 (-Werror) and a C program links against the
+    library; without a GPU the program stops at the first call with the library's message."""
+    import subprocess
+    exe = _build_demo(tmp_path)
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is present: the run is checked by the gpu test")
+    run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 1 and "mmsbm_hip_device_count" in run.stderr

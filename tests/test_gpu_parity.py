@@ -481,3 +481,34 @@ def test_randomised_shapes_against_oracle(hip):
                 assert rel_err(got, w) < 1e-10, (tag, nm)
             lik, lik_o = em.likelihood(), float(orc.compute_likelihood(data, t, e, p))
             assert lik == pytest.approx(lik_o, rel=1e-10, abs=1e-12), tag
+
+
+def test_plain_c_program_matches_python_path(hip, tmp_path):
+    """examples/abi_demo.c (C99, no Python) and the ctypes path give the same numbers on the same
+    LCG-generated problem."""
+    import re, subprocess
+    from test_abi_cpu import _build_demo
+    exe = _build_demo(tmp_path)
+    n, U, I, R, K, L, iters = 5000, 300, 120, 5, 6, 9, 25
+    run = subprocess.run([str(exe)] + [str(x) for x in (n, U, I, R, K, L, iters)], capture_output=True,
+                         text=True, timeout=300)
+    assert run.returncode == 0, run.stdout + run.stderr
+    m = re.search(r"likelihood (\S+) max\|rowsum-1\| (\S+) checksum (\S+)", run.stdout)
+    lik_c, worst, chk_c = float(m.group(1)), float(m.group(2)), float(m.group(3))
+    state = 88172645463325252
+    def lcg():
+        nonlocal state
+        state = (state * 6364136223846793005 + 1442695040888963407) % (1 << 64)
+        return state >> 33
+    trip = np.array([[lcg() % U, lcg() % I, lcg() % R] for _ in range(n)], dtype=np.int64)
+    unit = lambda: (lcg() + 1.0) / 2147483649.0
+    theta = np.array([unit() for _ in range(U * K)]).reshape(U, K)
+    eta = np.array([unit() for _ in range(I * L)]).reshape(I, L)
+    pr = np.array([unit() for _ in range(K * L * R)]).reshape(K, L, R)
+    with hip.HipEM(trip, K, L, U, I, R) as em:
+        em.set_params(theta, eta, pr)
+        em.iterate(iters)
+        t = em.get_params()[0]
+        assert em.likelihood() == pytest.approx(lik_c, rel=1e-12)
+        assert float(((np.arange(U) % 7 + 1)[:, None] * t).sum()) == pytest.approx(chk_c, rel=1e-12)
+    assert worst < 1e-12
