@@ -81,7 +81,7 @@ class MMSBM:
 
     def _device_list(self):
         if self.devices is not None:
-            return list(self.devices)
+            return list(dict.fromkeys(int(d) for d in self.devices))  # unique, order kept
         return [0]
 
     def _ctx(self, device, slot=0):

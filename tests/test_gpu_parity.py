@@ -512,3 +512,29 @@ def test_plain_c_program_matches_python_path(hip, tmp_path):
         assert em.likelihood() == pytest.approx(lik_c, rel=1e-12)
         assert float(((np.arange(U) % 7 + 1)[:, None] * t).sum()) == pytest.approx(chk_c, rel=1e-12)
     assert worst < 1e-12
+
+
+def test_degenerate_sizes(hip):
+    """No triples at all, a single triple, and ids that never occur: defined results, no launch of
+    an empty grid, same numbers as the oracle."""
+    rng = np.random.default_rng(3)
+    theta = rng.random((3, 2)); eta = rng.random((2, 3)); pr = orc.normalize_with_self(rng.random((2, 3, 2)))
+    empty = np.zeros((0, 3), dtype=np.int64)
+    with hip.HipEM(empty, 2, 3, n_users=3, n_items=2, n_ratings=2) as em:
+        em.set_params(theta, eta, pr)
+        for got in em.update_coefficients():
+            assert not got.any()
+        em.iterate(2)
+        t, e, p = em.get_params()
+        assert not t.any() and not e.any() and not p.any()      # 0/1 and the zero-row guard
+        assert em.likelihood() == 0.0 and em.compute_omegas().shape == (0, 2, 3)
+    one = np.array([[2, 1, 1]], dtype=np.int64)
+    with hip.HipEM(one, 2, 3, n_users=3, n_items=2, n_ratings=2) as em:
+        em.set_params(theta, eta, pr)
+        want = orc.update_coefficients(one, theta, eta, pr)
+        for got, w in zip(em.update_coefficients(), want):
+            assert np.allclose(got, w, rtol=1e-13, atol=0)
+        em.iterate(1)
+        d_u, d_i = np.array([1, 1, 1]), np.array([1, 1])
+        for got, w in zip(em.get_params(), orc.em_step(one, theta, eta, pr, d_u, d_i)):
+            assert np.allclose(got, w, rtol=1e-13, atol=0)
