@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Random restarts across the GPUs of one node, one process per GPU:
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        examples/fit_multi_gpu.py --sampling 8 --iterations 400
+
+Restart i runs on rank i mod W (no collective on the data path); one all-reduce over RCCL at the
+end tells every rank all likelihoods, i.e. the maximum-likelihood restart; the parameters of all
+restarts are gathered so that rank 0 can predict like the reference does (mean over restarts)."""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import numpy as np  # noqa: E402
+
+from mmsbm_amd import restarts  # noqa: E402  (imports torch before the HIP library)
+from mmsbm_amd import MMSBM  # noqa: E402
+from mmsbm_amd.synthetic import synthetic_triples  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--sampling", type=int, default=8)
+    ap.add_argument("--iterations", type=int, default=400)
+    ap.add_argument("--ratings", type=int, default=1_000_000)
+    ap.add_argument("--groups", type=int, default=20)
+    args = ap.parse_args()
+    rank, world, local, device = restarts.init_from_env()
+    train = synthetic_triples(args.ratings, args.ratings // 10, args.ratings // 50, 5, seed=0)
+    model = MMSBM(args.groups, args.groups, iterations=args.iterations, sampling=args.sampling, seed=0)
+    best, best_lik, liks = restarts.fit_distributed(model, train, device=device)
+    if rank == 0:
+        print(f"{world} rank(s), {args.sampling} restarts: likelihoods {np.round(liks, 3).tolist()}")
+        print(f"maximum-likelihood restart: {best} ({best_lik:.3f}); {len(model.results)} result sets gathered")
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
