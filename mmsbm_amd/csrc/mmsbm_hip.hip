@@ -312,139 +312,6 @@ __global__ __launch_bounds__(kBlock) void seg_combine_kernel(CombineArgs ca, Com
 }
 
 // ======================================================================================
-// kernels 1 and 5: pair_matvec -- out[q, :] = sum_d M_r[d, :] * in[row(q), d] for every
-// pair q of a rating-homogeneous chunk; the Din x Dout tile M_r lives in LDS.
-//   T = P_r^T-contract:  M = p[r] as [K][Lp],  in = C[q, :K],            out = T[q, :Lp]
-//   A = P_r-contract:    M = pT[r] as [L][Kp], in = eta[item(q), :L],    out = A[q, :Kp]
-// One group of G lanes per pair, lanes over the output dimension.
-// ======================================================================================
-template <int G, int VEC>
-__global__ __launch_bounds__(kBlock) void pair_matvec_kernel(
-    const double *__restrict__ tiles, const double *__restrict__ in_tab,
-    const int32_t *__restrict__ gather, const mmsbm::Chunk *__restrict__ chunks,
-    double *__restrict__ out, int din, int dinp, int doutp, int gpb) {
-  extern __shared__ double lds[];  // gpb <= kBlock / G groups work per batch (LDS budget)
-  double *tile = lds;                                   // [dinp][doutp]
-  double *rows = lds + static_cast<size_t>(dinp) * doutp;  // [gpb][dinp]
-  const mmsbm::Chunk ch = chunks[blockIdx.x];
-  const int tile_elems = dinp * doutp;
-  const double *src = tiles + static_cast<size_t>(ch.rating) * tile_elems;
-  for (int t = threadIdx.x * 2; t < tile_elems; t += kBlock * 2)
-    *reinterpret_cast<double2 *>(tile + t) = *reinterpret_cast<const double2 *>(src + t);
-
-  const int grp = threadIdx.x / G, gl = threadIdx.x % G;
-  const bool act = gl * VEC < doutp;
-  const int lane_off = act ? gl * VEC : 0;
-  double *myrow = rows + static_cast<size_t>(min(grp, gpb - 1)) * dinp;
-
-  for (int q0 = ch.q_begin; q0 < ch.q_end; q0 += gpb) {
-    const int q = q0 + grp;
-    const bool have = grp < gpb && q < ch.q_end;
-    __syncthreads();  // tile staged (first trip) / previous rows consumed
-    if (have) {
-      const size_t r = gather ? static_cast<size_t>(gather[q]) : static_cast<size_t>(q);
-      for (int d = gl * 2; d < dinp; d += G * 2)
-        *reinterpret_cast<double2 *>(myrow + d) =
-            *reinterpret_cast<const double2 *>(in_tab + r * dinp + d);
-    }
-    __syncthreads();
-    if (have) {
-      double acc[VEC];
-#pragma unroll
-      for (int v = 0; v < VEC; ++v) acc[v] = 0.0;
-      for (int d = 0; d < din; ++d) {
-        const double x = myrow[d];
-        double m[VEC];
-        load_vec<VEC>(tile + static_cast<size_t>(d) * doutp + lane_off, m);
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) acc[v] = fma(m[v], x, acc[v]);
-      }
-      if (act) store_vec<VEC>(out + static_cast<size_t>(q) * doutp + lane_off, acc);
-    }
-  }
-}
-
-// ======================================================================================
-// kernels 1 and 6 (fast form): pair_matvec_lane -- same contraction, one LANE per pair.
-// A wave owns 64 consecutive pairs of one rating.  Each lane copies its input row into a
-// wave-private, transposed LDS slab rowsT[d][lane] (conflict-free b64 reads); the tile
-// M_r[d][:] is the same for every lane: it is staged once per block in LDS and read with
-// broadcast ds_read_b128, so the inner loop runs at full 64-lane occupancy.
-// Outputs are produced in chunks of 4; NCH = dout/4 is a compile-time constant so the
-// row loop is branch-free.
-// ======================================================================================
-template <int NCH>
-__global__ __launch_bounds__(kBlock) void pair_matvec_lane_kernel(
-    const double *__restrict__ tiles, const double *__restrict__ in_tab,
-    const int32_t *__restrict__ gather, const mmsbm::Chunk *__restrict__ chunks,
-    double *__restrict__ out, int din, int dinp) {
-  constexpr int DOUT = NCH * 4;
-  extern __shared__ double lds[];
-  const mmsbm::Chunk ch = chunks[blockIdx.x];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
-  double *tile = lds;                                                   // [dinp][DOUT]
-  double *rows_t = lds + static_cast<size_t>(dinp) * DOUT + static_cast<size_t>(wave) * dinp * 64;
-  {  // all waves stage the rating's tile (one coalesced pass), overlapped with the row loads
-    const double *src = tiles + static_cast<size_t>(ch.rating) * dinp * DOUT;
-    for (int t = threadIdx.x * 2; t < dinp * DOUT; t += blockDim.x * 2)
-      *reinterpret_cast<double2 *>(tile + t) = *reinterpret_cast<const double2 *>(src + t);
-  }
-  bool first = true;
-  for (int base = ch.q_begin + wave * 64; base < ch.q_end || first; base += nwaves * 64) {
-    const int q = base + lane;
-    const bool have = q < ch.q_end;
-    const size_t row = have ? (gather ? static_cast<size_t>(gather[q]) : static_cast<size_t>(q)) : 0;
-    const double *src = in_tab + row * dinp;
-    for (int d0 = 0; d0 < dinp; d0 += 16) {  // 8 row pieces in flight per lane
-      double2 v[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j)
-        v[j] = *reinterpret_cast<const double2 *>(src + min(d0 + 2 * j, dinp - 2));
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int d = d0 + 2 * j;
-        if (d < dinp) {
-          rows_t[d * 64 + lane] = have ? v[j].x : 0.0;
-          rows_t[(d + 1) * 64 + lane] = have ? v[j].y : 0.0;
-        }
-      }
-    }
-    if (first) {
-      __syncthreads();  // tile staged (every wave of the block reaches this exactly once)
-      first = false;
-    } else {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-    }
-    if (base >= ch.q_end) break;
-    double acc[DOUT];
-#pragma unroll
-    for (int j = 0; j < DOUT; ++j) acc[j] = 0.0;
-    for (int d = 0; d < din; ++d) {
-      const double x = rows_t[d * 64 + lane];
-      const double *trow = tile + d * DOUT;
-#pragma unroll
-      for (int j = 0; j < DOUT; j += 2) {
-        const double2 m = *reinterpret_cast<const double2 *>(trow + j);
-        acc[j] = fma(x, m.x, acc[j]);
-        acc[j + 1] = fma(x, m.y, acc[j + 1]);
-      }
-    }
-    if (have) {
-      double *dst = out + static_cast<size_t>(q) * DOUT;
-#pragma unroll
-      for (int j = 0; j < DOUT; j += 2) {
-        double2 a;
-        a.x = acc[j]; a.y = acc[j + 1];
-        *reinterpret_cast<double2 *>(dst + j) = a;
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    __builtin_amdgcn_wave_barrier();  // rows_t is rewritten by the next trip
-  }
-}
-
-// ======================================================================================
 // pair_block -- the fused dense stage.  A block takes a unit of <= 64 consecutive pairs of
 // ONE rating (more if its chunk is longer) and, per unit, stages in LDS (coalesced flat copies;
 // the rating's Din x Dout tile p[r] / pT[r] is lane-uniform and comes through SGPRs instead):
@@ -698,113 +565,6 @@ __global__ __launch_bounds__(NT) void pair_block_kernel(PairBlockArgs pa,
 }
 
 // ======================================================================================
-// kernel 2: p_partial -- per chunk of pairs of one rating, the K x L partial sum
-//   S[k,l] = sum_{q in chunk} C[q,k] * eta[item(q), l]
-// C rows and gathered eta rows are staged in LDS in batches; each thread owns NACC
-// (k, l-pair) accumulators in registers.  One slab per chunk, combined by p_update in
-// a fixed order (deterministic, no atomics).
-// ======================================================================================
-// Thread slot = (k, group of 4 l); when the K x L/4 slots fit in 128 threads the block runs
-// two copies that split the pairs of a batch (combined in a fixed order at the end).  A
-// batch is as many pairs as the LDS budget holds -- normally the whole chunk, so a block
-// pays the (chunk -> item ids -> eta rows) latency chain once.
-template <int NACC>
-__global__ __launch_bounds__(kBlock) void p_partial_kernel(
-    const double *__restrict__ ctab, const double *__restrict__ eta,
-    const int32_t *__restrict__ pair_item, const mmsbm::Chunk *__restrict__ chunks,
-    double *__restrict__ partial, int kp, int lp, int batch, int spb) {
-  extern __shared__ double lds[];
-  double *cs = lds;                                   // [batch][kp]
-  double *es = lds + static_cast<size_t>(batch) * kp;  // [batch][lp]
-  const mmsbm::Chunk ch = chunks[blockIdx.x];
-  const int tid = threadIdx.x;
-  const int nsub = kBlock / spb, sub = tid / spb, slot0 = tid % spb;
-  const int lq = lp >> 2, nout = kp * lq;
-  int coff[NACC], eoff[NACC];
-  double acc[NACC][4];
-#pragma unroll
-  for (int a = 0; a < NACC; ++a) {
-    const int o = min(slot0 + a * spb, nout - 1);
-    coff[a] = o / lq;
-    eoff[a] = (o % lq) * 4;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[a][j] = 0.0;
-  }
-  const int kh = kp >> 1, lh = lp >> 1;
-  for (int q0 = ch.q_begin; q0 < ch.q_end; q0 += batch) {
-    const int nb = min(batch, ch.q_end - q0);
-    const int nc2 = nb * kh, ne2 = nb * lh;
-    __syncthreads();  // previous batch consumed
-    for (int u0 = tid; u0 < ne2; u0 += kBlock * 8) {  // gathered eta rows, 8 loads in flight
-      int it[8];
-      double2 v[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) it[j] = pair_item[q0 + min(u0 + j * kBlock, ne2 - 1) / lh];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int u = min(u0 + j * kBlock, ne2 - 1);
-        v[j] = *reinterpret_cast<const double2 *>(eta + static_cast<size_t>(it[j]) * lp + (u % lh) * 2);
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int u = u0 + j * kBlock;
-        if (u < ne2) *reinterpret_cast<double2 *>(es + 2 * u) = v[j];
-      }
-    }
-    for (int u0 = tid; u0 < nc2; u0 += kBlock * 8) {  // C rows are contiguous
-      double2 v[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j)
-        v[j] = *reinterpret_cast<const double2 *>(ctab + static_cast<size_t>(q0) * kp +
-                                                  2 * min(u0 + j * kBlock, nc2 - 1));
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int u = u0 + j * kBlock;
-        if (u < nc2) *reinterpret_cast<double2 *>(cs + 2 * u) = v[j];
-      }
-    }
-    __syncthreads();
-    for (int j = sub; j < nb; j += nsub) {
-#pragma unroll
-      for (int a = 0; a < NACC; ++a) {
-        const double c = cs[j * kp + coff[a]];
-        const double2 e0 = *reinterpret_cast<const double2 *>(es + j * lp + eoff[a]);
-        const double2 e1 = *reinterpret_cast<const double2 *>(es + j * lp + eoff[a] + 2);
-        acc[a][0] = fma(c, e0.x, acc[a][0]);
-        acc[a][1] = fma(c, e0.y, acc[a][1]);
-        acc[a][2] = fma(c, e1.x, acc[a][2]);
-        acc[a][3] = fma(c, e1.y, acc[a][3]);
-      }
-    }
-  }
-  if (nsub == 2) {  // second copy hands its sums over through LDS (NACC == 1 here)
-    __syncthreads();
-    if (sub == 1) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) lds[slot0 * 4 + j] = acc[0][j];
-    }
-    __syncthreads();
-    if (sub == 0) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[0][j] += lds[slot0 * 4 + j];
-    }
-  }
-  if (sub == 0) {
-    double *dst = partial + static_cast<size_t>(blockIdx.x) * kp * lp;
-#pragma unroll
-    for (int a = 0; a < NACC; ++a) {
-      const int o = slot0 + a * spb;
-      if (o < nout) {
-        double2 x, y;
-        x.x = acc[a][0]; x.y = acc[a][1]; y.x = acc[a][2]; y.y = acc[a][3];
-        *reinterpret_cast<double2 *>(dst + coff[a] * lp + eoff[a]) = x;
-        *reinterpret_cast<double2 *>(dst + coff[a] * lp + eoff[a] + 2) = y;
-      }
-    }
-  }
-}
-
-// ======================================================================================
 // kernel 4: p_update -- n_p[r][k][l] = p[r][k][l] * sum_{chunks c of r} S_c[k][l] (fixed
 // order: 64 strided partial sums, then 8 sums of 8, then a sum of 8), followed by
 // normalize_with_self over r (src/expectation_maximization.py:152-155; zero rows stay
@@ -977,16 +737,6 @@ __global__ __launch_bounds__(kRedThreads) void eta_p_kernel(EtaPArgs a) {
   else
     item_sum_block<G, VEC>(blockIdx.x - a.nb_p, a.ttab, a.item_off, a.item_pairs, a.item_deg,
                            a.eta, a.eta_new, a.n_items, a.lp, a.normalize);
-}
-
-// stand-alone forms (fallback path for shapes the fused kernels do not cover)
-__global__ __launch_bounds__(kRedThreads) void p_update_kernel(
-    const double *__restrict__ partial, const int32_t *__restrict__ chunk_off,
-    const double *__restrict__ p_old, double *__restrict__ p_new, double *__restrict__ pt_new,
-    double *__restrict__ npr, int n_ratings, int kp, int lp, int normalize) {
-  __shared__ double red[kRedGroup][kRedRows][kRedCols];
-  p_update_block<kRedRows>(red, blockIdx.x, partial, chunk_off, p_old, p_new, pt_new, npr, n_ratings,
-                           kp, lp, normalize);
 }
 
 // ======================================================================================
@@ -1224,9 +974,8 @@ struct mmsbm_hip_ctx {
   // internal dims ("item" = the side paired with the rating)
   int n_users = 0, n_items = 0, n_ratings = 0, k = 0, l = 0, kp = 0, lp = 0;
   int n_pairs = 0, n_chunks = 0;
-  int code_k = 0, code_l = 0, nacc = 1;
+  int code_k = 0, code_l = 0;
   int ablate = 0;           // tuning aid (mmsbm_hip_time_stage): phases pair_block skips
-  bool fused = false;       // pair_block path (else: pair_matvec + p_partial fallback)
   bool split_rows = false;  // theta and A kept as 128-byte main lines + tail rows (RowTab)
   int pb_threads_t = kBlock, pb_threads_a = kBlock;  // pair_block workgroup sizes (T+S mode, A mode)
   int pb_kt = 4;  // pair_block S phase: k-rows per register tile (2 when K x L is small)
@@ -1234,8 +983,8 @@ struct mmsbm_hip_ctx {
   size_t lds_t = 0, lds_a = 0;
   mmsbm::Layout lay;  // host copy (degrees, sizes)
   DevBuf<int32_t> pair_off, pair_user, pair_item, user_off, user_pair, item_off, item_pairs,
-      item_deg, chunk_off, mv_chunk_off, orig_u, orig_i, orig_r;
-  DevBuf<mmsbm::Chunk> chunks, mv_chunks;
+      item_deg, mv_chunk_off, orig_u, orig_i, orig_r;
+  DevBuf<mmsbm::Chunk> mv_chunks;
   DevBuf<mmsbm::WorkItem> pair_items, user_items;   // only when some segment is long
   DevBuf<mmsbm::SplitSeg> pair_splits, user_splits;
   DevBuf<double> pair_parts, user_parts;
@@ -1288,35 +1037,7 @@ struct LaunchScope {  // optional event pair around one launch
 
 void use_device(const mmsbm_hip_ctx *c) { HIP_CHECK(hipSetDevice(c->device)); }
 
-constexpr size_t kLdsBudget = 64 * 1024;  // static + dynamic LDS a launch may use by default
-
-// groups per batch of pair_matvec such that tile + rows fit the LDS budget (0: tile too big)
-int matvec_gpb(int dinp, int doutp, int g) {
-  const size_t tile = static_cast<size_t>(dinp) * doutp * sizeof(double);
-  if (tile + static_cast<size_t>(dinp) * sizeof(double) > kLdsBudget) return 0;
-  const size_t fit = (kLdsBudget - tile) / (static_cast<size_t>(dinp) * sizeof(double));
-  return static_cast<int>(std::min<size_t>(fit, static_cast<size_t>(kBlock / g)));
-}
-size_t matvec_lds_bytes(int dinp, int doutp, int gpb) {
-  return (static_cast<size_t>(dinp) * doutp + static_cast<size_t>(gpb) * dinp) * sizeof(double);
-}
-// p_partial: pairs per batch that the LDS budget holds; threads per copy (128 -> two copies
-// split each batch).
-int ppartial_batch(int kp, int lp) {
-  const size_t per = static_cast<size_t>(kp + lp) * sizeof(double);
-  return static_cast<int>(std::max<size_t>(std::min<size_t>(kLdsBudget / per, 1024), 1));
-}
-int ppartial_spb(int kp, int lp) { return (kp * (lp / 4) <= kBlock / 2) ? kBlock / 2 : kBlock; }
-
-// lane-per-pair mat-vec: waves per block the transposed row slabs allow (0: use the
-// group-per-pair kernel instead), and the compile-time bound on dout/4
-int lane_matvec_waves(int dinp, int doutp) {
-  if (doutp / 4 > 16) return 0;
-  const size_t tile = static_cast<size_t>(dinp) * doutp * sizeof(double);
-  const size_t per_wave = static_cast<size_t>(dinp) * 64 * sizeof(double);
-  if (tile + per_wave > kLdsBudget) return 0;
-  return static_cast<int>(std::min<size_t>(kBlock / 64, (kLdsBudget - tile) / per_wave));
-}
+constexpr size_t kLdsBudget = 64 * 1024;  // dynamic LDS a launch may use without hipFuncSetAttribute
 
 constexpr size_t kLdsMax = 160 * 1024;  // with hipFuncAttributeMaxDynamicSharedMemorySize
 
@@ -1340,26 +1061,13 @@ void allow_big_lds(K kernel, size_t bytes) {
                                   static_cast<int>(bytes)));
 }
 
-// fallback mat-vec (one group of lanes per pair, tile in LDS)
-void launch_group_matvec(mmsbm_hip_ctx *c, const double *tiles, const double *in_tab,
-                         const int32_t *gather, double *out, int din, int dinp, int doutp,
-                         int code_out) {
-  const int gpb = matvec_gpb(dinp, doutp, group_lanes(code_out));
-  const size_t lds = matvec_lds_bytes(dinp, doutp, gpb);
-#define CALL(G, V)                                                                          \
-  pair_matvec_kernel<G, V><<<c->n_chunks, kBlock, lds, c->stream>>>(                        \
-      tiles, in_tab, gather, c->chunks.ptr, out, din, dinp, doutp, gpb)
-  DISPATCH_GV(code_out, CALL);
-#undef CALL
-}
-
 // ---- the stages of one EM iteration ---------------------------------------------------------
 // commit: parameters advance (theta, eta, p normalised, A refreshed); otherwise the
 // un-normalised numerators are left in the "next" buffers / npr.
-// split (main/tail) tables: theta and A when the fused kernels are in use; plain otherwise
+// split (main/tail) tables -- see RowTab: theta and A are the gathered ones, eta/C/T stream
 RowTab plain_tab(double *base, int width) { return RowTab{base, 0, width, 0}; }
 RowTab gather_tab(const mmsbm_hip_ctx *c, double *base, size_t rows) {
-  int mw = c->split_rows ? (c->kp / 16) * 16 : c->kp;
+  int mw = c->split_rows ? (c->kp / 16) * 16 : c->kp;  // (split_rows is always on today)
   if (mw == 0) mw = c->kp;
   return RowTab{base, rows * static_cast<size_t>(mw), mw, c->kp - mw};
 }
@@ -1401,7 +1109,7 @@ EtaPArgs eta_p_args(const mmsbm_hip_ctx *c, bool commit, int cols_per_block) {
   const int cur = c->cur, nxt = cur ^ 1;
   EtaPArgs a;
   a.partial = c->partial.ptr;
-  a.chunk_off = c->fused ? c->mv_chunk_off.ptr : c->chunk_off.ptr;
+  a.chunk_off = c->mv_chunk_off.ptr;
   a.p_old = c->p[cur].ptr; a.p_new = c->p[nxt].ptr; a.pt_new = c->pt[nxt].ptr; a.npr = c->npr.ptr;
   a.ttab = c->ttab.ptr; a.item_off = c->item_off.ptr; a.item_pairs = c->item_pairs.ptr;
   a.item_deg = c->item_deg.ptr; a.eta = c->eta[cur].ptr; a.eta_new = c->eta[nxt].ptr;
@@ -1443,7 +1151,7 @@ void stage_seg(mmsbm_hip_ctx *c, bool commit, bool with_users) {
 void stage_dense(mmsbm_hip_ctx *c) {  // T = P^T C  and the K x L slabs for p
   if (c->n_chunks == 0) return;
   const int cur = c->cur;
-  if (c->fused) {
+  {
     LaunchScope ls(c, K_DENSE);
     const int nb = static_cast<int>(c->lay.mv_chunks.size());
     const PairBlockArgs pa = pair_block_t_args(c);
@@ -1473,32 +1181,7 @@ void stage_dense(mmsbm_hip_ctx *c) {  // T = P^T C  and the K x L slabs for p
 #undef PB_GO
 #undef PB_KT
     ls.done();
-    return;
   }
-  {
-    LaunchScope ls(c, K_DENSE);
-    launch_group_matvec(c, c->p[cur].ptr, c->ctab.ptr, nullptr, c->ttab.ptr, c->k, c->kp, c->lp,
-                        c->code_l);
-    ls.done();
-  }
-  LaunchScope ls(c, K_DENSE);
-  const int batch = std::min(ppartial_batch(c->kp, c->lp), std::max(c->lay.chunk_pairs, 1));
-  const int spb = ppartial_spb(c->kp, c->lp);
-  const size_t lds = std::max(static_cast<size_t>(batch) * (c->kp + c->lp),
-                              static_cast<size_t>(kBlock) * 2) * sizeof(double);
-#define PP(N)                                                                               \
-  p_partial_kernel<N><<<c->n_chunks, kBlock, lds, c->stream>>>(                             \
-      c->ctab.ptr, c->eta[cur].ptr, c->pair_item.ptr, c->chunks.ptr, c->partial.ptr, c->kp,  \
-      c->lp, batch, spb)
-  switch (c->nacc) {
-    case 1: PP(1); break;
-    case 2: PP(2); break;
-    case 4: PP(4); break;
-    case 8: PP(8); break;
-    default: PP(16); break;
-  }
-#undef PP
-  ls.done();
 }
 
 void stage_eta_p(mmsbm_hip_ctx *c, bool commit) {  // eta_new ; p_new, pT_new, raw n_p
@@ -1516,7 +1199,7 @@ void stage_eta_p(mmsbm_hip_ctx *c, bool commit) {  // eta_new ; p_new, pT_new, r
 void stage_matvec_a(mmsbm_hip_ctx *c, int slot, int a_slot) {
   if (c->n_chunks == 0) return;
   LaunchScope ls(c, K_MATVEC_A);
-  if (c->fused) {
+  {
     const int nb = static_cast<int>(c->lay.mv_chunks.size());
     const PairBlockArgs pa = pair_block_a_args(c, slot, a_slot);
 #define PA_GO(TL, NT)                                                                       \
@@ -1530,9 +1213,6 @@ void stage_matvec_a(mmsbm_hip_ctx *c, int slot, int a_slot) {
     else if (big) PA_GO(false, kPairBlockMax);
     else PA_GO(false, kBlock);
 #undef PA_GO
-  } else {
-    launch_group_matvec(c, c->pt[slot].ptr, c->eta[slot].ptr, c->pair_item.ptr,
-                        c->atab[a_slot].ptr, c->l, c->lp, c->kp, c->code_k);
   }
   ls.done();
 }
@@ -1731,15 +1411,6 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
     c->kp = pad_dim(c->k); c->lp = pad_dim(c->l);
     c->code_k = group_code(c->kp); c->code_l = group_code(c->lp);
     {
-      const int nout = c->kp * (c->lp / 4);
-      const int spb = ppartial_spb(c->kp, c->lp);
-      int need = (nout + spb - 1) / spb;
-      int n = 1;
-      while (n < need) n *= 2;
-      if (n > 16) throw ApiError(MMSBM_E_UNSUPPORTED, "K*L too large for p_partial (max 16384)");
-      c->nacc = n;
-    }
-    {
       // four waves share the chunks of 4 outputs of a short row; long rows get up to 8 waves
       // (measured: 320 threads do not beat 256 at L = 20, 512 beat 256 by 15 % at L = 50)
       auto threads_for = [](int nch) { return nch <= 6 ? kBlock : kPairBlockMax; };
@@ -1758,29 +1429,20 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
     }
     c->lds_t = pair_block_lds(c->kp, c->lp, true);
     c->lds_a = pair_block_lds(c->lp, c->kp, false);
-    c->fused = c->lds_t <= kLdsMax && c->lds_a <= kLdsMax;
-    if (c->pb_nacc > 4) c->fused = false;
-    c->split_rows = c->fused;  // the fallback mat-vec writes plain A rows
-    if (matvec_gpb(c->kp, c->lp, group_lanes(c->code_l)) < 1 ||
-        matvec_gpb(c->lp, c->kp, group_lanes(c->code_k)) < 1)
-      throw ApiError(MMSBM_E_UNSUPPORTED, "K*L tile does not fit the 64 KiB LDS budget");
+    if (c->lds_t > kLdsMax || c->lds_a > kLdsMax || c->pb_nacc > 4)
+      throw ApiError(MMSBM_E_UNSUPPORTED,
+                     "K and L too large: the 64-pair stage needs " +
+                         std::to_string(std::max(c->lds_t, c->lds_a) / 1024) +
+                         " KiB of LDS (limit 160; roughly K, L <= 90, or one of them small)");
+    c->split_rows = true;
     if (n_ratings > 65535)
       throw ApiError(MMSBM_E_UNSUPPORTED, "more than 65535 distinct ratings are not supported");
 
-    {
-      // chunks small enough for one p_partial batch, and at least ~2 per CU
-      const int cap = ppartial_batch(c->kp, c->lp);
-      int target = 512;
-      mmsbm::build_layout(n_obs, c->n_users, c->n_items, n_ratings, iu, ii, rating, target, c->lay);
-      if (c->lay.chunk_pairs > cap && cap >= 64) {
-        target = (c->lay.n_pairs + (cap / 16 * 16) - 1) / (cap / 16 * 16) + n_ratings;
-        mmsbm::build_layout(n_obs, c->n_users, c->n_items, n_ratings, iu, ii, rating, target, c->lay);
-      }
-    }
+    mmsbm::build_layout(n_obs, c->n_users, c->n_items, n_ratings, iu, ii, rating, 512, c->lay);
     // big K x L tiles: four 64-pair units per pair_block workgroup (4x fewer slabs to write + add)
     if (c->kp * c->lp > 1024) mmsbm::build_mv_chunks(c->lay, 4 * mmsbm::kMvChunkPairs);
     c->n_pairs = c->lay.n_pairs;
-    c->n_chunks = static_cast<int>(c->lay.chunks.size());
+    c->n_chunks = static_cast<int>(c->lay.mv_chunks.size());
 
     HIP_CHECK(hipSetDevice(device));
     HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
@@ -1793,8 +1455,6 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
     c->item_off.upload(c->lay.item_off, s);
     c->item_pairs.upload(c->lay.item_pairs, s);
     c->item_deg.upload(c->lay.item_deg, s);
-    c->chunk_off.upload(c->lay.chunk_off, s);
-    c->chunks.upload(c->lay.chunks, s);
     c->mv_chunks.upload(c->lay.mv_chunks, s);
     c->mv_chunk_off.upload(c->lay.mv_chunk_off, s);
     c->pair_items.upload(c->lay.pair_work.items, s);
@@ -1828,8 +1488,7 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
     }
     c->ctab.alloc(static_cast<size_t>(c->n_pairs) * c->kp);
     c->ttab.alloc(static_cast<size_t>(c->n_pairs) * c->lp);
-    c->partial.alloc(std::max<size_t>(std::max<size_t>(c->n_chunks, c->lay.mv_chunks.size()), 1) *
-                     c->kp * c->lp);
+    c->partial.alloc(std::max<size_t>(c->lay.mv_chunks.size(), 1) * c->kp * c->lp);
     c->npr.alloc(klr);
     c->pair_parts.alloc(static_cast<size_t>(c->lay.pair_work.n_parts) * c->kp);
     c->user_parts.alloc(static_cast<size_t>(c->lay.user_work.n_parts) * c->kp);
@@ -2099,7 +1758,7 @@ int mmsbm_hip_kernel_bytes(const mmsbm_hip_ctx *ctx, int index, int64_t *bytes_r
     if (!ctx || !bytes_read || !bytes_written) throw std::invalid_argument("null argument");
     const int64_t N = ctx->n_obs, U = ctx->n_users, I = ctx->n_items, R = ctx->n_ratings;
     const int64_t K = ctx->k, L = ctx->l, Q = ctx->n_pairs;
-    const int64_t C = ctx->fused ? static_cast<int64_t>(ctx->lay.mv_chunks.size()) : ctx->n_chunks;
+    const int64_t C = static_cast<int64_t>(ctx->lay.mv_chunks.size());
     int64_t rd = 0, wr = 0;
     switch (index) {
       case K_SEG:  // two passes: index + one gathered K-row per triple; fixed rows and offsets once

@@ -373,6 +373,9 @@ def test_c_abi_error_paths(hip):
         HipEM(good, 600, 2)
     assert e.value.code == _lib.E_UNSUPPORTED
     with pytest.raises(_lib.HipLibraryError) as e:
+        HipEM(good, 128, 128)                               # the 64-pair stage would need > 160 KiB of LDS
+    assert e.value.code == _lib.E_UNSUPPORTED and "LDS" in e.value.message
+    with pytest.raises(_lib.HipLibraryError) as e:
         HipEM(good, 2, 2, device=99)
     assert e.value.code == _lib.E_INVALID
     with HipEM(good, 2, 3) as em:
