@@ -54,6 +54,22 @@ def cpu_baseline(cfg, sample_rows, iters):
             "host_cpus": os.cpu_count()}
 
 
+def batched_rate(model, train, device, slots, iters):
+    """`slots` restarts of the same training set advance with one set of
+    launches.  Reported beside the headline, never as `value` (whose config is sampling=1)."""
+    from mmsbm_amd import HipEM
+    with HipEM(train, model.user_groups, model.item_groups, model.p + 1, model.m + 1,
+               model._dims["n_ratings"], device=device, slots=slots) as em:
+        d_u, d_i = em.degrees()
+        seeds = np.random.SeedSequence(0).spawn(slots)
+        for s in range(slots):
+            em.select(s).set_params(*model.init_params(seeds[s], d_u, d_i))
+        em.iterate(5)
+        ms = min(em.time_iterations(iters) for _ in range(3))
+    return {"slots": slots, "iterations": iters, "ms_per_step_all_slots": ms / iters,
+            "value": slots * iters / (ms * 1e-3), "unit": "restart-iterations/s on one GPU (HIP events)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -64,6 +80,9 @@ def main():
     ap.add_argument("--cpu-sample-rows", type=int, default=100_000)
     ap.add_argument("--cpu-iters", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batched-restarts", type=int, default=8,
+                    help="after the timed region also report the rate with this many restarts per "
+                         "GPU advancing as slots of one context (0 = skip); never part of `value`")
     ap.add_argument("--graph", action="store_true", help="replay a captured hipGraph instead of eager launches")
     ap.add_argument("--dist-backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
     ap.add_argument("--share-gpu", action="store_true",
@@ -160,6 +179,9 @@ def main():
                            for nm, v in prof.items()},
             "likelihoods": [float(x) for x in liks], "best_restart": best,
         }
+        if args.batched_restarts > 1:
+            out["batched_restarts"] = batched_rate(model, train, local, args.batched_restarts,
+                                                   max(20, args.steps // 10))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, min(args.cpu_sample_rows, n), args.cpu_iters)
             out["gpu_over_cpu"] = its / out["cpu_baseline"]["value"]

@@ -80,6 +80,23 @@ int mmsbm_hip_set_params(mmsbm_hip_ctx *ctx, const double *theta, const double *
                          const double *pr);
 int mmsbm_hip_get_params(mmsbm_hip_ctx *ctx, double *theta, double *eta, double *pr);
 
+/* ---- restart slots: several restarts of one training set in one context ------------- */
+/* The reference runs its `sampling` restarts as independent processes over the same triples
+ * (src/mmsbm.py:182-185; batching them is the TODO of README.md:188).  A context can hold
+ * n_slots independent parameter sets ("slots") that share the sorted triples on the device:
+ * mmsbm_hip_em_iterate advances ALL slots with one set of kernel launches (the slot is a grid
+ * dimension), every other entry point (set/get_params, update_coefficients, likelihood,
+ * compute_omegas, prod_dist) acts on the SELECTED slot.  Slots never interact: slot s holds
+ * exactly what a one-slot context given the same parameters would hold, bit for bit.
+ * set_slots drops all parameters (set_params must follow for every slot) and selects slot 0;
+ * a new context has one slot. */
+int mmsbm_hip_set_slots(mmsbm_hip_ctx *ctx, int n_slots);
+int mmsbm_hip_select_slot(mmsbm_hip_ctx *ctx, int slot);
+/* Any output may be NULL.  bytes_per_slot: device memory one more slot costs (a failed
+ * set_slots -- out of device memory -- leaves the context with ONE slot and no parameters). */
+int mmsbm_hip_slots(const mmsbm_hip_ctx *ctx, int *n_slots, int *selected,
+                    int64_t *bytes_per_slot);
+
 /* ---- the hot loop: src/mmsbm.py:243-250 ------------------------------------------- */
 /* n_iters x { update_coefficients; theta = n_theta/d_u; eta = n_eta/d_i;
  * pr = normalize_with_self(n_pr) } entirely on the device; enqueues on the context's

@@ -30,6 +30,9 @@ SIGNATURES = {
     "mmsbm_hip_degrees": (C.c_int, [C.c_void_p, c_i64p, c_i64p]),
     "mmsbm_hip_set_params": (C.c_int, [C.c_void_p, c_f64p, c_f64p, c_f64p]),
     "mmsbm_hip_get_params": (C.c_int, [C.c_void_p, c_f64p, c_f64p, c_f64p]),
+    "mmsbm_hip_set_slots": (C.c_int, [C.c_void_p, C.c_int]),
+    "mmsbm_hip_select_slot": (C.c_int, [C.c_void_p, C.c_int]),
+    "mmsbm_hip_slots": (C.c_int, [C.c_void_p, c_intp, c_intp, c_i64p]),
     "mmsbm_hip_em_iterate": (C.c_int, [C.c_void_p, C.c_int]),
     "mmsbm_hip_synchronize": (C.c_int, [C.c_void_p]),
     "mmsbm_hip_update_coefficients": (C.c_int, [C.c_void_p, c_f64p, c_f64p, c_f64p]),

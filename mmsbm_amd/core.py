@@ -40,7 +40,7 @@ class HipEM:
     """Device-resident EM state for one (GPU, training set, K, L)."""
 
     def __init__(self, data, k_groups, l_groups, n_users=None, n_items=None, n_ratings=None,
-                 device=0, swap_sides=-1):
+                 device=0, swap_sides=-1, slots=1):
         u, i, r = split_triples(data)
         n = len(u)
         self.n_obs = n
@@ -56,6 +56,9 @@ class HipEM:
         dims = (C.c_int64 * 8)()
         _lib.call("mmsbm_hip_dims", self._h, dims)
         self.n_pairs, self.swapped = int(dims[6]), bool(dims[7])
+        self.slots = 1
+        if int(slots) != 1:
+            self.set_slots(slots)
 
     # -- lifetime ------------------------------------------------------------------------
     def close(self):
@@ -74,6 +77,37 @@ class HipEM:
 
     def __exit__(self, *exc):
         self.close()
+
+    # -- restart slots -------------------------------------------------------------------
+    def set_slots(self, n_slots):
+        """Hold ``n_slots`` independent restarts (parameter sets) over the same triples;
+        ``iterate`` advances all of them with one set of launches, everything else acts on
+        the selected slot.  Drops all parameters and selects slot 0."""
+        _lib.call("mmsbm_hip_set_slots", self._h, int(n_slots))
+        self.slots = int(n_slots)
+
+    def select(self, slot):
+        _lib.call("mmsbm_hip_select_slot", self._h, int(slot))
+        return self
+
+    @property
+    def selected(self):
+        s = C.c_int(0)
+        _lib.call("mmsbm_hip_slots", self._h, None, C.byref(s), None)
+        return int(s.value)
+
+    @property
+    def bytes_per_slot(self):
+        """Device memory one restart slot occupies (parameters, A/C/T tables, slabs)."""
+        b = C.c_int64(0)
+        _lib.call("mmsbm_hip_slots", self._h, None, None, C.byref(b))
+        return int(b.value)
+
+    def max_slots(self, fraction=0.5):
+        """How many slots fit in `fraction` of the device's memory (at least 1)."""
+        mem = C.c_int64(0)
+        _lib.call("mmsbm_hip_device_info", self.device, None, 0, None, C.byref(mem))
+        return max(1, int(fraction * mem.value) // max(self.bytes_per_slot, 1))
 
     # -- parameters ----------------------------------------------------------------------
     def _shapes(self):

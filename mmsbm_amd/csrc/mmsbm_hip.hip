@@ -163,12 +163,20 @@ struct SegArgs {
   int32_t mode;  // 0: out = acc   1: out = fixed*acc/max(len,1)   2: out = fixed*acc
   const mmsbm::WorkItem *items;  // null: unit w is segment w.  Else unit w is a piece of a segment
   double *parts;                 // [n_parts][dp] partial rows of the split segments
+  // restart slots (blockIdx.y): distance in doubles between the slots' copies of each table
+  size_t bs_fixed, bs_gath, bs_out, bs_parts;
 };
+__device__ __forceinline__ RowTab slot_tab(RowTab t, size_t stride) {
+  t.base += static_cast<size_t>(blockIdx.y) * stride;
+  return t;
+}
 
 template <int G, int VEC, int B>
 __device__ __forceinline__ void seg_body(const SegArgs &a, int unit, int dp) {
   const int gl = threadIdx.x % G;
   if (unit >= a.nseg) return;  // whole groups leave together
+  const RowTab fixed = slot_tab(a.fixed, a.bs_fixed), gath = slot_tab(a.gath, a.bs_gath),
+               outt = slot_tab(a.out, a.bs_out);
   int seg = unit, beg, end, part = -1;
   if (a.items) {
     const mmsbm::WorkItem it = a.items[unit];
@@ -183,7 +191,7 @@ __device__ __forceinline__ void seg_body(const SegArgs &a, int unit, int dp) {
   double f[VEC], acc[VEC];
 #pragma unroll
   for (int v = 0; v < VEC; ++v) acc[v] = 0.0;
-  load_vec<VEC>(rowtab_ptr(a.fixed, seg, lane_off), f);
+  load_vec<VEC>(rowtab_ptr(fixed, seg, lane_off), f);
   if (!act) {
 #pragma unroll
     for (int v = 0; v < VEC; ++v) f[v] = 0.0;
@@ -193,10 +201,10 @@ __device__ __forceinline__ void seg_body(const SegArgs &a, int unit, int dp) {
   // triples); the indices are then broadcast inside the group with ds_bpermute, so the
   // dependent chain is offsets -> indices -> rows instead of one index load per batch.
   // this lane's part of every gathered row: main or tail, fixed for the whole kernel
-  const bool g_main = lane_off < a.gath.mw;
-  const double *gbase = g_main ? a.gath.base + lane_off
-                               : a.gath.base + a.gath.tail_off + (lane_off - a.gath.mw);
-  const size_t gstride = g_main ? a.gath.mw : a.gath.tw;
+  const bool g_main = lane_off < gath.mw;
+  const double *gbase = g_main ? gath.base + lane_off
+                               : gath.base + gath.tail_off + (lane_off - gath.mw);
+  const size_t gstride = g_main ? gath.mw : gath.tw;
   constexpr int CH = (G < 16) ? 2 * G : G;  // indices fetched per chunk (two per lane in small groups)
   for (int c0 = beg; c0 < end; c0 += CH) {
     const int cnt = min(CH, end - c0);
@@ -227,7 +235,7 @@ __device__ __forceinline__ void seg_body(const SegArgs &a, int unit, int dp) {
 
   if (!act) return;
   if (part >= 0) {  // a piece of a long segment: raw partial sum, finished by seg_combine_kernel
-    store_vec<VEC>(a.parts + static_cast<size_t>(part) * dp + lane_off, acc);
+    store_vec<VEC>(a.parts + blockIdx.y * a.bs_parts + static_cast<size_t>(part) * dp + lane_off, acc);
     return;
   }
   double o[VEC];
@@ -242,7 +250,7 @@ __device__ __forceinline__ void seg_body(const SegArgs &a, int unit, int dp) {
 #pragma unroll
     for (int v = 0; v < VEC; ++v) o[v] = f[v] * acc[v];
   }
-  store_vec<VEC>(rowtab_ptr(a.out, seg, lane_off), o);
+  store_vec<VEC>(rowtab_ptr(outt, seg, lane_off), o);
 }
 
 // blocks [0, blocks_a) work on segment set `sa`, the rest on `sb`
@@ -261,6 +269,7 @@ struct CombineArgs {
   const int32_t *off;
   RowTab fixed, out;
   int32_t n_splits, mode;
+  size_t bs_parts, bs_fixed, bs_out;  // restart slots, as in SegArgs
 };
 
 // One workgroup per split segment: its kBlock/G groups add the pieces j = g, g + NG, ... (four
@@ -277,6 +286,7 @@ __global__ __launch_bounds__(kBlock) void seg_combine_kernel(CombineArgs ca, Com
   const bool act = gl * VEC < dp;
   const int lane_off = act ? gl * VEC : 0;
   const mmsbm::SplitSeg sp = a.splits[w];
+  const double *parts = a.parts + blockIdx.y * a.bs_parts;
   double acc[VEC];
 #pragma unroll
   for (int v = 0; v < VEC; ++v) acc[v] = 0.0;
@@ -284,7 +294,7 @@ __global__ __launch_bounds__(kBlock) void seg_combine_kernel(CombineArgs ca, Com
     double t[4][VEC];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      load_vec<VEC>(a.parts + static_cast<size_t>(sp.first_part + min(j0 + i * NG, sp.n_parts - 1)) * dp +
+      load_vec<VEC>(parts + static_cast<size_t>(sp.first_part + min(j0 + i * NG, sp.n_parts - 1)) * dp +
                         lane_off, t[i]);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -303,12 +313,12 @@ __global__ __launch_bounds__(kBlock) void seg_combine_kernel(CombineArgs ca, Com
     for (int v = 0; v < VEC; ++v) acc[v] += t[v];
   }
   double f[VEC], o[VEC];
-  load_vec<VEC>(rowtab_ptr(a.fixed, sp.seg, lane_off), f);
+  load_vec<VEC>(rowtab_ptr(slot_tab(a.fixed, a.bs_fixed), sp.seg, lane_off), f);
   const double d = static_cast<double>(max(a.off[sp.seg + 1] - a.off[sp.seg], 1));
 #pragma unroll
   for (int v = 0; v < VEC; ++v)
     o[v] = a.mode == 0 ? acc[v] : (a.mode == 1 ? (f[v] * acc[v]) / d : f[v] * acc[v]);
-  store_vec<VEC>(rowtab_ptr(a.out, sp.seg, lane_off), o);
+  store_vec<VEC>(rowtab_ptr(slot_tab(a.out, a.bs_out), sp.seg, lane_off), o);
 }
 
 // ======================================================================================
@@ -334,16 +344,19 @@ struct PairBlockArgs {
   int din, dinp, doutp, spb, nsub, abl;
   int out_mw;           // output rows: main width (== doutp: plain table) ...
   size_t out_tail_off;  // ... and where the tail part starts (RowTab layout)
+  size_t bs_tiles, bs_in, bs_e, bs_out, bs_partial;  // restart slots (blockIdx.y): table strides
 };
 
 template <bool GATHER, bool DO_S, int NACC, bool TLDS, int NT, int KT>
 __device__ __forceinline__ void pair_block_body(const PairBlockArgs &pa,
-                                                const double *__restrict__ tiles, int block) {
-  const double *__restrict__ in_tab = pa.in_tab;
-  const double *__restrict__ e_tab = pa.e_tab;
+                                                const double *__restrict__ tiles0, int block) {
+  const size_t slot = blockIdx.y;
+  const double *__restrict__ tiles = tiles0 + slot * pa.bs_tiles;
+  const double *__restrict__ in_tab = pa.in_tab + slot * pa.bs_in;
+  const double *__restrict__ e_tab = pa.e_tab + slot * pa.bs_e;
   const int32_t *__restrict__ pair_item = pa.pair_item;
-  double *__restrict__ out = pa.out;
-  double *__restrict__ partial = pa.partial;
+  double *__restrict__ out = pa.out + slot * pa.bs_out;
+  double *__restrict__ partial = pa.partial + slot * pa.bs_partial;
   const int dinp = pa.dinp, doutp = pa.doutp, spb = pa.spb, abl = pa.abl;  // (rows >= din are zero)
   const int nsub = pa.nsub;
   // abl: tuning aid, normally 0 -- bit0 rows, bit1 eta rows, bit2 S, bit3 mat-vec, bit4 output
@@ -726,17 +739,22 @@ struct EtaPArgs {
   const double *ttab; const int32_t *item_off; const int32_t *item_pairs; const int32_t *item_deg;
   const double *eta; double *eta_new;
   int n_ratings, kp, lp, n_items, normalize, nb_p;
+  size_t bs_partial, bs_p, bs_t, bs_eta;  // restart slots (blockIdx.y): table strides
 };
 
 template <int G, int VEC>
 __global__ __launch_bounds__(kRedThreads) void eta_p_kernel(EtaPArgs a) {
   __shared__ double red[kRedGroup][kRedRows][kRedCols];
+  const size_t slot = blockIdx.y;
   if (static_cast<int>(blockIdx.x) < a.nb_p)
-    p_update_block<kRedRows>(red, blockIdx.x, a.partial, a.chunk_off, a.p_old, a.p_new, a.pt_new,
-                             a.npr, a.n_ratings, a.kp, a.lp, a.normalize);
+    p_update_block<kRedRows>(red, blockIdx.x, a.partial + slot * a.bs_partial, a.chunk_off,
+                             a.p_old + slot * a.bs_p, a.p_new + slot * a.bs_p,
+                             a.pt_new + slot * a.bs_p, a.npr + slot * a.bs_p, a.n_ratings, a.kp,
+                             a.lp, a.normalize);
   else
-    item_sum_block<G, VEC>(blockIdx.x - a.nb_p, a.ttab, a.item_off, a.item_pairs, a.item_deg,
-                           a.eta, a.eta_new, a.n_items, a.lp, a.normalize);
+    item_sum_block<G, VEC>(blockIdx.x - a.nb_p, a.ttab + slot * a.bs_t, a.item_off, a.item_pairs,
+                           a.item_deg, a.eta + slot * a.bs_eta, a.eta_new + slot * a.bs_eta,
+                           a.n_items, a.lp, a.normalize);
 }
 
 // ======================================================================================
@@ -957,6 +975,17 @@ struct DevBuf {
   }
 };
 
+// A per-restart table: `slots` copies, `stride` doubles apart (whole 128-byte lines, so every
+// copy keeps the alignment of the first).
+struct SlotBuf : DevBuf<double> {
+  size_t stride = 0;
+  void alloc_slots(size_t per_slot, int slots) {
+    stride = (per_slot + 15) / 16 * 16;
+    alloc(stride * static_cast<size_t>(slots));
+  }
+  double *at(int slot) const { return ptr + static_cast<size_t>(slot) * stride; }
+};
+
 enum KernelId { K_SEG = 0, K_DENSE, K_ETAP, K_MATVEC_A, K_COUNT };
 // The four launches of an iteration.
 const char *const kKernelNames[K_COUNT] = {"seg_pass_kernel", "pair_block_kernel(T+S)",
@@ -987,10 +1016,16 @@ struct mmsbm_hip_ctx {
   DevBuf<mmsbm::Chunk> mv_chunks;
   DevBuf<mmsbm::WorkItem> pair_items, user_items;   // only when some segment is long
   DevBuf<mmsbm::SplitSeg> pair_splits, user_splits;
-  DevBuf<double> pair_parts, user_parts;
-  DevBuf<double> theta[2], eta[2], p[2], pt[2], atab[2], ctab, ttab, partial, npr, lik_part;
+  // Per-restart state, one copy per slot.  A context carries n_slots independent restarts
+  // (parameter sets) over the SAME triples; em_iterate advances all of them with one set of
+  // launches (blockIdx.y = slot), the single-restart entry points act on slot `sel`.
+  int n_slots = 1, sel = 0;
+  int base_slot = 0, launch_slots = 1;  // what the next launches cover: [base_slot, base_slot + launch_slots)
+  SlotBuf pair_parts, user_parts;
+  SlotBuf theta[2], eta[2], p[2], pt[2], atab[2], ctab, ttab, partial, npr;
+  DevBuf<double> lik_part;
   int cur = 0;
-  bool have_params = false;
+  std::vector<char> have;  // per slot: set_params has been called
   bool graph_mode = false;  // replay a captured two-iteration hipGraph instead of eager launches
   hipGraphExec_t graph_exec[2] = {nullptr, nullptr};  // indexed by `cur` at capture time
   // per-launch profiling
@@ -1071,19 +1106,34 @@ RowTab gather_tab(const mmsbm_hip_ctx *c, double *base, size_t rows) {
   if (mw == 0) mw = c->kp;
   return RowTab{base, rows * static_cast<size_t>(mw), mw, c->kp - mw};
 }
-RowTab theta_tab(const mmsbm_hip_ctx *c, int slot) {
-  return gather_tab(c, c->theta[slot].ptr, static_cast<size_t>(c->n_users));
+// (`b` = which of the two ping-pong buffers; the restart slot is c->base_slot)
+RowTab theta_tab(const mmsbm_hip_ctx *c, int b) {
+  return gather_tab(c, c->theta[b].at(c->base_slot), static_cast<size_t>(c->n_users));
 }
-RowTab a_tab(const mmsbm_hip_ctx *c, int slot) {
-  return gather_tab(c, c->atab[slot].ptr, static_cast<size_t>(c->n_pairs));
+RowTab a_tab(const mmsbm_hip_ctx *c, int b) {
+  return gather_tab(c, c->atab[b].at(c->base_slot), static_cast<size_t>(c->n_pairs));
 }
+dim3 slot_grid(const mmsbm_hip_ctx *c, int blocks) {
+  return dim3(static_cast<unsigned>(blocks), static_cast<unsigned>(c->launch_slots), 1);
+}
+// Single-restart entry points: launches and copies cover the selected slot only.
+struct OneSlot {
+  mmsbm_hip_ctx *c;
+  int b, n;
+  explicit OneSlot(mmsbm_hip_ctx *ctx) : c(ctx), b(ctx->base_slot), n(ctx->launch_slots) {
+    c->base_slot = c->sel;
+    c->launch_slots = 1;
+  }
+  ~OneSlot() { c->base_slot = b; c->launch_slots = n; }
+};
 
 SegArgs seg_pairs_args(const mmsbm_hip_ctx *c) {  // C = sum over a pair's triples
   const bool it = !c->lay.pair_work.items.empty();
   return SegArgs{a_tab(c, c->cur), theta_tab(c, c->cur), c->pair_off.ptr, c->pair_user.ptr,
-                 plain_tab(c->ctab.ptr, c->kp),
+                 plain_tab(c->ctab.at(c->base_slot), c->kp),
                  it ? static_cast<int32_t>(c->lay.pair_work.items.size()) : c->n_pairs, 0,
-                 it ? c->pair_items.ptr : nullptr, c->pair_parts.ptr};
+                 it ? c->pair_items.ptr : nullptr, c->pair_parts.at(c->base_slot),
+                 c->atab[0].stride, c->theta[0].stride, c->ctab.stride, c->pair_parts.stride};
 }
 SegArgs seg_users_args(const mmsbm_hip_ctx *c, bool commit, int seg_end) {  // theta_new
   const bool it = !c->lay.user_work.items.empty();
@@ -1091,28 +1141,39 @@ SegArgs seg_users_args(const mmsbm_hip_ctx *c, bool commit, int seg_end) {  // t
                  theta_tab(c, c->cur ^ 1),
                  it ? static_cast<int32_t>(c->lay.user_work.items.size()) : seg_end,
                  commit ? 1 : 2,
-                 it ? c->user_items.ptr : nullptr, c->user_parts.ptr};
+                 it ? c->user_items.ptr : nullptr, c->user_parts.at(c->base_slot),
+                 c->theta[0].stride, c->atab[0].stride, c->theta[0].stride, c->user_parts.stride};
 }
 PairBlockArgs pair_block_t_args(const mmsbm_hip_ctx *c) {
-  return PairBlockArgs{c->p[c->cur].ptr, c->ctab.ptr,        c->eta[c->cur].ptr, c->pair_item.ptr,
-                       c->mv_chunks.ptr, c->ttab.ptr,        c->partial.ptr,     c->k,
-                       c->kp,            c->lp,              c->pb_spb,          c->pb_nsub,
-                       c->ablate,        c->lp,              0};
+  const int s = c->base_slot;
+  return PairBlockArgs{c->p[c->cur].at(s), c->ctab.at(s),      c->eta[c->cur].at(s), c->pair_item.ptr,
+                       c->mv_chunks.ptr,   c->ttab.at(s),      c->partial.at(s),     c->k,
+                       c->kp,              c->lp,              c->pb_spb,            c->pb_nsub,
+                       c->ablate,          c->lp,              0,
+                       c->p[0].stride,     c->ctab.stride,     c->eta[0].stride,     c->ttab.stride,
+                       c->partial.stride};
 }
 PairBlockArgs pair_block_a_args(const mmsbm_hip_ctx *c, int param_slot, int a_slot) {
-  return PairBlockArgs{c->pt[param_slot].ptr, c->eta[param_slot].ptr, nullptr, c->pair_item.ptr,
-                       c->mv_chunks.ptr,      c->atab[a_slot].ptr,    nullptr, c->l,
-                       c->lp,                 c->kp,                  kBlock,  1,
-                       c->ablate,             a_tab(c, a_slot).mw,    a_tab(c, a_slot).tail_off};
+  const int s = c->base_slot;  // (param_slot / a_slot: ping-pong buffer indices)
+  return PairBlockArgs{c->pt[param_slot].at(s), c->eta[param_slot].at(s), nullptr, c->pair_item.ptr,
+                       c->mv_chunks.ptr,        c->atab[a_slot].at(s),    nullptr, c->l,
+                       c->lp,                   c->kp,                    kBlock,  1,
+                       c->ablate,               a_tab(c, a_slot).mw,      a_tab(c, a_slot).tail_off,
+                       c->pt[0].stride,         c->eta[0].stride,         0,       c->atab[0].stride,
+                       0};
 }
 EtaPArgs eta_p_args(const mmsbm_hip_ctx *c, bool commit, int cols_per_block) {
   const int cur = c->cur, nxt = cur ^ 1;
   EtaPArgs a;
-  a.partial = c->partial.ptr;
+  const int s = c->base_slot;
+  a.partial = c->partial.at(s);
   a.chunk_off = c->mv_chunk_off.ptr;
-  a.p_old = c->p[cur].ptr; a.p_new = c->p[nxt].ptr; a.pt_new = c->pt[nxt].ptr; a.npr = c->npr.ptr;
-  a.ttab = c->ttab.ptr; a.item_off = c->item_off.ptr; a.item_pairs = c->item_pairs.ptr;
-  a.item_deg = c->item_deg.ptr; a.eta = c->eta[cur].ptr; a.eta_new = c->eta[nxt].ptr;
+  a.p_old = c->p[cur].at(s); a.p_new = c->p[nxt].at(s); a.pt_new = c->pt[nxt].at(s);
+  a.npr = c->npr.at(s);
+  a.ttab = c->ttab.at(s); a.item_off = c->item_off.ptr; a.item_pairs = c->item_pairs.ptr;
+  a.item_deg = c->item_deg.ptr; a.eta = c->eta[cur].at(s); a.eta_new = c->eta[nxt].at(s);
+  a.bs_partial = c->partial.stride; a.bs_p = c->p[0].stride; a.bs_t = c->ttab.stride;
+  a.bs_eta = c->eta[0].stride;
   a.n_ratings = c->n_ratings; a.kp = c->kp; a.lp = c->lp; a.n_items = c->n_items;
   a.normalize = commit ? 1 : 0;
   a.nb_p = (c->kp * c->lp + cols_per_block - 1) / cols_per_block;
@@ -1127,7 +1188,7 @@ void stage_seg(mmsbm_hip_ctx *c, bool commit, bool with_users) {
   const int bu = with_users ? (su.nseg + per - 1) / per : 0;
   if (bp + bu > 0) {
 #define CALL(G, V) \
-  seg_pass_kernel<G, V, 4><<<bp + bu, kBlock, 0, c->stream>>>(sp, su, bp, c->kp)
+  seg_pass_kernel<G, V, 4><<<slot_grid(c, bp + bu), kBlock, 0, c->stream>>>(sp, su, bp, c->kp)
     DISPATCH_GV(c->code_k, CALL);
 #undef CALL
   }
@@ -1135,13 +1196,13 @@ void stage_seg(mmsbm_hip_ctx *c, bool commit, bool with_users) {
   const int nsp = static_cast<int>(c->lay.pair_work.splits.size());
   const int nsu = with_users ? static_cast<int>(c->lay.user_work.splits.size()) : 0;
   if (nsp + nsu > 0) {
-    const CombineArgs cp{c->pair_splits.ptr, c->pair_parts.ptr, c->pair_off.ptr, sp.fixed, sp.out, nsp,
-                         sp.mode};
-    const CombineArgs cu{c->user_splits.ptr, c->user_parts.ptr, c->user_off.ptr, su.fixed, su.out, nsu,
-                         su.mode};
+    const CombineArgs cp{c->pair_splits.ptr, sp.parts, c->pair_off.ptr, sp.fixed, sp.out, nsp,
+                         sp.mode, sp.bs_parts, sp.bs_fixed, sp.bs_out};
+    const CombineArgs cu{c->user_splits.ptr, su.parts, c->user_off.ptr, su.fixed, su.out, nsu,
+                         su.mode, su.bs_parts, su.bs_fixed, su.bs_out};
     const size_t lds = static_cast<size_t>(per) * c->kp * sizeof(double);
 #define CALL(G, V) \
-  seg_combine_kernel<G, V><<<nsp + nsu, kBlock, lds, c->stream>>>(cp, cu, nsp, c->kp)
+  seg_combine_kernel<G, V><<<slot_grid(c, nsp + nsu), kBlock, lds, c->stream>>>(cp, cu, nsp, c->kp)
     DISPATCH_GV(c->code_k, CALL);
 #undef CALL
   }
@@ -1158,7 +1219,7 @@ void stage_dense(mmsbm_hip_ctx *c) {  // T = P^T C  and the K x L slabs for p
 #define PB_KT(N, TL, NT, KT)                                                                \
   do {                                                                                      \
     allow_big_lds(pair_block_kernel<false, true, N, TL, NT, KT>, c->lds_t);                 \
-    pair_block_kernel<false, true, N, TL, NT, KT><<<nb, NT, c->lds_t, c->stream>>>(pa, pa.tiles); \
+    pair_block_kernel<false, true, N, TL, NT, KT><<<slot_grid(c, nb), NT, c->lds_t, c->stream>>>(pa, pa.tiles); \
   } while (0)
 #define PB_GO(N, TL, NT)                                                                    \
   do {                                                                                      \
@@ -1189,7 +1250,7 @@ void stage_eta_p(mmsbm_hip_ctx *c, bool commit) {  // eta_new ; p_new, pT_new, r
   const EtaPArgs a = eta_p_args(c, commit, kRedCols);
   const int per = kRedThreads / group_lanes(c->code_l);
   const int nb_i = (c->n_items + per - 1) / per;
-#define CALL(G, V) eta_p_kernel<G, V><<<a.nb_p + nb_i, kRedThreads, 0, c->stream>>>(a)
+#define CALL(G, V) eta_p_kernel<G, V><<<slot_grid(c, a.nb_p + nb_i), kRedThreads, 0, c->stream>>>(a)
   DISPATCH_GV(c->code_l, CALL);
 #undef CALL
   ls.done();
@@ -1205,7 +1266,7 @@ void stage_matvec_a(mmsbm_hip_ctx *c, int slot, int a_slot) {
 #define PA_GO(TL, NT)                                                                       \
   do {                                                                                      \
     allow_big_lds(pair_block_kernel<true, false, 1, TL, NT, 4>, c->lds_a);                  \
-    pair_block_kernel<true, false, 1, TL, NT, 4><<<nb, NT, c->lds_a, c->stream>>>(pa, pa.tiles); \
+    pair_block_kernel<true, false, 1, TL, NT, 4><<<slot_grid(c, nb), NT, c->lds_a, c->stream>>>(pa, pa.tiles); \
   } while (0)
     const bool tl = tile_in_lds(c->lp, c->kp), big = c->pb_threads_a > kBlock;
     if (tl && big) PA_GO(true, kPairBlockMax);
@@ -1258,9 +1319,49 @@ void run_iterations(mmsbm_hip_ctx *c, int n) {
   for (; n > 0; --n) launch_iteration(c, true);
 }
 
-void require_params(const mmsbm_hip_ctx *c) {
+void require_params(const mmsbm_hip_ctx *c) {  // the selected slot
   if (!c) throw std::invalid_argument("null context");
-  if (!c->have_params) throw std::invalid_argument("set_params has not been called");
+  if (!c->have[c->sel]) throw std::invalid_argument("set_params has not been called");
+}
+void require_all_params(const mmsbm_hip_ctx *c) {  // every slot: the iteration advances all of them
+  if (!c) throw std::invalid_argument("null context");
+  for (int s = 0; s < c->n_slots; ++s)
+    if (!c->have[s])
+      throw std::invalid_argument(c->n_slots == 1 ? std::string("set_params has not been called")
+                                                  : "set_params has not been called for slot " +
+                                                        std::to_string(s));
+}
+
+// (Re)allocate the per-restart state for `slots` parameter sets; nothing is kept.
+void alloc_state(mmsbm_hip_ctx *c, int slots) {
+  hipStream_t s = c->stream;
+  HIP_CHECK(hipStreamSynchronize(s));
+  c->drop_graphs();
+  const size_t klr = static_cast<size_t>(c->n_ratings) * c->kp * c->lp;
+  auto zeroed = [&](SlotBuf &b, size_t per_slot) {
+    b.alloc_slots(per_slot, slots);
+    HIP_CHECK(hipMemsetAsync(b.ptr, 0, sizeof(double) * std::max<size_t>(b.count, 1), s));
+  };
+  for (int b = 0; b < 2; ++b) {
+    zeroed(c->theta[b], static_cast<size_t>(c->n_users) * c->kp);
+    zeroed(c->eta[b], static_cast<size_t>(c->n_items) * c->lp);
+    zeroed(c->p[b], klr);
+    zeroed(c->pt[b], klr);
+    zeroed(c->atab[b], static_cast<size_t>(c->n_pairs) * c->kp);
+  }
+  c->ctab.alloc_slots(static_cast<size_t>(c->n_pairs) * c->kp, slots);
+  c->ttab.alloc_slots(static_cast<size_t>(c->n_pairs) * c->lp, slots);
+  c->partial.alloc_slots(c->lay.mv_chunks.size() * c->kp * c->lp, slots);
+  c->npr.alloc_slots(klr, slots);
+  c->pair_parts.alloc_slots(static_cast<size_t>(c->lay.pair_work.n_parts) * c->kp, slots);
+  c->user_parts.alloc_slots(static_cast<size_t>(c->lay.user_work.n_parts) * c->kp, slots);
+  HIP_CHECK(hipStreamSynchronize(s));
+  c->n_slots = slots;
+  c->sel = 0;
+  c->base_slot = 0;
+  c->launch_slots = slots;
+  c->cur = 0;
+  c->have.assign(static_cast<size_t>(slots), 0);
 }
 
 // host (rows, d) row-major  <->  device (rows, dp) zero-padded
@@ -1470,28 +1571,7 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
       tmp.assign(rating, rating + n_obs); c->orig_r.upload(tmp, s);
       HIP_CHECK(hipStreamSynchronize(s));
     }
-    const size_t klr = static_cast<size_t>(n_ratings) * c->kp * c->lp;
-    for (int b = 0; b < 2; ++b) {
-      c->theta[b].alloc(static_cast<size_t>(c->n_users) * c->kp);
-      c->eta[b].alloc(static_cast<size_t>(c->n_items) * c->lp);
-      c->p[b].alloc(klr);
-      c->pt[b].alloc(klr);
-      HIP_CHECK(hipMemsetAsync(c->theta[b].ptr, 0, sizeof(double) * c->theta[b].count, s));
-      HIP_CHECK(hipMemsetAsync(c->eta[b].ptr, 0, sizeof(double) * c->eta[b].count, s));
-      HIP_CHECK(hipMemsetAsync(c->p[b].ptr, 0, sizeof(double) * klr, s));
-      HIP_CHECK(hipMemsetAsync(c->pt[b].ptr, 0, sizeof(double) * klr, s));
-    }
-    for (int b = 0; b < 2; ++b) {
-      c->atab[b].alloc(static_cast<size_t>(c->n_pairs) * c->kp);
-      HIP_CHECK(hipMemsetAsync(c->atab[b].ptr, 0,
-                               sizeof(double) * std::max<size_t>(c->atab[b].count, 1), s));
-    }
-    c->ctab.alloc(static_cast<size_t>(c->n_pairs) * c->kp);
-    c->ttab.alloc(static_cast<size_t>(c->n_pairs) * c->lp);
-    c->partial.alloc(std::max<size_t>(c->lay.mv_chunks.size(), 1) * c->kp * c->lp);
-    c->npr.alloc(klr);
-    c->pair_parts.alloc(static_cast<size_t>(c->lay.pair_work.n_parts) * c->kp);
-    c->user_parts.alloc(static_cast<size_t>(c->lay.user_work.n_parts) * c->kp);
+    alloc_state(c.get(), 1);
     c->lik_part.alloc(4096);
     HIP_CHECK(hipStreamSynchronize(s));
     *out = c.release();
@@ -1535,20 +1615,21 @@ int mmsbm_hip_set_params(mmsbm_hip_ctx *ctx, const double *theta, const double *
   return guarded([&] {
     if (!ctx || !theta || !eta || !pr) throw std::invalid_argument("null argument");
     use_device(ctx);
+    OneSlot one(ctx);
     const double *it = ctx->swapped ? eta : theta;  // internal theta rows = internal users
     const double *ie = ctx->swapped ? theta : eta;
-    const int cur = ctx->cur;
+    const int cur = ctx->cur, sl = ctx->sel;
     upload_rows(ctx, theta_tab(ctx, cur), it, ctx->n_users, ctx->k);
-    upload_rows(ctx, plain_tab(ctx->eta[cur].ptr, ctx->lp), ie, ctx->n_items, ctx->l);
+    upload_rows(ctx, plain_tab(ctx->eta[cur].at(sl), ctx->lp), ie, ctx->n_items, ctx->l);
     std::vector<double> p, pt;
     p_host_to_dev(ctx, pr, p, pt);
-    HIP_CHECK(hipMemcpyAsync(ctx->p[cur].ptr, p.data(), sizeof(double) * p.size(),
+    HIP_CHECK(hipMemcpyAsync(ctx->p[cur].at(sl), p.data(), sizeof(double) * p.size(),
                              hipMemcpyHostToDevice, ctx->stream));
-    HIP_CHECK(hipMemcpyAsync(ctx->pt[cur].ptr, pt.data(), sizeof(double) * pt.size(),
+    HIP_CHECK(hipMemcpyAsync(ctx->pt[cur].at(sl), pt.data(), sizeof(double) * pt.size(),
                              hipMemcpyHostToDevice, ctx->stream));
     stage_matvec_a(ctx, cur, cur);
     HIP_CHECK(hipStreamSynchronize(ctx->stream));  // host staging vectors die here
-    ctx->have_params = true;
+    ctx->have[sl] = 1;
   });
 }
 
@@ -1556,15 +1637,16 @@ int mmsbm_hip_get_params(mmsbm_hip_ctx *ctx, double *theta, double *eta, double 
   return guarded([&] {
     require_params(ctx);
     use_device(ctx);
+    OneSlot one(ctx);
     double *it = ctx->swapped ? eta : theta;
     double *ie = ctx->swapped ? theta : eta;
-    const int cur = ctx->cur;
+    const int cur = ctx->cur, sl = ctx->sel;
     if (it) download_rows(ctx, it, theta_tab(ctx, cur), ctx->n_users, ctx->k);
-    if (ie) download_rows(ctx, ie, plain_tab(ctx->eta[cur].ptr, ctx->lp), ctx->n_items, ctx->l);
+    if (ie) download_rows(ctx, ie, plain_tab(ctx->eta[cur].at(sl), ctx->lp), ctx->n_items, ctx->l);
     std::vector<double> p;
     if (pr) {
-      p.resize(ctx->p[cur].count);
-      HIP_CHECK(hipMemcpyAsync(p.data(), ctx->p[cur].ptr, sizeof(double) * p.size(),
+      p.resize(static_cast<size_t>(ctx->n_ratings) * ctx->kp * ctx->lp);
+      HIP_CHECK(hipMemcpyAsync(p.data(), ctx->p[cur].at(sl), sizeof(double) * p.size(),
                                hipMemcpyDeviceToHost, ctx->stream));
     }
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -1572,9 +1654,56 @@ int mmsbm_hip_get_params(mmsbm_hip_ctx *ctx, double *theta, double *eta, double 
   });
 }
 
+int mmsbm_hip_set_slots(mmsbm_hip_ctx *ctx, int n_slots) {
+  return guarded([&] {
+    if (!ctx) throw std::invalid_argument("null context");
+    if (n_slots < 1 || n_slots > 65535) throw std::invalid_argument("n_slots must be in [1, 65535]");
+    use_device(ctx);
+    if (n_slots == ctx->n_slots) {
+      ctx->have.assign(static_cast<size_t>(n_slots), 0);
+      ctx->sel = 0;
+      return;
+    }
+    try {
+      alloc_state(ctx, n_slots);
+    } catch (...) {  // most likely out of device memory: leave a consistent one-slot context
+      (void)hipGetLastError();
+      try { alloc_state(ctx, 1); } catch (...) {}
+      throw;
+    }
+  });
+}
+
+int mmsbm_hip_select_slot(mmsbm_hip_ctx *ctx, int slot) {
+  return guarded([&] {
+    if (!ctx) throw std::invalid_argument("null context");
+    if (slot < 0 || slot >= ctx->n_slots)
+      throw std::invalid_argument("slot " + std::to_string(slot) + " out of range (the context has " +
+                                  std::to_string(ctx->n_slots) + ")");
+    ctx->sel = slot;
+  });
+}
+
+int mmsbm_hip_slots(const mmsbm_hip_ctx *ctx, int *n_slots, int *selected,
+                    int64_t *bytes_per_slot) {
+  return guarded([&] {
+    if (!ctx) throw std::invalid_argument("null context");
+    if (n_slots) *n_slots = ctx->n_slots;
+    if (selected) *selected = ctx->sel;
+    if (bytes_per_slot) {
+      size_t d = ctx->ctab.stride + ctx->ttab.stride + ctx->partial.stride + ctx->npr.stride +
+                 ctx->pair_parts.stride + ctx->user_parts.stride;
+      for (int b = 0; b < 2; ++b)
+        d += ctx->theta[b].stride + ctx->eta[b].stride + ctx->p[b].stride + ctx->pt[b].stride +
+             ctx->atab[b].stride;
+      *bytes_per_slot = static_cast<int64_t>(d * sizeof(double));
+    }
+  });
+}
+
 int mmsbm_hip_em_iterate(mmsbm_hip_ctx *ctx, int n_iters) {
   return guarded([&] {
-    require_params(ctx);
+    require_all_params(ctx);
     if (n_iters < 0) throw std::invalid_argument("n_iters must be >= 0");
     use_device(ctx);
     run_iterations(ctx, n_iters);
@@ -1594,16 +1723,17 @@ int mmsbm_hip_update_coefficients(mmsbm_hip_ctx *ctx, double *n_theta, double *n
   return guarded([&] {
     require_params(ctx);
     use_device(ctx);
+    OneSlot one(ctx);
     launch_iteration(ctx, false);
-    const int nxt = ctx->cur ^ 1;
+    const int nxt = ctx->cur ^ 1, sl = ctx->sel;
     double *it = ctx->swapped ? n_eta : n_theta;
     double *ie = ctx->swapped ? n_theta : n_eta;
     if (it) download_rows(ctx, it, theta_tab(ctx, nxt), ctx->n_users, ctx->k);
-    if (ie) download_rows(ctx, ie, plain_tab(ctx->eta[nxt].ptr, ctx->lp), ctx->n_items, ctx->l);
+    if (ie) download_rows(ctx, ie, plain_tab(ctx->eta[nxt].at(sl), ctx->lp), ctx->n_items, ctx->l);
     std::vector<double> p;
     if (n_pr) {
-      p.resize(ctx->npr.count);
-      HIP_CHECK(hipMemcpyAsync(p.data(), ctx->npr.ptr, sizeof(double) * p.size(),
+      p.resize(static_cast<size_t>(ctx->n_ratings) * ctx->kp * ctx->lp);
+      HIP_CHECK(hipMemcpyAsync(p.data(), ctx->npr.at(sl), sizeof(double) * p.size(),
                                hipMemcpyDeviceToHost, ctx->stream));
     }
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -1616,7 +1746,8 @@ int mmsbm_hip_likelihood(mmsbm_hip_ctx *ctx, double *out) {
     require_params(ctx);
     if (!out) throw std::invalid_argument("null out");
     use_device(ctx);
-    const int cur = ctx->cur;
+    OneSlot one(ctx);
+    const int cur = ctx->cur, sl = ctx->sel;
     int nb;
     const size_t lik_lds = static_cast<size_t>(ctx->kp + ctx->lp) * kLikThreads * sizeof(double);
     if (lik_lds <= kLdsBudget - 2048 && !ctx->lay.mv_chunks.empty()) {
@@ -1624,14 +1755,14 @@ int mmsbm_hip_likelihood(mmsbm_hip_ctx *ctx, double *out) {
       if (ctx->lik_part.count < static_cast<size_t>(nb)) ctx->lik_part.alloc(nb);
       likelihood_units_kernel<<<nb, kLikThreads, lik_lds, ctx->stream>>>(
           ctx->mv_chunks.ptr, ctx->pair_off.ptr, ctx->pair_user.ptr, ctx->pair_item.ptr,
-          theta_tab(ctx, cur), ctx->eta[cur].ptr, ctx->p[cur].ptr, ctx->lik_part.ptr, ctx->k, ctx->l,
-          ctx->kp, ctx->lp);
+          theta_tab(ctx, cur), ctx->eta[cur].at(sl), ctx->p[cur].at(sl), ctx->lik_part.ptr, ctx->k,
+          ctx->l, ctx->kp, ctx->lp);
     } else {
       nb = static_cast<int>(std::min<int64_t>((ctx->n_obs + kBlock - 1) / kBlock, 4096));
       nb = std::max(nb, 1);
       likelihood_kernel<<<nb, kBlock, 0, ctx->stream>>>(
           ctx->orig_u.ptr, ctx->orig_i.ptr, ctx->orig_r.ptr, theta_tab(ctx, cur),
-          ctx->eta[cur].ptr, ctx->p[cur].ptr, ctx->lik_part.ptr, ctx->n_obs, ctx->k, ctx->l,
+          ctx->eta[cur].at(sl), ctx->p[cur].at(sl), ctx->lik_part.ptr, ctx->n_obs, ctx->k, ctx->l,
           ctx->kp, ctx->lp);
     }
     HIP_CHECK(hipGetLastError());
@@ -1659,16 +1790,17 @@ int mmsbm_hip_compute_omegas(mmsbm_hip_ctx *ctx, double *out, int64_t capacity_e
     if (n_elems == 0) return;
     DevBuf<double> dev;
     dev.alloc(static_cast<size_t>(n_elems));
-    const int cur = ctx->cur;
+    OneSlot one(ctx);
+    const int cur = ctx->cur, sl = ctx->sel;
     // internal (k,l) -> external position: not swapped [k][l] strides (L,1); swapped the
     // external tensor is [l_int][k_int] so strides are (1, K_int)
     const int sk = ctx->swapped ? 1 : ctx->l;
-    const int sl = ctx->swapped ? ctx->k : 1;
+    const int sl_stride = ctx->swapped ? ctx->k : 1;
     const int64_t nb = (n_elems + kBlock - 1) / kBlock;
     omegas_kernel<<<static_cast<unsigned>(nb), kBlock, 0, ctx->stream>>>(
         ctx->orig_u.ptr, ctx->orig_i.ptr, ctx->orig_r.ptr, theta_tab(ctx, cur),
-        ctx->eta[cur].ptr, ctx->p[cur].ptr, dev.ptr, n_elems, ctx->k, ctx->l, ctx->kp, ctx->lp,
-        sk, sl);
+        ctx->eta[cur].at(sl), ctx->p[cur].at(sl), dev.ptr, n_elems, ctx->k, ctx->l, ctx->kp,
+        ctx->lp, sk, sl_stride);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipMemcpyAsync(out, dev.ptr, sizeof(double) * n_elems, hipMemcpyDeviceToHost,
                              ctx->stream));
@@ -1697,10 +1829,11 @@ int mmsbm_hip_prod_dist(mmsbm_hip_ctx *ctx, int64_t n_pairs, const int32_t *user
     const int32_t *ii = ctx->swapped ? user : item;
     HIP_CHECK(hipMemcpyAsync(du.ptr, iu, sizeof(int32_t) * n_pairs, hipMemcpyHostToDevice, ctx->stream));
     HIP_CHECK(hipMemcpyAsync(di.ptr, ii, sizeof(int32_t) * n_pairs, hipMemcpyHostToDevice, ctx->stream));
-    const int cur = ctx->cur;
+    OneSlot one(ctx);
+    const int cur = ctx->cur, sl = ctx->sel;
     const int64_t nb = (n_elems + kBlock - 1) / kBlock;
     prod_dist_kernel<<<static_cast<unsigned>(nb), kBlock, 0, ctx->stream>>>(
-        du.ptr, di.ptr, theta_tab(ctx, cur), ctx->eta[cur].ptr, ctx->p[cur].ptr, dout.ptr,
+        du.ptr, di.ptr, theta_tab(ctx, cur), ctx->eta[cur].at(sl), ctx->p[cur].at(sl), dout.ptr,
         n_pairs, ctx->n_ratings, ctx->k, ctx->l, ctx->kp, ctx->lp);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipMemcpyAsync(out, dout.ptr, sizeof(double) * n_elems, hipMemcpyDeviceToHost, ctx->stream));
@@ -1710,7 +1843,7 @@ int mmsbm_hip_prod_dist(mmsbm_hip_ctx *ctx, int64_t n_pairs, const int32_t *user
 
 int mmsbm_hip_time_iterations(mmsbm_hip_ctx *ctx, int n_iters, float *elapsed_ms) {
   return guarded([&] {
-    require_params(ctx);
+    require_all_params(ctx);
     if (!elapsed_ms || n_iters < 0) throw std::invalid_argument("bad argument");
     use_device(ctx);
     hipEvent_t e0, e1;
@@ -1735,7 +1868,7 @@ const char *mmsbm_hip_kernel_name(int index) {
 int mmsbm_hip_profile_iterations(mmsbm_hip_ctx *ctx, int n_iters, float *mean_us,
                                  int *launches_per_iter) {
   return guarded([&] {
-    require_params(ctx);
+    require_all_params(ctx);
     if (!mean_us || n_iters <= 0) throw std::invalid_argument("bad argument");
     use_device(ctx);
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -1776,14 +1909,14 @@ int mmsbm_hip_kernel_bytes(const mmsbm_hip_ctx *ctx, int index, int64_t *bytes_r
       case K_MATVEC_A: rd = Q * (8 * L + 4) + C * 8 * K * L; wr = Q * 8 * K; break;
       default: throw std::invalid_argument("kernel index out of range");
     }
-    *bytes_read = rd;
-    *bytes_written = wr;
+    *bytes_read = rd * ctx->n_slots;  // one launch covers every restart slot
+    *bytes_written = wr * ctx->n_slots;
   });
 }
 
 int mmsbm_hip_time_stage(mmsbm_hip_ctx *ctx, int stage, int reps, float *mean_us) {
   return guarded([&] {
-    require_params(ctx);
+    require_all_params(ctx);
     ctx->ablate = stage >> 8;  // bits 8.. : phases to skip (timing experiments only)
     stage &= 0xff;
     struct Reset { mmsbm_hip_ctx *c; ~Reset() { c->ablate = 0; } } reset{ctx};

@@ -2,13 +2,16 @@
 ``backend='hip'``: same constructor keywords, ``fit`` / ``predict`` / ``score`` / ``cv_fit``,
 ``results`` as a list of ``{"likelihood", "pr", "theta", "eta"}`` dicts in restart order.
 
-What differs from the reference is where things run: a restart is one ``HipEM`` context
-whose whole EM loop stays on the GPU (src/mmsbm.py:243-250 becomes one C-ABI call), and
-restarts are spread over GPUs -- threads over ``devices`` inside one process, or
-ranks of a ``torch.distributed`` job (mmsbm_amd/restarts.py) -- instead of a
-``multiprocessing.Pool`` (src/mmsbm.py:182-185).  Restart ``i`` is seeded exactly like the
-reference (``SeedSequence(seed).spawn(sampling)[i]``, draw order theta, eta, p), so it does
-not depend on ``sampling`` or on which GPU runs it.
+What differs from the reference is where things run: the whole EM loop of a restart stays on
+the GPU (src/mmsbm.py:243-250 becomes one C-ABI call), the restarts that share a GPU advance
+together as the slots of one ``HipEM`` context (one set of kernel launches per iteration
+for all of them: the batching the reference lists as a TODO, README.md:188), and restarts
+are spread over GPUs -- threads over ``devices`` inside one process, or ranks of a
+``torch.distributed`` job (mmsbm_amd/restarts.py) -- instead of a ``multiprocessing.Pool``
+(src/mmsbm.py:182-185).  Restart ``i`` is seeded exactly like the reference
+(``SeedSequence(seed).spawn(sampling)[i]``, draw order theta, eta, p) and slots never
+interact, so its result does not depend on ``sampling``, on the batch it ran in or on
+which GPU ran it.
 """
 from __future__ import annotations
 
@@ -43,7 +46,8 @@ class MMSBM:
     rng = None
 
     def __init__(self, user_groups, item_groups, iterations=400, sampling=1, seed=None,
-                 debug=False, backend="auto", devices=None, contexts_per_device=2):
+                 debug=False, backend="auto", devices=None, restarts_per_launch=8,
+                 contexts_per_device=1):
         self.start_time = datetime.now()
         self.user_groups = user_groups
         self.item_groups = item_groups
@@ -52,8 +56,11 @@ class MMSBM:
         self.debug = debug
         self.backend = backend
         self.devices = devices
-        # restarts sharing one GPU run on separate contexts/streams: their kernels interleave
-        # (the dense stage of one beside the gather pass of another), ~10 % more restarts/s
+        # Restarts that share a GPU run as slots of one context, up to this many per batch
+        # (C3: 1.2x the restarts/s of one at a time, C2: 3x, C1-sized problems: ~Sx).
+        self.restarts_per_launch = max(1, int(restarts_per_launch))
+        # More than one context (= stream) per GPU is possible too; slots do the same job
+        # better, so the default is one.
         self.contexts_per_device = max(1, int(contexts_per_device))
         # src/mmsbm.py:81-85
         self.rng = np.random.default_rng(seed)
@@ -113,18 +120,22 @@ class MMSBM:
         # workers = (GPU, context slot); restart j of `todo` goes to worker j mod #workers
         workers = [(d, s) for s in range(self.contexts_per_device) for d in self._device_list()]
         workers = workers[:max(1, len(todo))]
+
+        def work(w):  # this worker's restarts, in batches of slots
+            dev, slot = workers[w]
+            mine, out = todo[w::len(workers)], []
+            for b in range(0, len(mine), self.restarts_per_launch):
+                batch = mine[b:b + self.restarts_per_launch]
+                out.extend(zip(batch, self.run_samplings(batch, device=dev, slot=slot)))
+            return out
+
         if len(workers) == 1:
-            done = [self.run_one_sampling(train, self.child_states[i], i, device=workers[0][0])
-                    for i in todo]
+            parts = [work(0)]
         else:  # one host thread per worker; ctypes releases the GIL inside the library
-            def work(w):
-                dev, slot = workers[w]
-                return [(i, self.run_one_sampling(train, self.child_states[i], i, device=dev, slot=slot))
-                        for i in todo[w::len(workers)]]
             with ThreadPoolExecutor(max_workers=len(workers)) as pool:
                 parts = list(pool.map(work, range(len(workers))))
-            by_i = dict(x for part in parts for x in part)
-            done = [by_i[i] for i in todo]
+        by_i = dict(x for part in parts for x in part)
+        done = [by_i[i] for i in todo]
         self.results = done
         self._restart_ids = todo
         liks = [float(r["likelihood"]) for r in done]
@@ -140,23 +151,41 @@ class MMSBM:
         pr = normalize_with_self(rng.random((k, l, r)))
         return theta, eta, pr
 
-    def run_one_sampling(self, data, seed, i, device=0, slot=0):
-        """One restart, device resident (src/mmsbm.py:187-269)."""
+    def run_samplings(self, ids, device=0, slot=0, seeds=None):
+        """Restarts ``ids`` together, device resident, as the slots of one context
+        (src/mmsbm.py:187-269 for each of them).  Returns their result dicts in order."""
         ctx = self._ctx(device, slot)
+        ids = list(ids)
+        seeds = [self.child_states[i] for i in ids] if seeds is None else list(seeds)
+        if len(ids) > 1:
+            fit_in = ctx.max_slots(0.5)
+            if len(ids) > fit_in:  # memory: run what fits, then the rest
+                return (self.run_samplings(ids[:fit_in], device, slot, seeds[:fit_in]) +
+                        self.run_samplings(ids[fit_in:], device, slot, seeds[fit_in:]))
+        ctx.set_slots(len(ids))
         d_u, d_i = ctx.degrees()
-        ctx.set_params(*self.init_params(seed, d_u, d_i))
+        for s, seed in enumerate(seeds):
+            ctx.select(s).set_params(*self.init_params(seed, d_u, d_i))
         if self.debug:
             done = 0
             while done < self.iterations:  # likelihood every 50 iterations (src/mmsbm.py:252-254)
                 step = min(50, self.iterations - done)
                 ctx.iterate(step)
                 done += step
-                self.logger.debug(f"\nLikelihood at run {i} is {ctx.likelihood():.0f}")
+                for s, i in enumerate(ids):
+                    self.logger.debug(f"\nLikelihood at run {i} is {ctx.select(s).likelihood():.0f}")
         else:
             ctx.iterate(self.iterations)
-        likelihood = ctx.likelihood()
-        theta, eta, pr = ctx.get_params()
-        return {"likelihood": likelihood, "pr": pr, "theta": theta, "eta": eta}
+        out = []
+        for s in range(len(ids)):
+            likelihood = ctx.select(s).likelihood()
+            theta, eta, pr = ctx.get_params()
+            out.append({"likelihood": likelihood, "pr": pr, "theta": theta, "eta": eta})
+        return out
+
+    def run_one_sampling(self, data, seed, i, device=0, slot=0):
+        """One restart, device resident (src/mmsbm.py:187-269)."""
+        return self.run_samplings([i], device, slot, seeds=[seed])[0]
 
     # ------------------------------------------------------------------ prediction
     def _check_is_fitted(self):
@@ -175,6 +204,7 @@ class MMSBM:
         test = self.data_handler.transform(data, self.logger)
         self.test = test
         ctx = self._ctx(self._device_list()[0])
+        ctx.select(0)
         rats = []
         for a in self.results:
             ctx.set_params(a["theta"], a["eta"], a["pr"])
@@ -233,7 +263,7 @@ class MMSBM:
     def compute_likelihood(self, data, theta, eta, pr):
         """src/mmsbm.py:541-553 on explicit parameters (device evaluation)."""
         ctx = self._ctx(self._device_list()[0])
-        ctx.set_params(theta, eta, pr)
+        ctx.select(0).set_params(theta, eta, pr)
         return ctx.likelihood()
 
     # ------------------------------------------------------------------ cross-validation (src/mmsbm.py:371-472)

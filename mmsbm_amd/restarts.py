@@ -99,22 +99,22 @@ def fit_distributed(model, train, runner=None, gather=True, device=None):
 
     model  : an ``mmsbm_amd.MMSBM`` (only ``sampling`` / ``child_states`` are used when a
              ``runner`` is given).
-    runner : ``runner(i, child_seed) -> result dict``; default runs the restart on this
-             rank's GPU through ``model.run_one_sampling``.
+    runner : ``runner(i, child_seed) -> result dict``; default runs this rank's restarts on
+             its GPU through ``model.fit_encoded`` (batched as slots of one context).
     Returns (best index, best likelihood, likelihood vector); ``model.results`` holds all
     restarts (``gather``) or this rank's share.
     """
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     mine = shard_restarts(model.sampling, rank, world)
-    if runner is None:
+    if runner is None:  # this rank's restarts, batched as slots of one context on its GPU
         local_dev = device.index if (device is not None and device.type == "cuda") else 0
-        model._prepare_objects(train)
         check_single_hip_runtime()
-
-        def runner(i, seed):
-            return model.run_one_sampling(train, seed, i, device=local_dev)
-    local = {i: runner(i, model.child_states[i]) for i in mine}
+        model.devices = [local_dev]
+        model.fit_encoded(train, restarts=mine)
+        local = dict(zip(mine, model.results))
+    else:
+        local = {i: runner(i, model.child_states[i]) for i in mine}
     best, best_lik, liks = pick_max_likelihood({i: r["likelihood"] for i, r in local.items()},
                                                model.sampling, device)
     model.best_by_likelihood = best

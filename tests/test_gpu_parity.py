@@ -541,3 +541,107 @@ def test_degenerate_sizes(hip):
         d_u, d_i = np.array([1, 1, 1]), np.array([1, 1])
         for got, w in zip(em.get_params(), orc.em_step(one, theta, eta, pr, d_u, d_i)):
             assert np.allclose(got, w, rtol=1e-13, atol=0)
+
+
+def _slot_problem(skew):
+    rng = np.random.default_rng(5 if skew else 6)
+    n = 20000
+    if skew:  # long segments: work items + ordered combine, per slot
+        u = np.where(rng.random(n) < 0.3, 3, rng.integers(0, 1500, n))
+        i = np.where(rng.random(n) < 0.2, 1, rng.integers(0, 200, n))
+    else:
+        u, i = rng.integers(0, 3000, n), rng.integers(0, 400, n)
+    data = np.stack([u, i, rng.integers(0, 5, n)], axis=1).astype(np.int64)
+    data[:, 0] = np.unique(data[:, 0], return_inverse=True)[1]
+    data[:, 1] = np.unique(data[:, 1], return_inverse=True)[1]
+    return data, int(data[:, 0].max()) + 1, int(data[:, 1].max()) + 1, 5
+
+
+@pytest.mark.parametrize("skew,k,l", [(False, 20, 20), (True, 7, 13), (False, 50, 36)])
+def test_restart_slots_are_independent_and_bit_identical(hip, skew, k, l):
+    """N1 (README.md:188 TODO): S restarts advance in one set of launches.  Slot s must hold,
+    bit for bit, what a one-slot context gives for the same start -- and match the oracle."""
+    data, n_u, n_i, n_r = _slot_problem(skew)
+    d_u, d_i = orc.degrees(data, n_u, n_i)
+    starts = [orc.init_params(100 + s, n_u, n_i, n_r, k, l, d_u, d_i) for s in range(3)]
+    test = data[:500]
+    single = []
+    for st in starts:
+        with hip.HipEM(data, k, l, n_u, n_i, n_r) as em:
+            em.set_params(*st)
+            num = em.update_coefficients()
+            em.iterate(5)
+            single.append((num, em.get_params(), em.likelihood(), em.prod_dist(test)))
+    with hip.HipEM(data, k, l, n_u, n_i, n_r, slots=3) as em:
+        assert em.slots == 3 and em.selected == 0
+        for s in (2, 0, 1):  # any order
+            em.select(s).set_params(*starts[s])
+        for s in range(3):
+            for a, b in zip(em.select(s).update_coefficients(), single[s][0]):
+                assert np.array_equal(a, b)
+        em.iterate(3)
+        em.iterate(2)
+        for s in range(3):
+            em.select(s)
+            assert em.selected == s
+            for a, b in zip(em.get_params(), single[s][1]):
+                assert np.array_equal(a, b)
+            assert em.likelihood() == single[s][2]
+            assert np.array_equal(em.prod_dist(test), single[s][3])
+        # and against the oracle
+        t, e, p = starts[1]
+        for _ in range(5):
+            t, e, p = orc.em_step(data, t, e, p, d_u, d_i)
+        for got, w, nm in zip(em.select(1).get_params(), (t, e, p), ("theta", "eta", "pr")):
+            assert rel_err(got, w) < 1e-11, nm
+        # shrinking back to one slot gives a fresh, working context
+        em.set_slots(1)
+        em.set_params(*starts[0])
+        em.iterate(5)
+        for a, b in zip(em.get_params(), single[0][1]):
+            assert np.array_equal(a, b)
+
+
+def test_restart_slot_errors(hip):
+    from mmsbm_amd import _lib
+    data, n_u, n_i, n_r = _slot_problem(False)
+    d_u, d_i = orc.degrees(data, n_u, n_i)
+    st = orc.init_params(1, n_u, n_i, n_r, 4, 4, d_u, d_i)
+    with hip.HipEM(data, 4, 4, n_u, n_i, n_r, slots=2) as em:
+        em.set_params(*st)
+        with pytest.raises(_lib.HipLibraryError) as e:
+            em.iterate(1)  # slot 1 has no parameters yet
+        assert e.value.code == _lib.E_INVALID and "slot 1" in e.value.message
+        with pytest.raises(_lib.HipLibraryError):
+            em.select(1).likelihood()
+        for bad in (-1, 2):
+            with pytest.raises(_lib.HipLibraryError) as e:
+                em.select(bad)
+            assert e.value.code == _lib.E_INVALID
+        with pytest.raises(_lib.HipLibraryError):
+            em.set_slots(0)
+        em.select(1).set_params(*st)
+        em.iterate(2)
+        a, b = em.select(0).get_params(), em.select(1).get_params()
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def test_host_class_batches_restarts_without_changing_them(hip):
+    """fit() runs the restarts of a GPU as slots of one context; batch size must not matter."""
+    g = load_golden("g4_2k_k10")
+    runs = {}
+    for per in (1, 2, 5):
+        mm = hip.MMSBM(10, 10, iterations=12, sampling=5, seed=3, restarts_per_launch=per)
+        mm.fit_encoded(g["train"])
+        runs[per] = mm.results
+        assert mm.best_by_likelihood == int(np.argmax([r["likelihood"] for r in mm.results]))
+        mm._release()
+    for per in (2, 5):
+        for a, b in zip(runs[1], runs[per]):
+            assert a["likelihood"] == b["likelihood"]
+            for key in ("theta", "eta", "pr"):
+                assert np.array_equal(a[key], b[key])
+    want = orc.fit(g["train"], 10, 10, 12, 5, 3)
+    for got, w in zip(runs[5], want):
+        assert abs(got["likelihood"] - w["likelihood"]) < 1e-9 * abs(w["likelihood"])
+        assert rel_err(got["theta"], w["theta"]) < TOL_LOOP
