@@ -121,6 +121,26 @@ int mmsbm_hip_compute_omegas(mmsbm_hip_ctx *ctx, double *out, int64_t capacity_e
 int mmsbm_hip_prod_dist(mmsbm_hip_ctx *ctx, int64_t n_pairs, const int32_t *user,
                         const int32_t *item, double *out);
 
+/* ---- predict / score on the device: src/mmsbm.py:297-315 and 488-539 ------------------ */
+/* A session over n_rows test triples (ids as in create(); rating = the true rating index;
+ * rating_weights: R doubles, the values the reference multiplies the distribution with --
+ * its `self.ratings`, src/mmsbm.py:95,518):
+ *   begin  uploads the rows;
+ *   add    evaluates prod_dist for the SELECTED slot's current parameters, adds it to the
+ *          running sum over restarts (in call order, which is numpy's order for
+ *          np.array(rats).mean(axis=0)) and returns that restart's indicators;
+ *   finish divides by the number of adds, returns the mean distribution (n_rows x R, may be
+ *          NULL) and ITS indicators, and closes the session.
+ * stats[6] = { rows kept (distribution not all zero), argmax == real, |argmax - real| <= 1,
+ *              sum |argmax - real|, real == round(P . w), sum |P . w - real| }, from which
+ * accuracy = [1]/[0], one_off = [2]/[0], mae = 1 - [4]/[0], s2 = [3], s2pond = [5]
+ * (src/mmsbm.py:530-539).  Counts are exact; argmax takes the first maximum like np.argmax. */
+int mmsbm_hip_predict_begin(mmsbm_hip_ctx *ctx, int64_t n_rows, const int32_t *user,
+                            const int32_t *item, const int32_t *rating,
+                            const double *rating_weights);
+int mmsbm_hip_predict_add(mmsbm_hip_ctx *ctx, double stats[6]);
+int mmsbm_hip_predict_finish(mmsbm_hip_ctx *ctx, double *mean_dist, double stats[6]);
+
 /* ---- measurement ------------------------------------------------------------------ */
 /* Runs n_iters EM iterations bracketed by HIP events on the context's stream; returns
  * the elapsed device time of the whole region in milliseconds (synchronises). */

@@ -39,6 +39,9 @@ SIGNATURES = {
     "mmsbm_hip_likelihood": (C.c_int, [C.c_void_p, c_f64p]),
     "mmsbm_hip_compute_omegas": (C.c_int, [C.c_void_p, c_f64p, C.c_int64]),
     "mmsbm_hip_prod_dist": (C.c_int, [C.c_void_p, C.c_int64, c_i32p, c_i32p, c_f64p]),
+    "mmsbm_hip_predict_begin": (C.c_int, [C.c_void_p, C.c_int64, c_i32p, c_i32p, c_i32p, c_f64p]),
+    "mmsbm_hip_predict_add": (C.c_int, [C.c_void_p, c_f64p]),
+    "mmsbm_hip_predict_finish": (C.c_int, [C.c_void_p, c_f64p, c_f64p]),
     "mmsbm_hip_time_iterations": (C.c_int, [C.c_void_p, C.c_int, c_f32p]),
     "mmsbm_hip_kernel_count": (C.c_int, []),
     "mmsbm_hip_kernel_name": (C.c_char_p, [C.c_int]),

@@ -168,6 +168,41 @@ class HipEM:
                   _p(out, C.c_double))
         return out
 
+    # -- predict / score on the device (src/mmsbm.py:297-315, 488-539) ----------------------
+    STAT_NAMES = ("rows", "true", "almost", "s2", "true_pond", "s2pond")
+
+    @staticmethod
+    def final_stats(raw):
+        """The reference's five scores (src/mmsbm.py:530-539) from the six device sums."""
+        n = raw[0]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            return {"accuracy": np.float64(raw[1]) / n, "one_off_accuracy": np.float64(raw[2]) / n,
+                    "mae": 1 - np.float64(raw[4]) / n, "s2": np.int64(raw[3]), "s2pond": np.float64(raw[5])}
+
+    def predict_begin(self, test, rating_weights):
+        """Open a scoring session over (M,3) test triples [user, item, true rating index]."""
+        u, i, r = split_triples(test)
+        w = _f64(rating_weights)
+        if w.shape != (self.n_ratings,):
+            raise ValueError(f"rating_weights has shape {w.shape}, expected ({self.n_ratings},)")
+        self._ps_rows = len(u)
+        _lib.call("mmsbm_hip_predict_begin", self._h, len(u), _p(u, C.c_int32), _p(i, C.c_int32),
+                  _p(r, C.c_int32), _p(w, C.c_double))
+
+    def predict_add(self):
+        """Add the selected slot's rating distribution to the session; its six raw sums."""
+        st = np.zeros(6, dtype=np.float64)
+        _lib.call("mmsbm_hip_predict_add", self._h, _p(st, C.c_double))
+        return st
+
+    def predict_finish(self, want_matrix=True):
+        """(mean distribution (M,R) or None, six raw sums of the mean); closes the session."""
+        st = np.zeros(6, dtype=np.float64)
+        out = np.empty((self._ps_rows, self.n_ratings), dtype=np.float64) if want_matrix else None
+        _lib.call("mmsbm_hip_predict_finish", self._h,
+                  _p(out, C.c_double) if want_matrix else None, _p(st, C.c_double))
+        return out, st
+
     # -- measurement -------------------------------------------------------------------------
     def time_iterations(self, n_iters):
         """Device milliseconds for n_iters EM iterations (HIP events on the context stream)."""

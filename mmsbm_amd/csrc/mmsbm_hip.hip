@@ -873,6 +873,21 @@ __global__ __launch_bounds__(kLikThreads) void likelihood_units_kernel(
   if (tid == 0) block_out[blockIdx.x] = red[0];
 }
 
+// P[m,r] = sum_kl theta[u,k] eta[i,l] p[k,l,r] for one (row, rating): src/kernels_numpy.py:94-96.
+__device__ __forceinline__ double prod_dist_elem(const RowTab &theta, size_t urow,
+                                                 const double *__restrict__ et,
+                                                 const double *__restrict__ pr, int k_groups,
+                                                 int l_groups, int lp) {
+  double acc = 0.0;
+  for (int k = 0; k < k_groups; ++k) {
+    const double tk = *rowtab_ptr(theta, urow, k);
+    double inner = 0.0;
+    for (int l = 0; l < l_groups; ++l) inner = fma(et[l], pr[k * lp + l], inner);
+    acc = fma(tk, inner, acc);
+  }
+  return acc;
+}
+
 // src/kernels_numpy.py:86-96.  One thread per (pair, rating).
 __global__ __launch_bounds__(kBlock) void prod_dist_kernel(
     const int32_t *__restrict__ pu, const int32_t *__restrict__ pi,
@@ -886,14 +901,78 @@ __global__ __launch_bounds__(kBlock) void prod_dist_kernel(
   const size_t urow = static_cast<size_t>(pu[m]);
   const double *et = eta + static_cast<size_t>(pi[m]) * lp;
   const double *pr = p + static_cast<size_t>(r) * kp * lp;
-  double acc = 0.0;
-  for (int k = 0; k < k_groups; ++k) {
-    const double tk = *rowtab_ptr(theta, urow, k);
-    double inner = 0.0;
-    for (int l = 0; l < l_groups; ++l) inner = fma(et[l], pr[k * lp + l], inner);
-    acc = fma(tk, inner, acc);
+  out[e] = prod_dist_elem(theta, urow, et, pr, k_groups, l_groups, lp);
+}
+
+// ======================================================================================
+// predict / score on the device (src/mmsbm.py:297-315 and 488-539): the rating distribution
+// of every test row for ONE restart is added into a running sum (restart order = call order,
+// the order numpy's mean over the restart axis adds in) and reduced on the spot to the
+// reference's indicators, so only six numbers per restart travel back:
+//   [0] rows kept (distribution not all zero)   [1] argmax == real   [2] |argmax - real| <= 1
+//   [3] sum |argmax - real|   [4] real == round(P . w)   [5] sum |P . w - real|
+// One thread per test row; fixed-order tree per workgroup, workgroup sums added by the host in
+// block order.  FINISH: the distribution is the running sum divided by the number of restarts
+// (written back in place), nothing new is computed.
+// ======================================================================================
+constexpr int kScoreStats = 6;
+
+template <bool FINISH>
+__global__ __launch_bounds__(kBlock) void predict_score_kernel(
+    const int32_t *__restrict__ pu, const int32_t *__restrict__ pi, const int32_t *__restrict__ preal,
+    RowTab theta, const double *__restrict__ eta, const double *__restrict__ p,
+    const double *__restrict__ weights, double *__restrict__ sum, double *__restrict__ block_out,
+    int64_t n_rows, int n_ratings, int k_groups, int l_groups, int kp, int lp, int first,
+    double n_added) {
+  __shared__ double red[kScoreStats][kBlock];
+  const int64_t m = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  double st[kScoreStats];
+#pragma unroll
+  for (int j = 0; j < kScoreStats; ++j) st[j] = 0.0;
+  if (m < n_rows) {
+    const size_t urow = static_cast<size_t>(FINISH ? 0 : pu[m]);
+    const double *et = FINISH ? nullptr : eta + static_cast<size_t>(pi[m]) * lp;
+    double *srow = sum + m * n_ratings;
+    int best = 0;
+    double bestv = 0.0, tot = 0.0, pond = 0.0;
+    for (int r = 0; r < n_ratings; ++r) {
+      double v;
+      if (FINISH) {
+        v = srow[r] / n_added;
+        srow[r] = v;
+      } else {
+        v = prod_dist_elem(theta, urow, et, p + static_cast<size_t>(r) * kp * lp, k_groups, l_groups, lp);
+        srow[r] = first ? v : srow[r] + v;
+      }
+      if (r == 0 || v > bestv) {  // np.argmax: the first maximum
+        bestv = v;
+        best = r;
+      }
+      tot += v;
+      pond += v * weights[r];
+    }
+    if (tot != 0.0) {  // src/mmsbm.py:505-510: rows whose distribution is all zero are dropped
+      const int real = preal[m];
+      const int dist = abs(best - real);
+      st[0] = 1.0;
+      st[1] = dist == 0 ? 1.0 : 0.0;
+      st[2] = dist <= 1 ? 1.0 : 0.0;
+      st[3] = static_cast<double>(dist);
+      st[4] = (static_cast<double>(real) == rint(pond)) ? 1.0 : 0.0;  // np.round: half to even
+      st[5] = fabs(pond - static_cast<double>(real));
+    }
   }
-  out[e] = acc;
+#pragma unroll
+  for (int j = 0; j < kScoreStats; ++j) red[j][threadIdx.x] = st[j];
+  __syncthreads();
+  for (int h = kBlock / 2; h > 0; h >>= 1) {
+    if (static_cast<int>(threadIdx.x) < h) {
+#pragma unroll
+      for (int j = 0; j < kScoreStats; ++j) red[j][threadIdx.x] += red[j][threadIdx.x + h];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < kScoreStats) block_out[blockIdx.x * kScoreStats + threadIdx.x] = red[threadIdx.x][0];
 }
 
 // src/kernels_numpy.py:21-36.  One thread per element; sk/sl = output strides of the
@@ -1024,6 +1103,11 @@ struct mmsbm_hip_ctx {
   SlotBuf pair_parts, user_parts;
   SlotBuf theta[2], eta[2], p[2], pt[2], atab[2], ctab, ttab, partial, npr;
   DevBuf<double> lik_part;
+  // predict/score session (mmsbm_hip_predict_begin .. finish)
+  DevBuf<int32_t> ps_u, ps_i, ps_r;
+  DevBuf<double> ps_sum, ps_w, ps_part;
+  int64_t ps_rows = -1;  // -1: no session open
+  int ps_added = 0;
   int cur = 0;
   std::vector<char> have;  // per slot: set_params has been called
   bool graph_mode = false;  // replay a captured two-iteration hipGraph instead of eager launches
@@ -1838,6 +1922,101 @@ int mmsbm_hip_prod_dist(mmsbm_hip_ctx *ctx, int64_t n_pairs, const int32_t *user
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipMemcpyAsync(out, dout.ptr, sizeof(double) * n_elems, hipMemcpyDeviceToHost, ctx->stream));
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  });
+}
+
+namespace {
+void score_launch(mmsbm_hip_ctx *ctx, bool finish, double *stats) {
+  const int64_t nb64 = (ctx->ps_rows + kBlock - 1) / kBlock;
+  const int nb = static_cast<int>(nb64);
+  if (ctx->ps_part.count < static_cast<size_t>(nb) * kScoreStats) ctx->ps_part.alloc(static_cast<size_t>(nb) * kScoreStats);
+  const int cur = ctx->cur, sl = ctx->sel;
+  if (nb > 0) {
+    if (finish)
+      predict_score_kernel<true><<<nb, kBlock, 0, ctx->stream>>>(
+          ctx->ps_u.ptr, ctx->ps_i.ptr, ctx->ps_r.ptr, theta_tab(ctx, cur), ctx->eta[cur].at(sl),
+          ctx->p[cur].at(sl), ctx->ps_w.ptr, ctx->ps_sum.ptr, ctx->ps_part.ptr, ctx->ps_rows,
+          ctx->n_ratings, ctx->k, ctx->l, ctx->kp, ctx->lp, 0, static_cast<double>(ctx->ps_added));
+    else
+      predict_score_kernel<false><<<nb, kBlock, 0, ctx->stream>>>(
+          ctx->ps_u.ptr, ctx->ps_i.ptr, ctx->ps_r.ptr, theta_tab(ctx, cur), ctx->eta[cur].at(sl),
+          ctx->p[cur].at(sl), ctx->ps_w.ptr, ctx->ps_sum.ptr, ctx->ps_part.ptr, ctx->ps_rows,
+          ctx->n_ratings, ctx->k, ctx->l, ctx->kp, ctx->lp, ctx->ps_added == 0 ? 1 : 0, 1.0);
+    HIP_CHECK(hipGetLastError());
+  }
+  std::vector<double> part(static_cast<size_t>(nb) * kScoreStats);
+  if (nb > 0)
+    HIP_CHECK(hipMemcpyAsync(part.data(), ctx->ps_part.ptr, sizeof(double) * part.size(),
+                             hipMemcpyDeviceToHost, ctx->stream));
+  HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  for (int j = 0; j < kScoreStats; ++j) stats[j] = 0.0;
+  for (int b = 0; b < nb; ++b)
+    for (int j = 0; j < kScoreStats; ++j) stats[j] += part[static_cast<size_t>(b) * kScoreStats + j];
+}
+}  // namespace
+
+int mmsbm_hip_predict_begin(mmsbm_hip_ctx *ctx, int64_t n_rows, const int32_t *user,
+                            const int32_t *item, const int32_t *rating,
+                            const double *rating_weights) {
+  return guarded([&] {
+    if (!ctx) throw std::invalid_argument("null context");
+    if (n_rows < 0) throw std::invalid_argument("negative n_rows");
+    if (!rating_weights || (n_rows > 0 && (!user || !item || !rating)))
+      throw std::invalid_argument("null argument");
+    if (n_rows > (int64_t(1) << 31) - kBlock)
+      throw ApiError(MMSBM_E_TOOLARGE, "predict: too many rows for one launch");
+    for (int64_t m = 0; m < n_rows; ++m)
+      if (user[m] < 0 || user[m] >= ctx->ext_users || item[m] < 0 || item[m] >= ctx->ext_items ||
+          rating[m] < 0 || rating[m] >= ctx->n_ratings)
+        throw std::invalid_argument("predict: id out of range at row " + std::to_string(m));
+    use_device(ctx);  // (arguments are fine: from here on the previous session is gone)
+    ctx->ps_rows = -1;
+    const int32_t *iu = ctx->swapped ? item : user;
+    const int32_t *ii = ctx->swapped ? user : item;
+    hipStream_t s = ctx->stream;
+    ctx->ps_u.alloc(n_rows); ctx->ps_i.alloc(n_rows); ctx->ps_r.alloc(n_rows);
+    ctx->ps_sum.alloc(static_cast<size_t>(n_rows) * ctx->n_ratings);
+    ctx->ps_w.alloc(ctx->n_ratings);
+    if (n_rows > 0) {
+      HIP_CHECK(hipMemcpyAsync(ctx->ps_u.ptr, iu, sizeof(int32_t) * n_rows, hipMemcpyHostToDevice, s));
+      HIP_CHECK(hipMemcpyAsync(ctx->ps_i.ptr, ii, sizeof(int32_t) * n_rows, hipMemcpyHostToDevice, s));
+      HIP_CHECK(hipMemcpyAsync(ctx->ps_r.ptr, rating, sizeof(int32_t) * n_rows, hipMemcpyHostToDevice, s));
+    }
+    HIP_CHECK(hipMemcpyAsync(ctx->ps_w.ptr, rating_weights, sizeof(double) * ctx->n_ratings,
+                             hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipStreamSynchronize(s));  // the caller's buffers are free again
+    ctx->ps_rows = n_rows;
+    ctx->ps_added = 0;
+  });
+}
+
+int mmsbm_hip_predict_add(mmsbm_hip_ctx *ctx, double stats[6]) {
+  return guarded([&] {
+    require_params(ctx);
+    if (!stats) throw std::invalid_argument("null stats");
+    if (ctx->ps_rows < 0) throw std::invalid_argument("predict_begin has not been called");
+    use_device(ctx);
+    OneSlot one(ctx);
+    score_launch(ctx, false, stats);
+    ctx->ps_added++;
+  });
+}
+
+int mmsbm_hip_predict_finish(mmsbm_hip_ctx *ctx, double *mean_dist, double stats[6]) {
+  return guarded([&] {
+    if (!ctx || !stats) throw std::invalid_argument("null argument");
+    if (ctx->ps_rows < 0) throw std::invalid_argument("predict_begin has not been called");
+    if (ctx->ps_added < 1) throw std::invalid_argument("predict_finish before any predict_add");
+    use_device(ctx);
+    OneSlot one(ctx);
+    const int64_t rows = ctx->ps_rows;
+    score_launch(ctx, true, stats);
+    ctx->ps_rows = -1;  // the session is over whatever happens next
+    if (mean_dist && rows > 0) {
+      HIP_CHECK(hipMemcpyAsync(mean_dist, ctx->ps_sum.ptr, sizeof(double) * rows * ctx->n_ratings,
+                               hipMemcpyDeviceToHost, ctx->stream));
+      HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    }
   });
 }
 

@@ -69,6 +69,8 @@ class MMSBM:
         self._backend = None  # resolved in _prepare_objects, like the reference (EM ctor)
         self.best_by_likelihood = None
         self._ctxs = {}
+        self._resident = {}      # (device, context) -> restart ids whose final parameters sit in its slots
+        self._scored = None      # (prediction matrix, raw device sums) of the last predict()
 
     # ------------------------------------------------------------------ preparation
     def _prepare_objects(self, train):
@@ -103,6 +105,7 @@ class MMSBM:
         for ctx in self._ctxs.values():
             ctx.close()
         self._ctxs = {}
+        self._resident = {}
 
     # ------------------------------------------------------------------ training
     def fit(self, data, silent=False):
@@ -181,6 +184,7 @@ class MMSBM:
             likelihood = ctx.select(s).likelihood()
             theta, eta, pr = ctx.get_params()
             out.append({"likelihood": likelihood, "pr": pr, "theta": theta, "eta": eta})
+        self._resident[(device, slot)] = ids
         return out
 
     def run_one_sampling(self, data, seed, i, device=0, slot=0):
@@ -197,27 +201,42 @@ class MMSBM:
 
     def predict(self, data):
         """Mean of prod_dist over restarts; stored objects from the run with the best test
-        accuracy (src/mmsbm.py:279-317)."""
+        accuracy (src/mmsbm.py:279-317).  Everything per test row -- the distributions, their
+        running sum over restarts, argmax and the indicators of src/mmsbm.py:488-528 -- is
+        evaluated on the device; per restart only six sums come back."""
         self._check_is_fitted()
         import pandas as pd
 
         test = self.data_handler.transform(data, self.logger)
         self.test = test
-        ctx = self._ctx(self._device_list()[0])
-        ctx.select(0)
-        rats = []
-        for a in self.results:
-            ctx.set_params(a["theta"], a["eta"], a["pr"])
-            rats.append(ctx.prod_dist(test))
+        dev = self._device_list()[0]
+        ctx = self._ctx(dev)
+        # restarts whose final parameters still sit in this context's slots need no upload
+        resident = self._resident.get((dev, 0)) == list(self._restart_ids) and ctx.slots == len(self.results)
+        if not resident:
+            ctx.set_slots(1)
+            self._resident.pop((dev, 0), None)
+        ctx.predict_begin(test, np.asarray(self.ratings, dtype=np.float64))
+        per_run = []
+        for j, a in enumerate(self.results):
+            if resident:
+                ctx.select(j)
+            else:
+                ctx.set_params(a["theta"], a["eta"], a["pr"])
+            per_run.append(ctx.predict_add())
+        matrix, raw = ctx.predict_finish()
+        self.run_stats = [ctx.final_stats(st) for st in per_run]
         likelihoods = np.array([a["likelihood"] for a in self.results])
-        best = self.choose_best_run(rats)
+        accuracies = [st["accuracy"] for st in self.run_stats]
+        best = accuracies.index(max(accuracies))  # src/mmsbm.py:474-478
         enc = self.data_handler
         res = self.results[best]
         self.theta = pd.DataFrame(res["theta"], index=enc.user_labels())
         self.eta = pd.DataFrame(res["eta"], index=enc.item_labels())
         self.pr = {lab: pd.DataFrame(res["pr"][:, :, j]) for j, lab in enumerate(enc.rating_labels())}
         self.likelihood = likelihoods[best]
-        self.prediction_matrix = np.array(rats).mean(axis=0)
+        self.prediction_matrix = matrix
+        self._scored = (matrix, raw)
         return self.prediction_matrix
 
     def choose_best_run(self, rats):
@@ -227,7 +246,10 @@ class MMSBM:
     # ------------------------------------------------------------------ scoring (src/mmsbm.py:319-369,488-539)
     def score(self, silent=False):
         self._check_has_predictions()
-        stats = self._compute_stats(self.prediction_matrix)
+        if self._scored is not None and self._scored[0] is self.prediction_matrix:
+            stats = HipEM.final_stats(self._scored[1])  # reduced on the device by predict()
+        else:  # a matrix the caller supplied
+            stats = self._compute_stats(self.prediction_matrix)
         stats["likelihood"] = self.likelihood
         if not silent:
             self.logger.info(
@@ -262,7 +284,9 @@ class MMSBM:
 
     def compute_likelihood(self, data, theta, eta, pr):
         """src/mmsbm.py:541-553 on explicit parameters (device evaluation)."""
-        ctx = self._ctx(self._device_list()[0])
+        dev = self._device_list()[0]
+        ctx = self._ctx(dev)
+        self._resident.pop((dev, 0), None)  # slot 0 is overwritten
         ctx.select(0).set_params(theta, eta, pr)
         return ctx.likelihood()
 

@@ -645,3 +645,102 @@ def test_host_class_batches_restarts_without_changing_them(hip):
     for got, w in zip(runs[5], want):
         assert abs(got["likelihood"] - w["likelihood"]) < 1e-9 * abs(w["likelihood"])
         assert rel_err(got["theta"], w["theta"]) < TOL_LOOP
+
+
+def _score_problem():
+    rng = np.random.default_rng(11)
+    n_u, n_i, n_r, k, l = 300, 120, 5, 6, 9
+    data = np.stack([rng.integers(0, n_u, 6000), rng.integers(0, n_i, 6000),
+                     rng.integers(0, n_r, 6000)], axis=1).astype(np.int64)
+    d_u, d_i = orc.degrees(data, n_u, n_i)
+    test = np.stack([rng.integers(0, n_u, 3001), rng.integers(0, n_i, 3001),
+                     rng.integers(0, n_r, 3001)], axis=1).astype(np.int64)
+    return data, test, (n_u, n_i, n_r, k, l), d_u, d_i
+
+
+@pytest.mark.parametrize("swap", [0, 1])
+def test_device_predict_score_matches_host_formulas(hip, swap):
+    """N2: prod_dist for every restart, mean over restarts, argmax and the indicators of
+    src/mmsbm.py:488-539 evaluated on the device."""
+    data, test, (n_u, n_i, n_r, k, l), d_u, d_i = _score_problem()
+    weights = np.arange(n_r, dtype=np.float64)  # the reference's self.ratings (rating indices)
+    with hip.HipEM(data, k, l, n_u, n_i, n_r, slots=3, swap_sides=swap) as em:
+        for s in range(3):
+            em.select(s).set_params(*orc.init_params(40 + s, n_u, n_i, n_r, k, l, d_u, d_i))
+        em.iterate(6)
+        # a user with an all-zero membership row: its test rows have an all-zero distribution
+        t, e, p = em.select(2).get_params()
+        t[test[0, 0]] = 0.0
+        em.set_params(t, e, p)
+        rats = [em.select(s).prod_dist(test) for s in range(3)]
+        assert (rats[2].sum(1) == 0).any()
+        em.predict_begin(test, weights)
+        per = [em.select(s).predict_add() for s in range(3)]
+        mean, raw = em.predict_finish()
+    assert np.array_equal(mean, np.array(rats).mean(axis=0))  # numpy adds the restarts in order too
+    for rat, st in list(zip(rats, per)) + [(mean, raw)]:
+        want = orc.score_stats(rat, test[:, 2], list(range(n_r)))
+        got = hip.HipEM.final_stats(st)
+        assert st[0] == (rat.sum(1) != 0).sum()
+        for key in ("accuracy", "one_off_accuracy", "mae"):
+            assert got[key] == want[key], key
+        assert got["s2"] == want["s2"]
+        assert abs(got["s2pond"] - want["s2pond"]) <= 1e-12 * want["s2pond"]
+
+
+def test_device_predict_session_errors(hip):
+    from mmsbm_amd import _lib
+    data, test, (n_u, n_i, n_r, k, l), d_u, d_i = _score_problem()
+    with hip.HipEM(data, k, l, n_u, n_i, n_r) as em:
+        em.set_params(*orc.init_params(1, n_u, n_i, n_r, k, l, d_u, d_i))
+        with pytest.raises(_lib.HipLibraryError) as e:
+            em.predict_add()
+        assert e.value.code == _lib.E_INVALID and "predict_begin" in e.value.message
+        em.predict_begin(test, np.arange(n_r))
+        with pytest.raises(_lib.HipLibraryError):
+            em.predict_finish()                      # nothing added yet
+        bad = test.copy()
+        bad[5, 2] = n_r
+        with pytest.raises(_lib.HipLibraryError) as e:
+            em.predict_begin(bad, np.arange(n_r))
+        assert e.value.code == _lib.E_INVALID
+        st = em.predict_add()                        # a rejected begin leaves the open session alone
+        assert st[0] == len(test)
+        with pytest.raises(ValueError):
+            em.predict_begin(test, np.arange(n_r + 1))
+        em.predict_begin(test[:0], np.arange(n_r))   # empty test set
+        st = em.predict_add()
+        mean, raw = em.predict_finish()
+        assert mean.shape == (0, n_r) and not st.any() and not raw.any()
+
+
+def test_host_predict_uses_resident_slots_or_uploads(hip):
+    """predict() after fit() reads the restarts straight from the context's slots; after the
+    slots were reused (or with results from elsewhere) it uploads -- same answer either way."""
+    import pandas as pd
+    rng = np.random.default_rng(3)
+    df = pd.DataFrame({"u": rng.integers(0, 60, 1500), "i": rng.integers(0, 40, 1500),
+                       "r": rng.integers(1, 6, 1500)})
+    test = df.iloc[:400]
+    mm = hip.MMSBM(3, 4, iterations=15, sampling=4, seed=2)
+    mm.fit(df.iloc[400:], silent=True)
+    assert mm._resident[(0, 0)] == [0, 1, 2, 3]
+    a = mm.predict(test).copy()
+    sa = mm.score(silent=True)["stats"]
+    mm.compute_likelihood(mm.train, mm.results[0]["theta"], mm.results[0]["eta"], mm.results[0]["pr"])
+    assert (0, 0) not in mm._resident
+    b = mm.predict(test)
+    sb = mm.score(silent=True)["stats"]
+    assert np.array_equal(a, b) and sa == sb
+    rats = []
+    ctx = mm._ctx(0)
+    for res in mm.results:
+        ctx.set_params(res["theta"], res["eta"], res["pr"])
+        rats.append(ctx.prod_dist(mm.test))
+    assert np.array_equal(a, np.array(rats).mean(axis=0))
+    host = mm._compute_stats(a)                      # the host-side formulas on the same matrix
+    for key in ("accuracy", "one_off_accuracy", "mae", "s2"):
+        assert sa[key] == host[key], key
+    assert abs(sa["s2pond"] - host["s2pond"]) < 1e-12 * host["s2pond"]
+    accs = [mm._compute_stats(r)["accuracy"] for r in rats]
+    assert [s["accuracy"] for s in mm.run_stats] == accs
