@@ -47,7 +47,7 @@ class MMSBM:
 
     def __init__(self, user_groups, item_groups, iterations=400, sampling=1, seed=None,
                  debug=False, backend="auto", devices=None, restarts_per_launch=8,
-                 contexts_per_device=1):
+                 contexts_per_device=1, tol=None, check_every=50):
         self.start_time = datetime.now()
         self.user_groups = user_groups
         self.item_groups = item_groups
@@ -62,6 +62,13 @@ class MMSBM:
         # More than one context (= stream) per GPU is possible too; slots do the same job
         # better, so the default is one.
         self.contexts_per_device = max(1, int(contexts_per_device))
+        # Convergence monitor (not in the reference, off by default): every `check_every`
+        # iterations the likelihood of each restart of the batch is evaluated -- the reference's
+        # debug hook, src/mmsbm.py:252-254 -- and with `tol` set the batch stops early once every
+        # restart's relative change is below it.  `iterations_run[i]` records what restart i got.
+        self.tol = tol
+        self.check_every = max(1, int(check_every))
+        self.iterations_run = {}
         # src/mmsbm.py:81-85
         self.rng = np.random.default_rng(seed)
         self.child_states = self.rng.bit_generator._seed_seq.spawn(sampling)
@@ -169,16 +176,27 @@ class MMSBM:
         d_u, d_i = ctx.degrees()
         for s, seed in enumerate(seeds):
             ctx.select(s).set_params(*self.init_params(seed, d_u, d_i))
-        if self.debug:
-            done = 0
-            while done < self.iterations:  # likelihood every 50 iterations (src/mmsbm.py:252-254)
-                step = min(50, self.iterations - done)
+        done = 0
+        if self.debug or self.tol is not None:
+            every = 50 if self.tol is None else self.check_every  # src/mmsbm.py:252-254: every 50
+            last = None
+            while done < self.iterations:
+                step = min(every, self.iterations - done)
                 ctx.iterate(step)
                 done += step
-                for s, i in enumerate(ids):
-                    self.logger.debug(f"\nLikelihood at run {i} is {ctx.select(s).likelihood():.0f}")
+                liks = np.array([ctx.select(s).likelihood() for s in range(len(ids))])
+                if self.debug:
+                    for i, lik in zip(ids, liks):
+                        self.logger.debug(f"\nLikelihood at run {i} is {lik:.0f}")
+                if self.tol is not None and last is not None and np.all(
+                        np.abs(liks - last) <= self.tol * np.abs(last)):
+                    break
+                last = liks
         else:
             ctx.iterate(self.iterations)
+            done = self.iterations
+        for i in ids:
+            self.iterations_run[i] = done
         out = []
         for s in range(len(ids)):
             likelihood = ctx.select(s).likelihood()
@@ -292,15 +310,18 @@ class MMSBM:
 
     # ------------------------------------------------------------------ cross-validation (src/mmsbm.py:371-472)
     def cv_fit(self, data, folds=5):
+        """src/mmsbm.py:371-472.  The fold splits are drawn first, in the reference's order (the
+        model's RNG is used for nothing else), so the folds are independent jobs: with several
+        entries in ``devices`` they run concurrently, one fold per entry at a time (an entry may
+        repeat a GPU), each fold's restarts batched on its GPU."""
         n_items = len(set(data.iloc[:, 1]))
         assert folds <= n_items, (
             f"Fold number can't be higher than {n_items} since this is the number of different "
             f"items you have.")
         per_fold = int(n_items / folds)
         temp = data
-        all_results = []
+        splits = []
         for f in range(folds):
-            self.logger.info(f"Running fold {f + 1} of {folds}...")
             picked = []
             for _, grp in temp.groupby(temp.columns[0]):
                 for cnt in range(per_fold, 0, -1):  # as many as the user has, at most per_fold
@@ -309,19 +330,50 @@ class MMSBM:
                         break
             picked = [a for a in picked if str(a) != "0"]
             test = temp.loc[picked, :]
-            train = data[~data.index.isin(test.index)]
+            splits.append((data[~data.index.isin(test.index)], test))
             temp = temp[~temp.index.isin(picked)]
-            self.fit(train, silent=True)
-            self.prediction_matrix = self.predict(test)
-            results = self.score(silent=True)
-            all_results.append({"stats": results["stats"],
-                                "objects": {"theta": self.theta, "eta": self.eta, "pr": self.pr,
-                                            "rat": self.prediction_matrix}})
+
+        def run_fold(model, f):
+            self.logger.info(f"Running fold {f + 1} of {folds}...")
+            train, test = splits[f]
+            model.fit(train, silent=True)
+            model.prediction_matrix = model.predict(test)
+            results = model.score(silent=True)
+            return {"stats": results["stats"],
+                    "objects": {"theta": model.theta, "eta": model.eta, "pr": model.pr,
+                                "rat": model.prediction_matrix}}
+
+        lanes = [int(d) for d in self.devices] if self.devices is not None else [0]
+        if len(lanes) == 1 or folds == 1:
+            all_results = [run_fold(self, f) for f in range(folds)]
+        else:
+            def lane(j):  # folds j, j + lanes, ... on GPU lanes[j], through a private model
+                child = self._fold_model(lanes[j])
+                try:
+                    return [(f, run_fold(child, f)) for f in range(j, folds, len(lanes))]
+                finally:
+                    child._release()
+            with ThreadPoolExecutor(max_workers=len(lanes)) as pool:
+                parts = list(pool.map(lane, range(min(len(lanes), folds))))
+            by_f = dict(x for part in parts for x in part)
+            all_results = [by_f[f] for f in range(folds)]
         accuracies = [a["stats"]["accuracy"] for a in all_results]
         best = accuracies.index(max(accuracies))
         self.theta = all_results[best]["objects"]["theta"]
         self.eta = all_results[best]["objects"]["eta"]
         self.pr = all_results[best]["objects"]["pr"]
         self.prediction_matrix = all_results[best]["objects"]["rat"]
+        self.cv_results = all_results
         self.logger.info(f"Ran {folds} folds with accuracies {accuracies}.")
         return accuracies
+
+    def _fold_model(self, device):
+        """A model with this one's settings and restart seeds, bound to one GPU."""
+        child = MMSBM(self.user_groups, self.item_groups, iterations=self.iterations,
+                      sampling=self.sampling, debug=self.debug, backend=self.backend,
+                      devices=[device], restarts_per_launch=self.restarts_per_launch,
+                      contexts_per_device=self.contexts_per_device, tol=self.tol,
+                      check_every=self.check_every)
+        child.child_states = self.child_states  # every fold restarts from the same seeds (src/mmsbm.py:441)
+        child.logger = self.logger
+        return child

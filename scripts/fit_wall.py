@@ -24,3 +24,10 @@ print(f"encode {t1-t0:.3f}s  context(sort+upload) {t2-t1:.3f}s  init rng {t3-t2:
 t0 = time.perf_counter(); mm2 = MMSBM(k, l, iterations=iters, sampling=1, seed=0); mm2.fit(df, silent=True); t1 = time.perf_counter()
 pm = mm2.predict(df.iloc[:100000]); t2 = time.perf_counter()
 print(f"fit() total {t1-t0:.3f}s   predict(100k rows) {t2-t1:.3f}s  accuracy {mm2.score(silent=True)['stats']['accuracy']:.4f}")
+for samp in (8,):
+    t0 = time.perf_counter(); mm3 = MMSBM(k, l, iterations=iters, sampling=samp, seed=0); mm3.fit(df, silent=True); t1 = time.perf_counter()
+    pm = mm3.predict(df.iloc[:100000]); t2 = time.perf_counter()
+    print(f"sampling={samp}: fit() {t1-t0:.3f}s   predict(100k rows, {samp} restarts) {t2-t1:.3f}s  "
+          f"accuracy {mm3.score(silent=True)['stats']['accuracy']:.4f}")
+    t0 = time.perf_counter(); mm4 = MMSBM(k, l, iterations=iters, sampling=samp, seed=0, restarts_per_launch=1); mm4.fit(df, silent=True); t1 = time.perf_counter()
+    print(f"sampling={samp}, one restart at a time: fit() {t1-t0:.3f}s")

@@ -331,22 +331,24 @@ def test_c5_shape_small(hip):
         assert em.likelihood() == pytest.approx(float(orc.compute_likelihood(data, theta, eta, pr)), rel=1e-11)
 
 
-@pytest.mark.parametrize("opt", [{"graph": 1}])
-def test_launch_modes_give_identical_results(hip, opt):
-    """hipGraph replay changes scheduling only: bitwise-identical output."""
+@pytest.mark.parametrize("slots", [1, 3])
+def test_launch_modes_give_identical_results(hip, slots):
+    """hipGraph replay changes scheduling only: bitwise-identical output (with restart slots too)."""
     g = load_golden("g4_2k_k10")
     outs = []
     for use in (False, True):
         with make_ctx(hip, g["train"], g["theta_0"], g["eta_0"], g["pr_0"]) as em:
+            if slots > 1:
+                em.set_slots(slots)
+                for s in range(slots):
+                    em.select(s).set_params(g["theta_0"] * (1 + 0.01 * s), g["eta_0"], g["pr_0"])
             if use:
-                if "graph" in opt:
-                    em.set_graph_mode(1)
-                if "rolefuse" in opt:
-                    em.set_option("rolefuse", 1)
+                em.set_graph_mode(1)
             em.iterate(7)
-            outs.append(em.get_params())
-    for a, b in zip(*outs):
-        assert np.array_equal(a, b)
+            outs.append([em.select(s).get_params() for s in range(slots)])
+    for ra, rb in zip(*outs):
+        for a, b in zip(ra, rb):
+            assert np.array_equal(a, b)
 
 
 def test_cv_fit_matches_reference(hip):
@@ -744,3 +746,39 @@ def test_host_predict_uses_resident_slots_or_uploads(hip):
     assert abs(sa["s2pond"] - host["s2pond"]) < 1e-12 * host["s2pond"]
     accs = [mm._compute_stats(r)["accuracy"] for r in rats]
     assert [s["accuracy"] for s in mm.run_stats] == accs
+
+
+def test_cv_folds_run_concurrently_with_the_same_result(hip):
+    """N4: with several entries in `devices` the folds are independent jobs on separate contexts
+    (here two lanes on the one GPU); accuracies and the kept objects equal the sequential run."""
+    import pandas as pd
+    g = load_golden("g6_cv_fit")
+    df = pd.DataFrame({"users": g["raw_users"], "items": g["raw_items"], "ratings": g["raw_ratings"]})
+    seq = hip.MMSBM(2, 2, iterations=10, sampling=2, seed=1)
+    acc_seq = seq.cv_fit(df, folds=3)
+    par = hip.MMSBM(2, 2, iterations=10, sampling=2, seed=1, devices=[0, 0])
+    acc_par = par.cv_fit(df, folds=3)
+    assert acc_seq == acc_par
+    assert np.array_equal(seq.prediction_matrix, par.prediction_matrix)
+    assert seq.theta.equals(par.theta) and seq.eta.equals(par.eta)
+    for a, b in zip(seq.cv_results, par.cv_results):
+        assert a["stats"] == b["stats"]
+
+
+def test_convergence_monitor_stops_early_and_matches_fixed_length_run(hip):
+    """`tol` stops a batch once every restart's likelihood moved by less than tol (relative)
+    between two checks; what it ran is exactly the fixed-length run of that many iterations."""
+    g = load_golden("g4_2k_k10")
+    mm = hip.MMSBM(10, 10, iterations=4000, sampling=2, seed=3, tol=1e-4, check_every=25)
+    mm.fit_encoded(g["train"])
+    ran = mm.iterations_run[0]
+    assert ran == mm.iterations_run[1] and 50 <= ran < 4000 and ran % 25 == 0
+    ref = hip.MMSBM(10, 10, iterations=ran, sampling=2, seed=3)
+    ref.fit_encoded(g["train"])
+    assert ref.iterations_run == {0: ran, 1: ran}
+    for a, b in zip(mm.results, ref.results):
+        assert a["likelihood"] == b["likelihood"] and np.array_equal(a["theta"], b["theta"])
+    shorter = hip.MMSBM(10, 10, iterations=ran - 25, sampling=2, seed=3)
+    shorter.fit_encoded(g["train"])
+    for a, b in zip(mm.results, shorter.results):  # the stopping rule, checked from outside
+        assert abs(a["likelihood"] - b["likelihood"]) <= 1e-4 * abs(b["likelihood"])
