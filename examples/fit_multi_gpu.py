@@ -26,8 +26,13 @@ def main():
     ap.add_argument("--iterations", type=int, default=400)
     ap.add_argument("--ratings", type=int, default=1_000_000)
     ap.add_argument("--groups", type=int, default=20)
+    ap.add_argument("--dist-backend", default=None, help="default nccl (= RCCL)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal on a one-GPU box: every rank uses GPU 0 (with --dist-backend gloo)")
     args = ap.parse_args()
-    rank, world, local, device = restarts.init_from_env()
+    if args.share_gpu:
+        os.environ["LOCAL_RANK"] = "0"
+    rank, world, local, device = restarts.init_from_env(args.dist_backend)
     train = synthetic_triples(args.ratings, args.ratings // 10, args.ratings // 50, 5, seed=0)
     model = MMSBM(args.groups, args.groups, iterations=args.iterations, sampling=args.sampling, seed=0)
     best, best_lik, liks = restarts.fit_distributed(model, train, device=device)
