@@ -347,7 +347,7 @@ struct PairBlockArgs {
   size_t bs_tiles, bs_in, bs_e, bs_out, bs_partial;  // restart slots (blockIdx.y): table strides
 };
 
-template <bool GATHER, bool DO_S, int NACC, bool TLDS, int NT, int KT>
+template <bool GATHER, bool DO_S, int NACC, bool TLDS, int NT, int KT, bool DIRECT>
 __device__ __forceinline__ void pair_block_body(const PairBlockArgs &pa,
                                                 const double *__restrict__ tiles0, int block) {
   const size_t slot = blockIdx.y;
@@ -479,7 +479,7 @@ __device__ __forceinline__ void pair_block_body(const PairBlockArgs &pa,
           }
         }
       }
-      __syncthreads();  // es is dead: its space becomes tout
+      if (!DIRECT) __syncthreads();  // es is dead: its space becomes tout
     }
     // ---- mat-vec: lane = pair, wave = output chunk ------------------------------------------
     // (readfirstlane: tell the compiler the wave index is uniform so the tile loads scalarise)
@@ -512,9 +512,20 @@ __device__ __forceinline__ void pair_block_body(const PairBlockArgs &pa,
       }
       double2 w0, w1;
       w0.x = a0; w0.y = a1; w1.x = a2; w1.y = a3;
-      *reinterpret_cast<double2 *>(tout + lane * doutp + c * 4) = w0;
-      *reinterpret_cast<double2 *>(tout + lane * doutp + c * 4 + 2) = w1;
+      if (DIRECT) {  // each lane stores its 32 bytes of row q0 + lane straight from registers
+        if (lane < np && !(abl & 16)) {
+          const int j = c * 4, mw = pa.out_mw;
+          double *dst = j < mw ? out + static_cast<size_t>(q0 + lane) * mw + j
+                               : out + pa.out_tail_off + static_cast<size_t>(q0 + lane) * (doutp - mw) + (j - mw);
+          *reinterpret_cast<double2 *>(dst) = w0;
+          *reinterpret_cast<double2 *>(dst + 2) = w1;
+        }
+      } else {
+        *reinterpret_cast<double2 *>(tout + lane * doutp + c * 4) = w0;
+        *reinterpret_cast<double2 *>(tout + lane * doutp + c * 4 + 2) = w1;
+      }
     }
+    if (DIRECT) continue;
     __syncthreads();
     if (!(abl & 16)) {  // the unit's 64 output rows are contiguous in memory: flat coalesced copy
       const int total = np * doutp;
@@ -571,10 +582,10 @@ __device__ __forceinline__ void pair_block_body(const PairBlockArgs &pa,
 
 constexpr int kPairBlockMax = 512;
 
-template <bool GATHER, bool DO_S, int NACC, bool TLDS, int NT, int KT>
+template <bool GATHER, bool DO_S, int NACC, bool TLDS, int NT, int KT, bool DIRECT>
 __global__ __launch_bounds__(NT) void pair_block_kernel(PairBlockArgs pa,
                                                         const double *__restrict__ tiles) {
-  pair_block_body<GATHER, DO_S, NACC, TLDS, NT, KT>(pa, tiles, blockIdx.x);
+  pair_block_body<GATHER, DO_S, NACC, TLDS, NT, KT, DIRECT>(pa, tiles, blockIdx.x);
 }
 
 // ======================================================================================
@@ -1083,6 +1094,7 @@ struct mmsbm_hip_ctx {
   int n_users = 0, n_items = 0, n_ratings = 0, k = 0, l = 0, kp = 0, lp = 0;
   int n_pairs = 0, n_chunks = 0;
   int code_k = 0, code_l = 0;
+  bool direct_out = false;  // pair_block: output rows stored straight from registers (no LDS transpose)
   int ablate = 0;           // tuning aid (mmsbm_hip_time_stage): phases pair_block skips
   bool split_rows = false;  // theta and A kept as 128-byte main lines + tail rows (RowTab)
   int pb_threads_t = kBlock, pb_threads_a = kBlock;  // pair_block workgroup sizes (T+S mode, A mode)
@@ -1300,10 +1312,14 @@ void stage_dense(mmsbm_hip_ctx *c) {  // T = P^T C  and the K x L slabs for p
     LaunchScope ls(c, K_DENSE);
     const int nb = static_cast<int>(c->lay.mv_chunks.size());
     const PairBlockArgs pa = pair_block_t_args(c);
+#define PB_D(N, TL, NT, KT, D)                                                              \
+  do {                                                                                      \
+    allow_big_lds(pair_block_kernel<false, true, N, TL, NT, KT, D>, c->lds_t);              \
+    pair_block_kernel<false, true, N, TL, NT, KT, D><<<slot_grid(c, nb), NT, c->lds_t, c->stream>>>(pa, pa.tiles); \
+  } while (0)
 #define PB_KT(N, TL, NT, KT)                                                                \
   do {                                                                                      \
-    allow_big_lds(pair_block_kernel<false, true, N, TL, NT, KT>, c->lds_t);                 \
-    pair_block_kernel<false, true, N, TL, NT, KT><<<slot_grid(c, nb), NT, c->lds_t, c->stream>>>(pa, pa.tiles); \
+    if (c->direct_out) PB_D(N, TL, NT, KT, true); else PB_D(N, TL, NT, KT, false);          \
   } while (0)
 #define PB_GO(N, TL, NT)                                                                    \
   do {                                                                                      \
@@ -1325,6 +1341,7 @@ void stage_dense(mmsbm_hip_ctx *c) {  // T = P^T C  and the K x L slabs for p
 #undef PB
 #undef PB_GO
 #undef PB_KT
+#undef PB_D
     ls.done();
   }
 }
@@ -1347,10 +1364,14 @@ void stage_matvec_a(mmsbm_hip_ctx *c, int slot, int a_slot) {
   {
     const int nb = static_cast<int>(c->lay.mv_chunks.size());
     const PairBlockArgs pa = pair_block_a_args(c, slot, a_slot);
+#define PA_D(TL, NT, D)                                                                     \
+  do {                                                                                      \
+    allow_big_lds(pair_block_kernel<true, false, 1, TL, NT, 4, D>, c->lds_a);               \
+    pair_block_kernel<true, false, 1, TL, NT, 4, D><<<slot_grid(c, nb), NT, c->lds_a, c->stream>>>(pa, pa.tiles); \
+  } while (0)
 #define PA_GO(TL, NT)                                                                       \
   do {                                                                                      \
-    allow_big_lds(pair_block_kernel<true, false, 1, TL, NT, 4>, c->lds_a);                  \
-    pair_block_kernel<true, false, 1, TL, NT, 4><<<slot_grid(c, nb), NT, c->lds_a, c->stream>>>(pa, pa.tiles); \
+    if (c->direct_out) PA_D(TL, NT, true); else PA_D(TL, NT, false);                        \
   } while (0)
     const bool tl = tile_in_lds(c->lp, c->kp), big = c->pb_threads_a > kBlock;
     if (tl && big) PA_GO(true, kPairBlockMax);
@@ -1358,6 +1379,7 @@ void stage_matvec_a(mmsbm_hip_ctx *c, int slot, int a_slot) {
     else if (big) PA_GO(false, kPairBlockMax);
     else PA_GO(false, kBlock);
 #undef PA_GO
+#undef PA_D
   }
   ls.done();
 }
@@ -1626,6 +1648,10 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
     mmsbm::build_layout(n_obs, c->n_users, c->n_items, n_ratings, iu, ii, rating, 512, c->lay);
     // big K x L tiles: four 64-pair units per pair_block workgroup (4x fewer slabs to write + add)
     if (c->kp * c->lp > 1024) mmsbm::build_mv_chunks(c->lay, 4 * mmsbm::kMvChunkPairs);
+    // long rows: the mat-vec's outputs go to memory straight from registers (C5: -6 % on both
+    // pair_block launches); short rows are cheaper transposed through LDS and copied out flat
+    // (C3: direct stores cost +1.1 / +1.7 us)
+    c->direct_out = c->kp * c->lp > 1024;
     c->n_pairs = c->lay.n_pairs;
     c->n_chunks = static_cast<int>(c->lay.mv_chunks.size());
 
@@ -2132,6 +2158,8 @@ int mmsbm_hip_set_option(mmsbm_hip_ctx *ctx, const char *name, double value) {
     const std::string key(name);
     if (key == "graph") {
       ctx->graph_mode = value != 0.0;
+    } else if (key == "direct") {
+      ctx->direct_out = value != 0.0;
     } else {
       throw std::invalid_argument("unknown option: " + key);
     }
