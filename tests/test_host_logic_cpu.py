@@ -1,0 +1,140 @@
+"""The host class's orchestration on CPU: ``MMSBM`` driven through a stand-in device that runs
+the oracle (tests/fake_device.py), pinned to the outputs of the real reference
+(tests/golden).  Covers what the GPU suite covers for the host logic -- restart batching over
+slots, residency of the fitted restarts, predict/score flow, fold lanes, the convergence
+monitor -- so that it is checked on every CPU run too."""
+import numpy as np
+import pandas as pd
+import pytest
+
+import fake_device
+from conftest import load_golden
+from mmsbm_amd import mmsbm as host
+
+
+@pytest.fixture()
+def fake(monkeypatch):
+    monkeypatch.setattr(host, "HipEM", fake_device.FakeHipEM)
+    monkeypatch.setattr(host, "load_backend", lambda name: (None, None, None, "hip"))
+    monkeypatch.setattr(fake_device.FakeHipEM, "MAX_SLOTS", 1 << 20, raising=False)
+    fake_device.LOG.clear()
+    return fake_device
+
+
+def _frame(g, prefix):
+    return pd.DataFrame({"users": g[prefix + "_users"], "items": g[prefix + "_items"],
+                         "ratings": g[prefix + "_ratings"]})
+
+
+def test_fit_predict_score_reproduce_the_reference_end_to_end_case(fake):
+    """tests/test_mmsbm.py:53-102 of the reference, through this package's host class."""
+    g = load_golden("g1_c1_mock")
+    mm = host.MMSBM(2, 2, iterations=10, seed=1, backend="hip")
+    mm.fit(_frame(g, "train_raw"), silent=True)
+    res = mm.results[0]
+    for nm in ("theta", "eta", "pr"):
+        assert np.array_equal(res[nm], g[f"t_{nm}"]), nm      # oracle underneath: bit exact
+    assert float(res["likelihood"]) == -13.773187406968459
+    pm = mm.predict(_frame(g, "test_raw"))
+    assert np.array_equal(pm, g["t_prediction_matrix"])
+    sc = mm.score(silent=True)["stats"]
+    want = dict(zip(g["t_stats_keys"].tolist(), g["t_stats_vals"].tolist()))
+    for key in ("accuracy", "one_off_accuracy", "mae", "s2", "s2pond", "likelihood"):
+        assert sc[key] == pytest.approx(want[key], rel=1e-12), key
+    assert ("predict_add", 0) in fake.LOG and ("set_params", 0) in fake.LOG
+    # the restart was still resident in the context: predict() did not upload it again
+    assert [e for e in fake.LOG if e[0] == "set_params"] == [("set_params", 0)]
+    # a matrix supplied by the caller is scored with the host formulas
+    mm.prediction_matrix = pm.copy()
+    again = mm.score(silent=True)["stats"]
+    assert all(again[k] == pytest.approx(sc[k], rel=1e-12) for k in sc)
+
+
+def test_restarts_are_batched_over_slots_without_changing_them(fake):
+    g = load_golden("g2_c1_sampling3")
+    runs = {}
+    for per in (1, 2, 8):
+        fake.LOG.clear()
+        mm = host.MMSBM(2, 2, iterations=10, sampling=3, seed=1, restarts_per_launch=per)
+        mm.fit_encoded(g["train"])
+        runs[per] = mm.results
+        sizes = [e[1] for e in fake.LOG if e[0] == "set_slots"][1:]   # [0] is the constructor's
+        assert sizes == {1: [1, 1, 1], 2: [2, 1], 8: [3]}[per]
+        assert [e[1] for e in fake.LOG if e[0] == "iterate"] == [10] * len(sizes)
+        assert mm.iterations_run == {0: 10, 1: 10, 2: 10}
+        liks = np.array([r["likelihood"] for r in mm.results])
+        assert np.array_equal(liks, g["likelihoods"])            # the reference's sampling=3 run
+        assert mm.best_by_likelihood == int(np.argmax(g["likelihoods"]))
+        for s in range(3):
+            assert np.array_equal(mm.results[s]["theta"], g[f"theta_{s}"])
+    # a device with room for two slots only: the batch of three is split, results unchanged
+    fake.FakeHipEM.MAX_SLOTS = 2
+    fake.LOG.clear()
+    mm = host.MMSBM(2, 2, iterations=10, sampling=3, seed=1)
+    mm.fit_encoded(g["train"])
+    assert [e[1] for e in fake.LOG if e[0] == "set_slots"][1:] == [2, 1]
+    assert all(np.array_equal(a["theta"], b["theta"]) for a, b in zip(mm.results, runs[8]))
+    # ... and predict() then uploads (only restart 2 is still resident), same matrix either way
+    test = g["train"][:40]
+    mm.data_handler = type("Id", (), {"transform": staticmethod(lambda d, log: d),
+                                       "user_labels": lambda s: list(range(mm.p + 1)),
+                                       "item_labels": lambda s: list(range(mm.m + 1)),
+                                       "rating_labels": lambda s: [str(x) for x in mm.ratings]})()
+    fake.LOG.clear()
+    pm = mm.predict(test)
+    assert [e for e in fake.LOG if e[0] == "set_params"] == [("set_params", 0)] * 3
+    from oracle import mmsbm_oracle as orc
+    rats = [orc.prod_dist(test, r["theta"], r["eta"], r["pr"]) for r in mm.results]
+    assert np.array_equal(pm, np.array(rats).mean(axis=0))
+    accs = [orc.score_stats(r, test[:, 2], mm.ratings)["accuracy"] for r in rats]
+    assert [s["accuracy"] for s in mm.run_stats] == accs
+    assert mm.likelihood == mm.results[accs.index(max(accs))]["likelihood"]   # best run = best accuracy
+
+
+def test_restarts_spread_over_devices_and_contexts(fake):
+    g = load_golden("g2_c1_sampling3")
+    mm = host.MMSBM(2, 2, iterations=10, sampling=3, seed=1, devices=[1, 0, 1], contexts_per_device=1)
+    mm.fit_encoded(g["train"])
+    assert sorted(e[1] for e in fake.LOG if e[0] == "create") == [0, 1]   # duplicates dropped for fit
+    assert mm._resident == {(1, 0): [0, 2], (0, 0): [1]}
+    assert np.array_equal(np.array([r["likelihood"] for r in mm.results]), g["likelihoods"])
+    part = host.MMSBM(2, 2, iterations=10, sampling=3, seed=1)
+    part.fit_encoded(g["train"], restarts=[2])                      # a rank's share
+    assert len(part.results) == 1 and np.array_equal(part.results[0]["theta"], g["theta_2"])
+
+
+def test_cv_fit_reference_case_sequential_and_over_lanes(fake):
+    """tests/test_mmsbm.py:30-34,57-61 of the reference (folds=2 -> accuracies 0.125, 0.16)."""
+    g = load_golden("g6_cv_fit")
+    df = pd.DataFrame({"users": g["raw_users"], "items": g["raw_items"], "ratings": g["raw_ratings"]})
+    seq = host.MMSBM(2, 2, iterations=10, seed=1)
+    acc = seq.cv_fit(df, folds=2)
+    assert acc == pytest.approx(g["accuracies"].tolist(), rel=1e-12)
+    assert np.array_equal(seq.prediction_matrix, g["best_prediction_matrix"])
+    fake.LOG.clear()
+    par = host.MMSBM(2, 2, iterations=10, seed=1, devices=[0, 1])
+    assert par.cv_fit(df, folds=2) == acc
+    assert sorted(e[1] for e in fake.LOG if e[0] == "create") == [0, 1]   # one fold per lane
+    assert np.array_equal(par.prediction_matrix, seq.prediction_matrix)
+    assert par.theta.equals(seq.theta) and par.eta.equals(seq.eta)
+    with pytest.raises(AssertionError, match="Fold number"):
+        seq.cv_fit(df, folds=10**6)
+
+
+def test_convergence_monitor_and_debug_hook(fake, caplog):
+    g = load_golden("g4_2k_k10")
+    mm = host.MMSBM(10, 10, iterations=60, sampling=2, seed=3, tol=0.05, check_every=5)
+    mm.fit_encoded(g["train"])
+    ran = mm.iterations_run[0]
+    assert ran == mm.iterations_run[1] and 10 <= ran < 60 and ran % 5 == 0
+    assert [e[1] for e in fake.LOG if e[0] == "iterate"] == [5] * (ran // 5)
+    ref = host.MMSBM(10, 10, iterations=ran, sampling=2, seed=3)
+    ref.fit_encoded(g["train"])
+    assert all(np.array_equal(a["theta"], b["theta"]) for a, b in zip(mm.results, ref.results))
+    # debug: the reference's hook, a likelihood line per restart every 50 iterations
+    dbg = host.MMSBM(10, 10, iterations=120, sampling=2, seed=3, debug=True)
+    fake.LOG.clear()
+    with caplog.at_level("DEBUG", logger="MMSBM"):
+        dbg.fit_encoded(g["train"])
+    assert [e[1] for e in fake.LOG if e[0] == "iterate"] == [50, 50, 20]
+    assert caplog.text.count("Likelihood at run 0") == 3 and caplog.text.count("Likelihood at run 1") == 3
