@@ -36,6 +36,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/mmsbm_hip.h"
@@ -816,6 +817,7 @@ __global__ __launch_bounds__(kBlock) void likelihood_kernel(
 // lane-uniform and comes through scalar loads.  Element-wise formula and association order
 // are the reference's; only the order of the outer sum differs.
 constexpr int kLikThreads = 128;
+static_assert(mmsbm::kMvChunkPairs == kUnitPairs, "likelihood units are built with kMvChunkPairs pairs");
 
 __global__ __launch_bounds__(kLikThreads) void likelihood_units_kernel(
     const mmsbm::Chunk *__restrict__ units, const int32_t *__restrict__ pair_off,
@@ -874,6 +876,115 @@ __global__ __launch_bounds__(kLikThreads) void likelihood_units_kernel(
       }
     }
     if (have) total += acc;
+  }
+  red[tid] = total;
+  __syncthreads();
+  for (int h = kLikThreads / 2; h > 0; h >>= 1) {
+    if (tid < h) red[tid] += red[tid + h];
+    __syncthreads();
+  }
+  if (tid == 0) block_out[blockIdx.x] = red[0];
+}
+
+// The same likelihood without a logarithm per element.  With w = max(omega, eps) and
+// ls = log max(s, eps), a triple contributes
+//   sum_{omega >= eps} omega (log omega - ls)  +  #{omega < eps} * eps (log eps - ls)
+// and log omega = log theta_k + log eta_l + log p_kl comes from tables of logarithms that
+// log_table_kernel fills once per evaluation (U*K + I*L + R*K*L logs instead of N*K*L).  One
+// pass gathers A = sum omega log omega, W = sum omega over the unclamped elements, their count
+// and s; ls enters at the end: A - ls W + count eps (log eps - ls).  The element sum is
+// re-associated relative to the reference (agreement ~1e-15 relative), the formula is not
+// changed.  G lanes share a triple, each holding LW columns of the eta row and of its logarithms
+// in registers; the rating's tile (and its logarithms) is lane-uniform for G = 1 (scalar loads)
+// or sits in LDS.
+__global__ __launch_bounds__(kBlock) void log_table_kernel(const double *__restrict__ in,
+                                                           double *__restrict__ out, size_t n) {
+  const size_t e = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (e < n) out[e] = log(in[e]);  // log(0) = -inf belongs to elements that are clamped, never used
+}
+
+template <int LW, int G, bool TLDS>
+__global__ __launch_bounds__(kLikThreads) void likelihood_fast_kernel(
+    const mmsbm::Chunk *__restrict__ units, const int32_t *__restrict__ pair_off,
+    const int32_t *__restrict__ pair_user, const int32_t *__restrict__ pair_item, RowTab theta,
+    RowTab ltheta, const double *__restrict__ eta, const double *__restrict__ leta,
+    const double *__restrict__ p, const double *__restrict__ logp, double *__restrict__ block_out,
+    int k_groups, int l_groups, int kp, int lp) {
+  extern __shared__ double lds[];  // TLDS: [kp*lp] tile, [kp*lp] its logarithms
+  __shared__ int32_t poff[kUnitPairs + 4];
+  __shared__ double red[kLikThreads];
+  const mmsbm::Chunk ch = units[blockIdx.x];
+  const int tid = threadIdx.x;
+  const int npairs = ch.q_end - ch.q_begin;
+  if (tid <= npairs) poff[tid] = pair_off[ch.q_begin + tid];
+  const size_t toff = static_cast<size_t>(ch.rating) * kp * lp;
+  if (TLDS) {
+    for (int t = tid * 2; t < kp * lp; t += kLikThreads * 2) {
+      *reinterpret_cast<double2 *>(lds + t) = *reinterpret_cast<const double2 *>(p + toff + t);
+      *reinterpret_cast<double2 *>(lds + kp * lp + t) = *reinterpret_cast<const double2 *>(logp + toff + t);
+    }
+  }
+  __syncthreads();
+  typedef const double __attribute__((address_space(4))) * const_tile_ptr;
+  const const_tile_ptr gtile = (const_tile_ptr)(reinterpret_cast<uintptr_t>(p + toff));
+  const const_tile_ptr gltile = (const_tile_ptr)(reinterpret_cast<uintptr_t>(logp + toff));
+  constexpr int TPB = kLikThreads / G;  // triples per round
+  const int grp = tid / G, g = tid % G;
+  const int col0 = g * LW;
+  const double log_eps = log(kEps);
+  const int t0 = poff[0], t1 = poff[npairs];
+  double total = 0.0;
+  for (int base = t0; base < t1; base += TPB) {
+    const int n = base + grp;
+    const bool have = n < t1;
+    const int nn = have ? n : t1 - 1;
+    int lo = 0, hi = npairs;  // pair of triple nn: last q with poff[q] <= nn
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (poff[mid] <= nn) lo = mid; else hi = mid;
+    }
+    const size_t urow = static_cast<size_t>(pair_user[nn]);
+    const size_t irow = static_cast<size_t>(pair_item[ch.q_begin + lo]);
+    double e[LW], le[LW];
+#pragma unroll
+    for (int j = 0; j < LW; j += 2) {  // (columns past lp: any in-range address, masked below)
+      const int cc = min(col0 + j, lp - 2);
+      const double2 v = *reinterpret_cast<const double2 *>(eta + irow * lp + cc);
+      const double2 lv = *reinterpret_cast<const double2 *>(leta + irow * lp + cc);
+      e[j] = v.x; e[j + 1] = v.y;
+      le[j] = lv.x; le[j + 1] = lv.y;
+    }
+    double s = 0.0, a_sum = 0.0, w_sum = 0.0, clamped = 0.0;
+    for (int k = 0; k < k_groups; ++k) {
+      const double tk = *rowtab_ptr(theta, urow, k);
+      const double ltk = *rowtab_ptr(ltheta, urow, k);
+#pragma unroll
+      for (int j = 0; j < LW; ++j) {
+        const int l = col0 + j;
+        const bool real = l < l_groups;
+        const int lc = min(l, lp - 1);
+        double pv, lpv;
+        if (TLDS) {
+          pv = lds[k * lp + lc];
+          lpv = lds[kp * lp + k * lp + lc];
+        } else {  // G == 1: l is the same for every lane
+          pv = gtile[k * lp + lc];
+          lpv = gltile[k * lp + lc];
+        }
+        const double w = (tk * e[j]) * pv;
+        const bool big = real && w >= kEps;
+        s += real ? w : 0.0;
+        a_sum += big ? w * ((ltk + le[j]) + lpv) : 0.0;
+        w_sum += big ? w : 0.0;
+        clamped += (real && !big) ? 1.0 : 0.0;
+      }
+    }
+    s = group_sum<G>(s);
+    a_sum = group_sum<G>(a_sum);
+    w_sum = group_sum<G>(w_sum);
+    clamped = group_sum<G>(clamped);
+    const double ls = log(fmax(s, kEps));
+    if (have && g == 0) total += (a_sum - ls * w_sum) + clamped * (kEps * (log_eps - ls));
   }
   red[tid] = total;
   __syncthreads();
@@ -1076,6 +1187,52 @@ struct SlotBuf : DevBuf<double> {
   double *at(int slot) const { return ptr + static_cast<size_t>(slot) * stride; }
 };
 
+// Pinned host staging: parameter rows travel as ONE contiguous copy in the device layout
+// (packed / unpacked on the host by a few threads) instead of strided 2-D copies from
+// pageable memory.
+struct PinBuf {
+  double *ptr = nullptr;
+  size_t cap = 0, used = 0;
+  PinBuf() = default;
+  PinBuf(const PinBuf &) = delete;
+  PinBuf &operator=(const PinBuf &) = delete;
+  ~PinBuf() {
+    if (ptr) (void)hipHostFree(ptr);
+  }
+  void reset(size_t need) {
+    used = 0;
+    if (need <= cap) return;
+    if (ptr) (void)hipHostFree(ptr);
+    ptr = nullptr;
+    cap = 0;
+    HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&ptr), need * sizeof(double), hipHostMallocDefault));
+    cap = need;
+  }
+  double *take(size_t n) {
+    double *r = ptr + used;
+    used += n;
+    return r;
+  }
+};
+
+// fn(first_row, last_row) over [0, rows), on up to 8 host threads when the table is large
+template <class F>
+void for_row_blocks(int rows, size_t row_doubles, F &&fn) {
+  const size_t total = static_cast<size_t>(rows) * row_doubles;
+  unsigned nt = total < (size_t(1) << 19) ? 1u : std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+  if (nt <= 1) {
+    fn(0, rows);
+    return;
+  }
+  std::vector<std::thread> th;
+  const int per = (rows + static_cast<int>(nt) - 1) / static_cast<int>(nt);
+  for (unsigned t = 0; t < nt; ++t) {
+    const int a = static_cast<int>(t) * per, b = std::min(rows, a + per);
+    if (a < b) th.emplace_back([&fn, a, b] { fn(a, b); });
+  }
+  for (auto &x : th) x.join();
+}
+
 enum KernelId { K_SEG = 0, K_DENSE, K_ETAP, K_MATVEC_A, K_COUNT };
 // The four launches of an iteration.
 const char *const kKernelNames[K_COUNT] = {"seg_pass_kernel", "pair_block_kernel(T+S)",
@@ -1105,6 +1262,8 @@ struct mmsbm_hip_ctx {
   DevBuf<int32_t> pair_off, pair_user, pair_item, user_off, user_pair, item_off, item_pairs,
       item_deg, mv_chunk_off, orig_u, orig_i, orig_r;
   DevBuf<mmsbm::Chunk> mv_chunks;
+  DevBuf<mmsbm::Chunk> lik_units;  // 64-pair units for the likelihood kernel (mv_chunks may hold 256)
+  int n_lik_units = 0;
   DevBuf<mmsbm::WorkItem> pair_items, user_items;   // only when some segment is long
   DevBuf<mmsbm::SplitSeg> pair_splits, user_splits;
   // Per-restart state, one copy per slot.  A context carries n_slots independent restarts
@@ -1115,6 +1274,10 @@ struct mmsbm_hip_ctx {
   SlotBuf pair_parts, user_parts;
   SlotBuf theta[2], eta[2], p[2], pt[2], atab[2], ctab, ttab, partial, npr;
   DevBuf<double> lik_part;
+  DevBuf<double> lg_theta, lg_eta, lg_p;  // logarithm tables of the selected slot (likelihood)
+  bool lik_fast = true;                   // option "lik_fast": 0 = the log-per-element kernels
+  int lik_g = 0;                          // option "lik_g": lanes per triple (0 = automatic)
+  PinBuf pin;  // host staging for set_params / get_params / update_coefficients
   // predict/score session (mmsbm_hip_predict_begin .. finish)
   DevBuf<int32_t> ps_u, ps_i, ps_r;
   DevBuf<double> ps_sum, ps_w, ps_part;
@@ -1307,7 +1470,6 @@ void stage_seg(mmsbm_hip_ctx *c, bool commit, bool with_users) {
 
 void stage_dense(mmsbm_hip_ctx *c) {  // T = P^T C  and the K x L slabs for p
   if (c->n_chunks == 0) return;
-  const int cur = c->cur;
   {
     LaunchScope ls(c, K_DENSE);
     const int nb = static_cast<int>(c->lay.mv_chunks.size());
@@ -1470,46 +1632,57 @@ void alloc_state(mmsbm_hip_ctx *c, int slots) {
   c->have.assign(static_cast<size_t>(slots), 0);
 }
 
-// host (rows, d) row-major  <->  device (rows, dp) zero-padded
-// host (rows, d) row-major  <->  device RowTab (rows, dp) zero-padded, main + tail parts
+// host (rows, d) row-major  <->  device RowTab (rows, dp) zero-padded, main + tail parts (the two
+// parts are adjacent on the device: tail_off == rows * mw), staged through pinned memory
 void upload_rows(mmsbm_hip_ctx *c, const RowTab &t, const double *host, int rows, int d) {
-  const int dp = t.mw + t.tw;
-  if (d == dp && t.tw == 0) {
-    HIP_CHECK(hipMemcpyAsync(t.base, host, sizeof(double) * rows * d, hipMemcpyHostToDevice,
-                             c->stream));
-    return;
-  }
-  HIP_CHECK(hipMemsetAsync(t.base, 0, sizeof(double) * rows * dp, c->stream));
-  const int wm = std::min(d, t.mw);
-  HIP_CHECK(hipMemcpy2DAsync(t.base, sizeof(double) * t.mw, host, sizeof(double) * d,
-                             sizeof(double) * wm, rows, hipMemcpyHostToDevice, c->stream));
-  if (t.tw > 0 && d > t.mw)
-    HIP_CHECK(hipMemcpy2DAsync(t.base + t.tail_off, sizeof(double) * t.tw, host + t.mw,
-                               sizeof(double) * d, sizeof(double) * (d - t.mw), rows,
-                               hipMemcpyHostToDevice, c->stream));
+  const int dp = t.mw + t.tw, mw = t.mw, tw = t.tw;
+  double *stage = c->pin.take(static_cast<size_t>(rows) * dp);
+  double *tail = stage + static_cast<size_t>(rows) * mw;
+  const int wm = std::min(d, mw), wt = std::max(0, d - mw);
+  for_row_blocks(rows, dp, [=](int a, int b) {
+    for (int r = a; r < b; ++r) {
+      const double *src = host + static_cast<size_t>(r) * d;
+      double *m = stage + static_cast<size_t>(r) * mw;
+      std::memcpy(m, src, sizeof(double) * wm);
+      for (int j = wm; j < mw; ++j) m[j] = 0.0;
+      if (tw > 0) {
+        double *tl = tail + static_cast<size_t>(r) * tw;
+        std::memcpy(tl, src + mw, sizeof(double) * wt);
+        for (int j = wt; j < tw; ++j) tl[j] = 0.0;
+      }
+    }
+  });
+  HIP_CHECK(hipMemcpyAsync(t.base, stage, sizeof(double) * rows * dp, hipMemcpyHostToDevice, c->stream));
 }
-void download_rows(mmsbm_hip_ctx *c, double *host, const RowTab &t, int rows, int d) {
+// enqueue the device -> pinned copy; unpack_rows after the stream has been synchronised
+double *download_rows(mmsbm_hip_ctx *c, const RowTab &t, int rows) {
   const int dp = t.mw + t.tw;
-  if (d == dp && t.tw == 0) {
-    HIP_CHECK(hipMemcpyAsync(host, t.base, sizeof(double) * rows * d, hipMemcpyDeviceToHost,
-                             c->stream));
-    return;
-  }
-  const int wm = std::min(d, t.mw);
-  HIP_CHECK(hipMemcpy2DAsync(host, sizeof(double) * d, t.base, sizeof(double) * t.mw,
-                             sizeof(double) * wm, rows, hipMemcpyDeviceToHost, c->stream));
-  if (t.tw > 0 && d > t.mw)
-    HIP_CHECK(hipMemcpy2DAsync(host + t.mw, sizeof(double) * d, t.base + t.tail_off,
-                               sizeof(double) * t.tw, sizeof(double) * (d - t.mw), rows,
-                               hipMemcpyDeviceToHost, c->stream));
+  double *stage = c->pin.take(static_cast<size_t>(rows) * dp);
+  HIP_CHECK(hipMemcpyAsync(stage, t.base, sizeof(double) * rows * dp, hipMemcpyDeviceToHost, c->stream));
+  return stage;
+}
+void unpack_rows(double *host, const double *stage, const RowTab &t, int rows, int d) {
+  const int dp = t.mw + t.tw, mw = t.mw, tw = t.tw;
+  const double *tail = stage + static_cast<size_t>(rows) * mw;
+  const int wm = std::min(d, mw), wt = std::max(0, d - mw);
+  for_row_blocks(rows, dp, [=](int a, int b) {
+    for (int r = a; r < b; ++r) {
+      double *dst = host + static_cast<size_t>(r) * d;
+      std::memcpy(dst, stage + static_cast<size_t>(r) * mw, sizeof(double) * wm);
+      if (tw > 0 && wt > 0) std::memcpy(dst + mw, tail + static_cast<size_t>(r) * tw, sizeof(double) * wt);
+    }
+  });
+}
+size_t rows_doubles(const mmsbm_hip_ctx *c) {  // staging for theta + eta + p + pT of one slot
+  return static_cast<size_t>(c->n_users) * c->kp + static_cast<size_t>(c->n_items) * c->lp +
+         2 * static_cast<size_t>(c->n_ratings) * c->kp * c->lp;
 }
 
 // device p layout [R][kp][lp] (internal k, l)  <->  host pr (K, L, R) external
-void p_host_to_dev(const mmsbm_hip_ctx *c, const double *pr, std::vector<double> &p,
-                   std::vector<double> &pt) {
+void p_host_to_dev(const mmsbm_hip_ctx *c, const double *pr, double *p, double *pt) {
   const int R = c->n_ratings, K = c->k, L = c->l, kp = c->kp, lp = c->lp;
-  p.assign(static_cast<size_t>(R) * kp * lp, 0.0);
-  pt.assign(static_cast<size_t>(R) * kp * lp, 0.0);
+  std::fill(p, p + static_cast<size_t>(R) * kp * lp, 0.0);
+  std::fill(pt, pt + static_cast<size_t>(R) * kp * lp, 0.0);
   for (int k = 0; k < K; ++k)
     for (int l = 0; l < L; ++l)
       for (int r = 0; r < R; ++r) {
@@ -1521,7 +1694,7 @@ void p_host_to_dev(const mmsbm_hip_ctx *c, const double *pr, std::vector<double>
         pt[(static_cast<size_t>(r) * lp + l) * kp + k] = v;
       }
 }
-void p_dev_to_host(const mmsbm_hip_ctx *c, const std::vector<double> &p, double *pr) {
+void p_dev_to_host(const mmsbm_hip_ctx *c, const double *p, double *pr) {
   const int R = c->n_ratings, K = c->k, L = c->l, kp = c->kp, lp = c->lp;
   for (int k = 0; k < K; ++k)
     for (int l = 0; l < L; ++l)
@@ -1530,6 +1703,25 @@ void p_dev_to_host(const mmsbm_hip_ctx *c, const std::vector<double> &p, double 
                                     : (static_cast<size_t>(k) * c->ext_l + l) * R + r;
         pr[h] = p[(static_cast<size_t>(r) * kp + k) * lp + l];
       }
+}
+
+// (theta, eta, p) tables of one slot -> host arrays in host layout; any output may be null
+void fetch_params(mmsbm_hip_ctx *c, const RowTab &tt, const RowTab &et, const double *p_dev,
+                  double *theta, double *eta, double *pr) {
+  HIP_CHECK(hipStreamSynchronize(c->stream));
+  c->pin.reset(rows_doubles(c));
+  const size_t klr = static_cast<size_t>(c->n_ratings) * c->kp * c->lp;
+  const double *st = theta ? download_rows(c, tt, c->n_users) : nullptr;
+  const double *se = eta ? download_rows(c, et, c->n_items) : nullptr;
+  double *sp = nullptr;
+  if (pr) {
+    sp = c->pin.take(klr);
+    HIP_CHECK(hipMemcpyAsync(sp, p_dev, sizeof(double) * klr, hipMemcpyDeviceToHost, c->stream));
+  }
+  HIP_CHECK(hipStreamSynchronize(c->stream));
+  if (theta) unpack_rows(theta, st, tt, c->n_users, c->k);
+  if (eta) unpack_rows(eta, se, et, c->n_items, c->l);
+  if (pr) p_dev_to_host(c, sp, pr);
 }
 
 void collect_profile(mmsbm_hip_ctx *c, float *mean_us, int *launches, int n_iters) {
@@ -1647,6 +1839,8 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
 
     mmsbm::build_layout(n_obs, c->n_users, c->n_items, n_ratings, iu, ii, rating, 512, c->lay);
     // big K x L tiles: four 64-pair units per pair_block workgroup (4x fewer slabs to write + add)
+    const std::vector<mmsbm::Chunk> units64 = c->lay.mv_chunks;  // likelihood_units_kernel: <= 64 pairs
+    c->n_lik_units = static_cast<int>(units64.size());
     if (c->kp * c->lp > 1024) mmsbm::build_mv_chunks(c->lay, 4 * mmsbm::kMvChunkPairs);
     // long rows: the mat-vec's outputs go to memory straight from registers (C5: -6 % on both
     // pair_block launches); short rows are cheaper transposed through LDS and copied out flat
@@ -1667,6 +1861,7 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
     c->item_pairs.upload(c->lay.item_pairs, s);
     c->item_deg.upload(c->lay.item_deg, s);
     c->mv_chunks.upload(c->lay.mv_chunks, s);
+    c->lik_units.upload(units64, s);
     c->mv_chunk_off.upload(c->lay.mv_chunk_off, s);
     c->pair_items.upload(c->lay.pair_work.items, s);
     c->user_items.upload(c->lay.user_work.items, s);
@@ -1729,16 +1924,19 @@ int mmsbm_hip_set_params(mmsbm_hip_ctx *ctx, const double *theta, const double *
     const double *it = ctx->swapped ? eta : theta;  // internal theta rows = internal users
     const double *ie = ctx->swapped ? theta : eta;
     const int cur = ctx->cur, sl = ctx->sel;
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));  // nothing in flight still reads the staging area
+    ctx->pin.reset(rows_doubles(ctx));
     upload_rows(ctx, theta_tab(ctx, cur), it, ctx->n_users, ctx->k);
     upload_rows(ctx, plain_tab(ctx->eta[cur].at(sl), ctx->lp), ie, ctx->n_items, ctx->l);
-    std::vector<double> p, pt;
+    const size_t klr = static_cast<size_t>(ctx->n_ratings) * ctx->kp * ctx->lp;
+    double *p = ctx->pin.take(klr), *pt = ctx->pin.take(klr);
     p_host_to_dev(ctx, pr, p, pt);
-    HIP_CHECK(hipMemcpyAsync(ctx->p[cur].at(sl), p.data(), sizeof(double) * p.size(),
-                             hipMemcpyHostToDevice, ctx->stream));
-    HIP_CHECK(hipMemcpyAsync(ctx->pt[cur].at(sl), pt.data(), sizeof(double) * pt.size(),
-                             hipMemcpyHostToDevice, ctx->stream));
+    HIP_CHECK(hipMemcpyAsync(ctx->p[cur].at(sl), p, sizeof(double) * klr, hipMemcpyHostToDevice,
+                             ctx->stream));
+    HIP_CHECK(hipMemcpyAsync(ctx->pt[cur].at(sl), pt, sizeof(double) * klr, hipMemcpyHostToDevice,
+                             ctx->stream));
     stage_matvec_a(ctx, cur, cur);
-    HIP_CHECK(hipStreamSynchronize(ctx->stream));  // host staging vectors die here
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));  // the staging area is free again
     ctx->have[sl] = 1;
   });
 }
@@ -1751,16 +1949,8 @@ int mmsbm_hip_get_params(mmsbm_hip_ctx *ctx, double *theta, double *eta, double 
     double *it = ctx->swapped ? eta : theta;
     double *ie = ctx->swapped ? theta : eta;
     const int cur = ctx->cur, sl = ctx->sel;
-    if (it) download_rows(ctx, it, theta_tab(ctx, cur), ctx->n_users, ctx->k);
-    if (ie) download_rows(ctx, ie, plain_tab(ctx->eta[cur].at(sl), ctx->lp), ctx->n_items, ctx->l);
-    std::vector<double> p;
-    if (pr) {
-      p.resize(static_cast<size_t>(ctx->n_ratings) * ctx->kp * ctx->lp);
-      HIP_CHECK(hipMemcpyAsync(p.data(), ctx->p[cur].at(sl), sizeof(double) * p.size(),
-                               hipMemcpyDeviceToHost, ctx->stream));
-    }
-    HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    if (pr) p_dev_to_host(ctx, p, pr);
+    fetch_params(ctx, theta_tab(ctx, cur), plain_tab(ctx->eta[cur].at(sl), ctx->lp),
+                 ctx->p[cur].at(sl), it, ie, pr);
   });
 }
 
@@ -1838,18 +2028,69 @@ int mmsbm_hip_update_coefficients(mmsbm_hip_ctx *ctx, double *n_theta, double *n
     const int nxt = ctx->cur ^ 1, sl = ctx->sel;
     double *it = ctx->swapped ? n_eta : n_theta;
     double *ie = ctx->swapped ? n_theta : n_eta;
-    if (it) download_rows(ctx, it, theta_tab(ctx, nxt), ctx->n_users, ctx->k);
-    if (ie) download_rows(ctx, ie, plain_tab(ctx->eta[nxt].at(sl), ctx->lp), ctx->n_items, ctx->l);
-    std::vector<double> p;
-    if (n_pr) {
-      p.resize(static_cast<size_t>(ctx->n_ratings) * ctx->kp * ctx->lp);
-      HIP_CHECK(hipMemcpyAsync(p.data(), ctx->npr.at(sl), sizeof(double) * p.size(),
-                               hipMemcpyDeviceToHost, ctx->stream));
-    }
-    HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    if (n_pr) p_dev_to_host(ctx, p, n_pr);
+    fetch_params(ctx, theta_tab(ctx, nxt), plain_tab(ctx->eta[nxt].at(sl), ctx->lp),
+                 ctx->npr.at(sl), it, ie, n_pr);
   });
 }
+
+namespace {
+// likelihood of the selected slot through the logarithm tables; returns the number of partial sums
+int likelihood_fast(mmsbm_hip_ctx *c) {
+  const int cur = c->cur, sl = c->sel;
+  const size_t nt = static_cast<size_t>(c->n_users) * c->kp, ne = static_cast<size_t>(c->n_items) * c->lp;
+  const size_t np = static_cast<size_t>(c->n_ratings) * c->kp * c->lp;
+  if (c->lg_theta.count < nt) c->lg_theta.alloc(nt);
+  if (c->lg_eta.count < ne) c->lg_eta.alloc(ne);
+  if (c->lg_p.count < np) c->lg_p.alloc(np);
+  auto logs = [&](const double *in, double *out, size_t n) {
+    if (n == 0) return;
+    log_table_kernel<<<static_cast<unsigned>((n + kBlock - 1) / kBlock), kBlock, 0, c->stream>>>(in, out, n);
+  };
+  const RowTab th = theta_tab(c, cur);
+  logs(th.base, c->lg_theta.ptr, nt);  // same (main + tail) layout as theta
+  logs(c->eta[cur].at(sl), c->lg_eta.ptr, ne);
+  logs(c->p[cur].at(sl), c->lg_p.ptr, np);
+  RowTab lth = th;
+  lth.base = c->lg_theta.ptr;
+  const int nb = c->n_lik_units;
+  if (c->lik_part.count < static_cast<size_t>(nb)) c->lik_part.alloc(nb);
+  // lanes per triple and columns per lane: at most ~20 columns (40 + 40 registers) per lane
+  int G = c->lp <= 20 ? 1 : (c->lp <= 40 ? 2 : 4);
+  if (c->lik_g > 0) G = c->lik_g;  // tuning override
+  while (G < 8 && (c->lp + G - 1) / G > 20) G *= 2;
+  const int LW = ((c->lp + G - 1) / G + 3) / 4 * 4;
+  const bool tl = G > 1 || tile_in_lds(c->kp, c->lp) ||
+                  2 * static_cast<size_t>(c->kp) * c->lp * sizeof(double) > kScalarTileBytes;
+  const size_t lds = tl ? 2 * static_cast<size_t>(c->kp) * c->lp * sizeof(double) : 0;
+#define LIK_GO(LW_, G_, TL_)                                                                      \
+  likelihood_fast_kernel<LW_, G_, TL_><<<nb, kLikThreads, lds, c->stream>>>(                      \
+      c->lik_units.ptr, c->pair_off.ptr, c->pair_user.ptr, c->pair_item.ptr, th, lth,            \
+      c->eta[cur].at(sl), c->lg_eta.ptr, c->p[cur].at(sl), c->lg_p.ptr, c->lik_part.ptr, c->k,    \
+      c->l, c->kp, c->lp)
+#define LIK_LW(G_, TL_)                                                                           \
+  do {                                                                                            \
+    switch (LW) {                                                                                 \
+      case 4: LIK_GO(4, G_, TL_); break;                                                          \
+      case 8: LIK_GO(8, G_, TL_); break;                                                          \
+      case 12: LIK_GO(12, G_, TL_); break;                                                        \
+      case 16: LIK_GO(16, G_, TL_); break;                                                        \
+      default: LIK_GO(20, G_, TL_); break;                                                        \
+    }                                                                                             \
+  } while (0)
+  if (G == 1) {
+    if (tl) LIK_LW(1, true); else LIK_LW(1, false);
+  } else if (G == 2) {
+    LIK_LW(2, true);
+  } else if (G == 4) {
+    LIK_LW(4, true);
+  } else {
+    LIK_LW(8, true);
+  }
+#undef LIK_LW
+#undef LIK_GO
+  return nb;
+}
+}  // namespace
 
 int mmsbm_hip_likelihood(mmsbm_hip_ctx *ctx, double *out) {
   return guarded([&] {
@@ -1859,12 +2100,16 @@ int mmsbm_hip_likelihood(mmsbm_hip_ctx *ctx, double *out) {
     OneSlot one(ctx);
     const int cur = ctx->cur, sl = ctx->sel;
     int nb;
+    if (ctx->lik_fast && ctx->lp <= 160 && ctx->n_lik_units > 0) {
+      nb = likelihood_fast(ctx);
+    } else {
     const size_t lik_lds = static_cast<size_t>(ctx->kp + ctx->lp) * kLikThreads * sizeof(double);
-    if (lik_lds <= kLdsBudget - 2048 && !ctx->lay.mv_chunks.empty()) {
-      nb = static_cast<int>(ctx->lay.mv_chunks.size());
+    if (lik_lds <= kLdsMax - 2048 && ctx->n_lik_units > 0) {
+      nb = ctx->n_lik_units;
+      allow_big_lds(likelihood_units_kernel, lik_lds);
       if (ctx->lik_part.count < static_cast<size_t>(nb)) ctx->lik_part.alloc(nb);
       likelihood_units_kernel<<<nb, kLikThreads, lik_lds, ctx->stream>>>(
-          ctx->mv_chunks.ptr, ctx->pair_off.ptr, ctx->pair_user.ptr, ctx->pair_item.ptr,
+          ctx->lik_units.ptr, ctx->pair_off.ptr, ctx->pair_user.ptr, ctx->pair_item.ptr,
           theta_tab(ctx, cur), ctx->eta[cur].at(sl), ctx->p[cur].at(sl), ctx->lik_part.ptr, ctx->k,
           ctx->l, ctx->kp, ctx->lp);
     } else {
@@ -1874,6 +2119,7 @@ int mmsbm_hip_likelihood(mmsbm_hip_ctx *ctx, double *out) {
           ctx->orig_u.ptr, ctx->orig_i.ptr, ctx->orig_r.ptr, theta_tab(ctx, cur),
           ctx->eta[cur].at(sl), ctx->p[cur].at(sl), ctx->lik_part.ptr, ctx->n_obs, ctx->k, ctx->l,
           ctx->kp, ctx->lp);
+    }
     }
     HIP_CHECK(hipGetLastError());
     std::vector<double> part(nb);
@@ -2158,6 +2404,12 @@ int mmsbm_hip_set_option(mmsbm_hip_ctx *ctx, const char *name, double value) {
     const std::string key(name);
     if (key == "graph") {
       ctx->graph_mode = value != 0.0;
+    } else if (key == "lik_fast") {
+      ctx->lik_fast = value != 0.0;
+    } else if (key == "lik_g") {
+      const int g = static_cast<int>(value);
+      if (g != 0 && g != 1 && g != 2 && g != 4 && g != 8) throw std::invalid_argument("lik_g: 0, 1, 2, 4 or 8");
+      ctx->lik_g = g;
     } else if (key == "direct") {
       ctx->direct_out = value != 0.0;
     } else {

@@ -782,3 +782,34 @@ def test_convergence_monitor_stops_early_and_matches_fixed_length_run(hip):
     shorter.fit_encoded(g["train"])
     for a, b in zip(mm.results, shorter.results):  # the stopping rule, checked from outside
         assert abs(a["likelihood"] - b["likelihood"]) <= 1e-4 * abs(b["likelihood"])
+
+
+@pytest.mark.parametrize("k,l", [(1, 1), (3, 5), (7, 2), (16, 17), (20, 24), (33, 50), (20, 61),
+                                 (6, 130), (5, 200)])
+def test_likelihood_kernels_agree_with_the_reference_formula(hip, k, l):
+    """src/expectation_maximization.py:157-167 through both device forms: a logarithm per element
+    (the reference's order) and the logarithm tables (1..8 lanes per triple; rows wider than
+    160 use the first form).  Zero memberships give -inf table entries that must never be used,
+    tiny ones exercise the eps clamp."""
+    rng = np.random.default_rng(k * 1000 + l)
+    n_u, n_i, n_r = 90, 70, 4
+    data = np.stack([rng.integers(0, n_u, 1500), rng.integers(0, n_i, 1500),
+                     rng.integers(0, n_r, 1500)], axis=1).astype(np.int64)
+    d_u, d_i = orc.degrees(data, n_u, n_i)
+    theta, eta, pr = orc.init_params(9, n_u, n_i, n_r, k, l, d_u, d_i)
+    theta[::7, 0] = 0.0                      # exact zeros
+    eta[::5, -1] = 1e-300                    # far below eps
+    pr[0, 0, :] = 0.0                        # a zero tile entry for every rating
+    want = float(orc.compute_likelihood(data, theta, eta, pr))
+    for swap in (0, 1):
+        with make_ctx(hip, data, theta, eta, pr, swap_sides=swap) as em:
+            em.set_option("lik_fast", 0)
+            slow = em.likelihood()
+            em.set_option("lik_fast", 1)
+            fast = em.likelihood()
+            assert np.isfinite(fast)
+            assert slow == pytest.approx(want, rel=1e-12)
+            assert fast == pytest.approx(want, rel=1e-12)
+            for g in (1, 2, 4, 8):
+                em.set_option("lik_g", g)
+                assert em.likelihood() == pytest.approx(want, rel=1e-12), g
