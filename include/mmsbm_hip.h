@@ -79,6 +79,17 @@ int mmsbm_hip_degrees(const mmsbm_hip_ctx *ctx, int64_t *d_user, int64_t *d_item
 int mmsbm_hip_set_params(mmsbm_hip_ctx *ctx, const double *theta, const double *eta,
                          const double *pr);
 int mmsbm_hip_get_params(mmsbm_hip_ctx *ctx, double *theta, double *eta, double *pr);
+/* The random initialisation of src/mmsbm.py:224-233 ON the device, bit for bit:
+ * theta0 = rng.random((U,K)) / d_u, then eta0 = rng.random((I,L)) / d_i, drawn from the PCG64
+ * stream (numpy's default_rng) whose state is pcg64_state = { state_hi, state_lo, inc_hi, inc_lo }
+ * (numpy: bit_generator.state["state"]["state" | "inc"], split in 64-bit halves).  pr is the
+ * third draw -- p0 (K,L,R), already normalised -- which the caller makes on the host from the
+ * same stream advanced by U*K + I*L draws (it is tiny).  Equivalent to
+ * set_params(theta0, eta0, pr) without generating or moving the two big tables on the host. */
+int mmsbm_hip_init_params(mmsbm_hip_ctx *ctx, const uint64_t pcg64_state[4], const double *pr);
+/* Host-only: n doubles of that stream starting `offset` draws in (what Generator.random gives
+ * after advancing); lets the generator be checked against numpy without a GPU. */
+int mmsbm_hip_pcg64_doubles(const uint64_t pcg64_state[4], uint64_t offset, int64_t n, double *out);
 
 /* ---- restart slots: several restarts of one training set in one context ------------- */
 /* The reference runs its `sampling` restarts as independent processes over the same triples

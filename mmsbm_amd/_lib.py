@@ -30,6 +30,8 @@ SIGNATURES = {
     "mmsbm_hip_degrees": (C.c_int, [C.c_void_p, c_i64p, c_i64p]),
     "mmsbm_hip_set_params": (C.c_int, [C.c_void_p, c_f64p, c_f64p, c_f64p]),
     "mmsbm_hip_get_params": (C.c_int, [C.c_void_p, c_f64p, c_f64p, c_f64p]),
+    "mmsbm_hip_init_params": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), c_f64p]),
+    "mmsbm_hip_pcg64_doubles": (C.c_int, [C.POINTER(C.c_uint64), C.c_uint64, C.c_int64, c_f64p]),
     "mmsbm_hip_set_slots": (C.c_int, [C.c_void_p, C.c_int]),
     "mmsbm_hip_select_slot": (C.c_int, [C.c_void_p, C.c_int]),
     "mmsbm_hip_slots": (C.c_int, [C.c_void_p, c_intp, c_intp, c_i64p]),

@@ -24,6 +24,30 @@ def _p(a, ctype):
     return a.ctypes.data_as(C.POINTER(ctype))
 
 
+def normalize_with_self(p):
+    """p[k,l,:] /= sum_r p[k,l,r]; zero rows stay zero (src/expectation_maximization.py:152-155).
+    Host-side, used for the random initialisation only."""
+    flat = p.reshape(-1, p.shape[2])
+    tot = flat.sum(axis=1)
+    return (flat / np.where(tot == 0, 1, tot)[:, None]).reshape(p.shape)
+
+
+def pcg64_words(bit_generator):
+    """{state_hi, state_lo, inc_hi, inc_lo} of a numpy PCG64, as the C ABI takes them."""
+    st = bit_generator.state["state"]
+    mask = (1 << 64) - 1
+    return (C.c_uint64 * 4)(st["state"] >> 64, st["state"] & mask, st["inc"] >> 64, st["inc"] & mask)
+
+
+def pcg64_doubles(seed, offset, n):
+    """n doubles of default_rng(seed)'s stream starting `offset` draws in, from the library's own
+    generator (host code; no GPU needed)."""
+    out = np.empty(int(n), dtype=np.float64)
+    _lib.call("mmsbm_hip_pcg64_doubles", pcg64_words(np.random.PCG64(seed)), int(offset), int(n),
+              _p(out, C.c_double))
+    return out
+
+
 def split_triples(data):
     """(N,3) integer array (any int dtype, any strides) -> three contiguous int32 columns."""
     d = np.asarray(data)
@@ -120,6 +144,17 @@ class HipEM:
                 raise ValueError(f"{nm} has shape {arr.shape}, expected {shp}")
         _lib.call("mmsbm_hip_set_params", self._h, _p(theta, C.c_double), _p(eta, C.c_double),
                   _p(pr, C.c_double))
+
+    def init_params(self, seed):
+        """The reference's random start (src/mmsbm.py:224-233) generated on the device:
+        theta0 and eta0 are drawn there from ``default_rng(seed)``'s PCG64 stream (bit-identical
+        to numpy), only the small p0 is drawn on the host.  Returns p0."""
+        bg = np.random.PCG64(seed)
+        words = pcg64_words(bg)
+        bg.advance(self.n_users * self.k + self.n_items * self.l)
+        pr = normalize_with_self(np.random.Generator(bg).random((self.k, self.l, self.n_ratings)))
+        _lib.call("mmsbm_hip_init_params", self._h, words, _p(pr, C.c_double))
+        return pr
 
     def get_params(self):
         theta, eta, pr = (np.empty(s, dtype=np.float64) for s in self._shapes())

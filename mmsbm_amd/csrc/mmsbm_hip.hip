@@ -41,6 +41,7 @@
 
 #include "../../include/mmsbm_hip.h"
 #include "layout.hpp"
+#include "pcg64.hpp"
 
 namespace {
 
@@ -995,6 +996,33 @@ __global__ __launch_bounds__(kLikThreads) void likelihood_fast_kernel(
   if (tid == 0) block_out[blockIdx.x] = red[0];
 }
 
+// ======================================================================================
+// Initial parameters on the device (src/mmsbm.py:224-233): table[row][j] = U / degree(row) with
+// U the (offset + row*d + j)-th double of the restart's PCG64 stream -- bit for bit what
+// ``default_rng(child_seed).random((rows, d)) / degree`` gives on the host.  Each thread jumps
+// the stream to its own 8 consecutive draws.
+// ======================================================================================
+constexpr int kDrawsPerThread = 8;
+
+__global__ __launch_bounds__(kBlock) void init_rows_kernel(
+    RowTab out, const int32_t *__restrict__ off, const int32_t *__restrict__ deg, int rows, int d,
+    uint64_t s_hi, uint64_t s_lo, uint64_t i_hi, uint64_t i_lo, uint64_t stream_offset) {
+  const uint64_t total = static_cast<uint64_t>(rows) * d;
+  const uint64_t f0 = (static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x) * kDrawsPerThread;
+  if (f0 >= total) return;
+  pcg64::Stream g{pcg64::make128(s_hi, s_lo), pcg64::make128(i_hi, i_lo)};
+  pcg64::advance(g, stream_offset + f0);
+  int row = static_cast<int>(f0 / d), j = static_cast<int>(f0 % d);
+  for (int e = 0; e < kDrawsPerThread && f0 + e < total; ++e) {
+    const int cnt = off ? off[row + 1] - off[row] : deg[row];  // rows of this user / item
+    *rowtab_ptr(out, static_cast<size_t>(row), j) = pcg64::next_double(g) / static_cast<double>(max(cnt, 1));
+    if (++j == d) {
+      j = 0;
+      ++row;
+    }
+  }
+}
+
 // P[m,r] = sum_kl theta[u,k] eta[i,l] p[k,l,r] for one (row, rating): src/kernels_numpy.py:94-96.
 __device__ __forceinline__ double prod_dist_elem(const RowTab &theta, size_t urow,
                                                  const double *__restrict__ et,
@@ -1938,6 +1966,55 @@ int mmsbm_hip_set_params(mmsbm_hip_ctx *ctx, const double *theta, const double *
     stage_matvec_a(ctx, cur, cur);
     HIP_CHECK(hipStreamSynchronize(ctx->stream));  // the staging area is free again
     ctx->have[sl] = 1;
+  });
+}
+
+int mmsbm_hip_init_params(mmsbm_hip_ctx *ctx, const uint64_t pcg64_state[4], const double *pr) {
+  return guarded([&] {
+    if (!ctx || !pcg64_state || !pr) throw std::invalid_argument("null argument");
+    use_device(ctx);
+    OneSlot one(ctx);
+    const int cur = ctx->cur, sl = ctx->sel;
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    const size_t klr = static_cast<size_t>(ctx->n_ratings) * ctx->kp * ctx->lp;
+    ctx->pin.reset(2 * klr);
+    double *p = ctx->pin.take(klr), *pt = ctx->pin.take(klr);
+    p_host_to_dev(ctx, pr, p, pt);
+    HIP_CHECK(hipMemcpyAsync(ctx->p[cur].at(sl), p, sizeof(double) * klr, hipMemcpyHostToDevice, ctx->stream));
+    HIP_CHECK(hipMemcpyAsync(ctx->pt[cur].at(sl), pt, sizeof(double) * klr, hipMemcpyHostToDevice, ctx->stream));
+    // the reference draws theta (external users x K) first, then eta; internally the two sides
+    // may be swapped, the stream offsets are not
+    const uint64_t n_theta_ext = static_cast<uint64_t>(ctx->ext_users) * ctx->ext_k;
+    const uint64_t off_users = ctx->swapped ? n_theta_ext : 0;  // internal users' table
+    const uint64_t off_items = ctx->swapped ? 0 : n_theta_ext;
+    const RowTab tt = theta_tab(ctx, cur), et = plain_tab(ctx->eta[cur].at(sl), ctx->lp);
+    HIP_CHECK(hipMemsetAsync(tt.base, 0, sizeof(double) * ctx->n_users * ctx->kp, ctx->stream));  // padding
+    HIP_CHECK(hipMemsetAsync(et.base, 0, sizeof(double) * ctx->n_items * ctx->lp, ctx->stream));
+    auto blocks = [](uint64_t total) {
+      return static_cast<unsigned>((total + uint64_t(kBlock) * kDrawsPerThread - 1) / (uint64_t(kBlock) * kDrawsPerThread));
+    };
+    const uint64_t nu = static_cast<uint64_t>(ctx->n_users) * ctx->k, ni = static_cast<uint64_t>(ctx->n_items) * ctx->l;
+    if (nu > 0)
+      init_rows_kernel<<<blocks(nu), kBlock, 0, ctx->stream>>>(tt, ctx->user_off.ptr, nullptr, ctx->n_users, ctx->k,
+                                                               pcg64_state[0], pcg64_state[1], pcg64_state[2],
+                                                               pcg64_state[3], off_users);
+    if (ni > 0)
+      init_rows_kernel<<<blocks(ni), kBlock, 0, ctx->stream>>>(et, nullptr, ctx->item_deg.ptr, ctx->n_items, ctx->l,
+                                                               pcg64_state[0], pcg64_state[1], pcg64_state[2],
+                                                               pcg64_state[3], off_items);
+    HIP_CHECK(hipGetLastError());
+    stage_matvec_a(ctx, cur, cur);
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ctx->have[sl] = 1;
+  });
+}
+
+int mmsbm_hip_pcg64_doubles(const uint64_t pcg64_state[4], uint64_t offset, int64_t n, double *out) {
+  return guarded([&] {
+    if (!pcg64_state || (n > 0 && !out) || n < 0) throw std::invalid_argument("bad argument");
+    pcg64::Stream g{pcg64::make128(pcg64_state[0], pcg64_state[1]), pcg64::make128(pcg64_state[2], pcg64_state[3])};
+    pcg64::advance(g, offset);
+    for (int64_t j = 0; j < n; ++j) out[j] = pcg64::next_double(g);
   });
 }
 

@@ -22,16 +22,8 @@ from datetime import datetime
 import numpy as np
 
 from .backend import load_backend
-from .core import HipEM
+from .core import HipEM, normalize_with_self  # noqa: F401  (re-exported)
 from .encode import Encoder
-
-
-def normalize_with_self(p):
-    """p[k,l,:] /= sum_r p[k,l,r]; zero rows stay zero (src/expectation_maximization.py:152-155).
-    Host-side, used for the random initialisation only."""
-    flat = p.reshape(-1, p.shape[2])
-    tot = flat.sum(axis=1)
-    return (flat / np.where(tot == 0, 1, tot)[:, None]).reshape(p.shape)
 
 
 class MMSBM:
@@ -173,9 +165,8 @@ class MMSBM:
                 return (self.run_samplings(ids[:fit_in], device, slot, seeds[:fit_in]) +
                         self.run_samplings(ids[fit_in:], device, slot, seeds[fit_in:]))
         ctx.set_slots(len(ids))
-        d_u, d_i = ctx.degrees()
-        for s, seed in enumerate(seeds):
-            ctx.select(s).set_params(*self.init_params(seed, d_u, d_i))
+        for s, seed in enumerate(seeds):  # theta0, eta0 are drawn on the device (same PCG64 stream)
+            ctx.select(s).init_params(seed)
         done = 0
         if self.debug or self.tol is not None:
             every = 50 if self.tol is None else self.check_every  # src/mmsbm.py:252-254: every 50

@@ -55,6 +55,12 @@ class FakeHipEM:
         self._params[self._sel] = tuple(np.array(a, dtype=np.float64) for a in (theta, eta, pr))
         LOG.append(("set_params", self._sel))
 
+    def init_params(self, seed):
+        d_u, d_i = self.degrees()
+        t, e, p = orc.init_params(seed, self.n_users, self.n_items, self.n_ratings, self.k, self.l, d_u, d_i)
+        self.set_params(t, e, p)
+        return p
+
     def get_params(self):
         return tuple(a.copy() for a in self._params[self._sel])
 

@@ -85,3 +85,19 @@ def test_header_is_plain_c99_and_demo_links(tmp_path):
         pytest.skip("a GPU is present: the run is checked by the gpu test")
     run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert run.returncode == 1 and "mmsbm_hip_device_count" in run.stderr
+
+
+def test_pcg64_stream_matches_numpy_at_any_offset():
+    """The generator behind mmsbm_hip_init_params (device-side theta0 / eta0) against numpy's
+    default_rng: same doubles, from the start and after a jump-ahead."""
+    import numpy as np
+    from mmsbm_amd.core import pcg64_doubles
+    for seed in (0, 1, 12345, np.random.SeedSequence(1).spawn(3)[2]):
+        want = np.random.default_rng(seed).random(5000)
+        assert np.array_equal(pcg64_doubles(seed, 0, 5000), want)
+        for off in (1, 7, 64, 1023, 4097):
+            assert np.array_equal(pcg64_doubles(seed, off, 300), want[off:off + 300])
+        big = 2_000_000_123                      # far beyond anything that is drawn sequentially here
+        bg = np.random.PCG64(seed)
+        bg.advance(big)
+        assert np.array_equal(pcg64_doubles(seed, big, 64), np.random.Generator(bg).random(64))

@@ -813,3 +813,30 @@ def test_likelihood_kernels_agree_with_the_reference_formula(hip, k, l):
             for g in (1, 2, 4, 8):
                 em.set_option("lik_g", g)
                 assert em.likelihood() == pytest.approx(want, rel=1e-12), g
+
+
+@pytest.mark.parametrize("k,l,swap", [(2, 4, 0), (20, 20, 0), (20, 20, 1), (7, 13, 1), (50, 36, 0), (1, 1, 0)])
+def test_device_side_random_start_is_numpys(hip, k, l, swap):
+    """a7 (src/mmsbm.py:224-233): theta0 = rng.random((U,K))/d_u, eta0 = rng.random((I,L))/d_i,
+    p0 = normalize_with_self(rng.random((K,L,R))) from default_rng(child seed) -- drawn on the
+    device from the same PCG64 stream, bit for bit, including ids that never occur (degree 1)."""
+    rng = np.random.default_rng(77)
+    n_u, n_i, n_r = 1234, 321, 6
+    data = np.stack([rng.integers(0, n_u - 3, 9000), rng.integers(0, n_i - 2, 9000),
+                     rng.integers(0, n_r, 9000)], axis=1).astype(np.int64)
+    d_u, d_i = orc.degrees(data, n_u, n_i)
+    seeds = orc.child_seeds(5, 3)
+    with hip.HipEM(data, k, l, n_u, n_i, n_r, swap_sides=swap, slots=3) as em:
+        for s in (1, 0, 2):
+            p0 = em.select(s).init_params(seeds[s])
+            want = orc.init_params(seeds[s], n_u, n_i, n_r, k, l, d_u, d_i)
+            assert np.array_equal(p0, want[2])
+            for got, w, nm in zip(em.get_params(), want, ("theta", "eta", "pr")):
+                assert np.array_equal(got, w), (s, nm)
+        em.iterate(3)                                   # and the run that follows is the usual one
+        got = em.select(2).get_params()
+    with hip.HipEM(data, k, l, n_u, n_i, n_r, swap_sides=swap) as em:
+        em.set_params(*orc.init_params(seeds[2], n_u, n_i, n_r, k, l, d_u, d_i))
+        em.iterate(3)
+        for a, b in zip(got, em.get_params()):
+            assert np.array_equal(a, b)
