@@ -29,9 +29,11 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <stdexcept>
@@ -1822,6 +1824,16 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
       throw ApiError(MMSBM_E_NODEVICE, "no HIP device available (this library has no CPU path)");
     if (device < 0 || device >= ndev) throw std::invalid_argument("device index out of range");
 
+    // MMSBM_HIP_TIMING=1: where the time of building a context goes (stderr)
+    const bool timing = std::getenv("MMSBM_HIP_TIMING") != nullptr;
+    auto clk = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+      if (!timing) return;
+      const auto now = std::chrono::steady_clock::now();
+      std::fprintf(stderr, "[mmsbm_hip_create] %-28s %8.2f ms\n", what,
+                   std::chrono::duration<double, std::milli>(now - clk).count());
+      clk = now;
+    };
     std::unique_ptr<mmsbm_hip_ctx> c(new mmsbm_hip_ctx());
     c->device = device;
     c->swapped = swap_sides > 0 || (swap_sides < 0 && n_users < n_items);
@@ -1865,7 +1877,9 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
     if (n_ratings > 65535)
       throw ApiError(MMSBM_E_UNSUPPORTED, "more than 65535 distinct ratings are not supported");
 
+    lap("checks");
     mmsbm::build_layout(n_obs, c->n_users, c->n_items, n_ratings, iu, ii, rating, 512, c->lay);
+    lap("host layout (sorts)");
     // big K x L tiles: four 64-pair units per pair_block workgroup (4x fewer slabs to write + add)
     const std::vector<mmsbm::Chunk> units64 = c->lay.mv_chunks;  // likelihood_units_kernel: <= 64 pairs
     c->n_lik_units = static_cast<int>(units64.size());
@@ -1880,6 +1894,7 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
     HIP_CHECK(hipSetDevice(device));
     HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     hipStream_t s = c->stream;
+    lap("device + stream");
     c->pair_off.upload(c->lay.pair_off, s);
     c->pair_user.upload(c->lay.pair_user, s);
     c->pair_item.upload(c->lay.pair_item, s);
@@ -1904,9 +1919,11 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
       tmp.assign(rating, rating + n_obs); c->orig_r.upload(tmp, s);
       HIP_CHECK(hipStreamSynchronize(s));
     }
+    lap("index uploads");
     alloc_state(c.get(), 1);
     c->lik_part.alloc(4096);
     HIP_CHECK(hipStreamSynchronize(s));
+    lap("state allocation");
     *out = c.release();
   });
 }

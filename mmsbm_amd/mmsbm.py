@@ -79,7 +79,7 @@ class MMSBM:
         *_, self._backend = load_backend(self.backend)
         train = np.asarray(train)
         self.train = train
-        self.ratings = sorted(set(train[:, 2].tolist()))
+        self.ratings = np.unique(train[:, 2]).tolist()  # = sorted(set(...)), src/mmsbm.py:95
         self.r = max(self.ratings)
         self.p = int(train[:, 0].max())
         self.m = int(train[:, 1].max())
