@@ -80,9 +80,11 @@ def main():
     ap.add_argument("--cpu-sample-rows", type=int, default=100_000)
     ap.add_argument("--cpu-iters", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--batched-restarts", type=int, default=8,
+    ap.add_argument("--batched-restarts", type=int, default=0,
                     help="after the timed region also report the rate with this many restarts per "
-                         "GPU advancing as slots of one context (0 = skip); never part of `value`")
+                         "GPU advancing as slots of one context (e.g. 8); never part of `value`.  Off by "
+                         "default so that a kernel trace of the default command holds one-restart "
+                         "launches only")
     ap.add_argument("--graph", action="store_true", help="replay a captured hipGraph instead of eager launches")
     ap.add_argument("--dist-backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
     ap.add_argument("--share-gpu", action="store_true",
