@@ -17,7 +17,8 @@ os.makedirs(dst, exist_ok=True)
 def short(name):
     for key, nm in (("seg_pass_kernel", "seg_pass_kernel"), ("pair_block_kernel<false", "pair_block_kernel(T+S)"),
                     ("pair_block_kernel<true", "pair_block_kernel(A)"), ("eta_p_kernel", "eta_p_kernel"),
-                    ("seg_combine_kernel", "seg_combine_kernel"), ("likelihood_units_kernel", "likelihood_units_kernel"),
+                    ("seg_combine_kernel", "seg_combine_kernel"), ("likelihood_fast_kernel", "likelihood_fast_kernel"), ("log_table_kernel", "log_table_kernel"),
+                    ("init_rows_kernel", "init_rows_kernel"), ("likelihood_units_kernel", "likelihood_units_kernel"),
                     ("likelihood_kernel", "likelihood_kernel"), ("prod_dist_kernel", "prod_dist_kernel")):
         if key in name:
             return nm
