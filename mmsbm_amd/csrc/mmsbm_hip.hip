@@ -594,13 +594,14 @@ __global__ __launch_bounds__(NT) void pair_block_kernel(PairBlockArgs pa,
 
 // ======================================================================================
 // kernel 4: p_update -- n_p[r][k][l] = p[r][k][l] * sum_{chunks c of r} S_c[k][l] (fixed
-// order: 64 strided partial sums, then 8 sums of 8, then a sum of 8), followed by
+// order: 128 strided partial sums, then 8 sums of 16, then a sum of 8), followed by
 // normalize_with_self over r (src/expectation_maximization.py:152-155; zero rows stay
-// zero).  One block owns 16 (k,l) columns for ALL ratings, so no inter-block hand-off is
+// zero).  One block owns 8 (k,l) columns for ALL ratings (measured: 16 x 64 rows 8.4 us for
+// the launch at C3, 8 x 128 rows 7.9, 4 x 256 rows 10.8), so no inter-block hand-off is
 // needed; every thread's slab loads are independent and issued back to back.  Writes
 // p_new as [R][Kp][Lp] and transposed [R][Lp][Kp]; optionally the raw numerators.
 // ======================================================================================
-constexpr int kRedCols = 16, kRedRows = 64, kRedGroup = 6;  // ratings per LDS pass
+constexpr int kRedCols = 8, kRedRows = 128, kRedGroup = 6;  // ratings per LDS pass
 constexpr int kRedThreads = kRedCols * kRedRows, kRedBatch = 4;
 
 template <int ROWS>
@@ -753,7 +754,7 @@ struct EtaPArgs {
   double *p_new; double *pt_new; double *npr;
   const double *ttab; const int32_t *item_off; const int32_t *item_pairs; const int32_t *item_deg;
   const double *eta; double *eta_new;
-  int n_ratings, kp, lp, n_items, normalize, nb_p;
+  int n_ratings, kp, lp, n_items, normalize, nb_p, abl;
   size_t bs_partial, bs_p, bs_t, bs_eta;  // restart slots (blockIdx.y): table strides
 };
 
@@ -761,6 +762,7 @@ template <int G, int VEC>
 __global__ __launch_bounds__(kRedThreads) void eta_p_kernel(EtaPArgs a) {
   __shared__ double red[kRedGroup][kRedRows][kRedCols];
   const size_t slot = blockIdx.y;
+  if (a.abl & (static_cast<int>(blockIdx.x) < a.nb_p ? 64 : 128)) return;  // tuning aid: skip a role
   if (static_cast<int>(blockIdx.x) < a.nb_p)
     p_update_block<kRedRows>(red, blockIdx.x, a.partial + slot * a.bs_partial, a.chunk_off,
                              a.p_old + slot * a.bs_p, a.p_new + slot * a.bs_p,
@@ -1465,6 +1467,7 @@ EtaPArgs eta_p_args(const mmsbm_hip_ctx *c, bool commit, int cols_per_block) {
   a.bs_eta = c->eta[0].stride;
   a.n_ratings = c->n_ratings; a.kp = c->kp; a.lp = c->lp; a.n_items = c->n_items;
   a.normalize = commit ? 1 : 0;
+  a.abl = c->ablate;
   a.nb_p = (c->kp * c->lp + cols_per_block - 1) / cols_per_block;
   return a;
 }
