@@ -1290,6 +1290,7 @@ struct mmsbm_hip_ctx {
   int pb_kt = 4;  // pair_block S phase: k-rows per register tile (2 when K x L is small)
   int pb_spb = kBlock, pb_nacc = 1, pb_nsub = 1;  // pair_block S phase: threads per slot-grid copy, slots per thread
   size_t lds_t = 0, lds_a = 0;
+  bool tl_t = false, tl_a = false;  // rating tile staged in LDS (T+S launch / A launch)
   mmsbm::Layout lay;  // host copy (degrees, sizes)
   DevBuf<int32_t> pair_off, pair_user, pair_item, user_off, user_pair, item_off, item_pairs,
       item_deg, mv_chunk_off, orig_u, orig_i, orig_r;
@@ -1372,10 +1373,10 @@ constexpr size_t kScalarTileBytes = 8 * 1024;  // larger tiles thrash the scalar
 bool tile_in_lds(int dinp, int doutp) {
   return static_cast<size_t>(dinp) * doutp * sizeof(double) > kScalarTileBytes;
 }
-size_t pair_block_lds(int dinp, int doutp, bool with_s) {
-  (void)with_s;  // the eta rows and the output rows share one region
+size_t pair_block_lds(int dinp, int doutp, bool tile_lds) {
+  // transposed input rows + one region shared by the eta rows and the output rows [+ the tile]
   const size_t d = static_cast<size_t>(dinp) * (kUnitPairs + 1) + static_cast<size_t>(kUnitPairs) * doutp +
-                   (tile_in_lds(dinp, doutp) ? static_cast<size_t>(dinp) * doutp : 0);
+                   (tile_lds ? static_cast<size_t>(dinp) * doutp : 0);
   return d * sizeof(double);  // the S hand-over area reuses it (create() bounds the copies by it)
 }
 
@@ -1522,7 +1523,7 @@ void stage_dense(mmsbm_hip_ctx *c) {  // T = P^T C  and the K x L slabs for p
   } while (0)
 #define PB(N)                                                                               \
   do {                                                                                      \
-    const bool tl = tile_in_lds(c->kp, c->lp), big = c->pb_threads_t > kBlock;              \
+    const bool tl = c->tl_t, big = c->pb_threads_t > kBlock;                                \
     if (tl && big) PB_GO(N, true, kPairBlockMax);                                           \
     else if (tl) PB_GO(N, true, kBlock);                                                    \
     else if (big) PB_GO(N, false, kPairBlockMax);                                           \
@@ -1568,7 +1569,7 @@ void stage_matvec_a(mmsbm_hip_ctx *c, int slot, int a_slot) {
   do {                                                                                      \
     if (c->direct_out) PA_D(TL, NT, true); else PA_D(TL, NT, false);                        \
   } while (0)
-    const bool tl = tile_in_lds(c->lp, c->kp), big = c->pb_threads_a > kBlock;
+    const bool tl = c->tl_a, big = c->pb_threads_a > kBlock;
     if (tl && big) PA_GO(true, kPairBlockMax);
     else if (tl) PA_GO(true, kBlock);
     else if (big) PA_GO(false, kPairBlockMax);
@@ -1869,13 +1870,19 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
       }
       else { c->pb_spb = nthr; int n = 1; while (n * nthr < nslot) n *= 2; c->pb_nacc = n; }
     }
-    c->lds_t = pair_block_lds(c->kp, c->lp, true);
-    c->lds_a = pair_block_lds(c->lp, c->kp, false);
+    // the rating tile sits in LDS when it is too big for the scalar cache -- unless that does not
+    // fit beside the rows, then it is read through scalar loads after all (slower, but it runs)
+    c->tl_t = tile_in_lds(c->kp, c->lp);
+    c->tl_a = tile_in_lds(c->lp, c->kp);
+    c->lds_t = pair_block_lds(c->kp, c->lp, c->tl_t);
+    c->lds_a = pair_block_lds(c->lp, c->kp, c->tl_a);
+    if (c->lds_t > kLdsMax) { c->tl_t = false; c->lds_t = pair_block_lds(c->kp, c->lp, false); }
+    if (c->lds_a > kLdsMax) { c->tl_a = false; c->lds_a = pair_block_lds(c->lp, c->kp, false); }
     if (c->lds_t > kLdsMax || c->lds_a > kLdsMax || c->pb_nacc > 4)
       throw ApiError(MMSBM_E_UNSUPPORTED,
                      "K and L too large: the 64-pair stage needs " +
                          std::to_string(std::max(c->lds_t, c->lds_a) / 1024) +
-                         " KiB of LDS (limit 160; roughly K, L <= 90, or one of them small)");
+                         " KiB of LDS (limit 160; roughly K, L <= 150 together, or one of them small)");
     c->split_rows = true;
     if (n_ratings > 65535)
       throw ApiError(MMSBM_E_UNSUPPORTED, "more than 65535 distinct ratings are not supported");
@@ -2131,6 +2138,15 @@ int mmsbm_hip_update_coefficients(mmsbm_hip_ctx *ctx, double *n_theta, double *n
 }
 
 namespace {
+// likelihood_fast_kernel: tile + its logarithms in LDS?  (always with several lanes per triple)
+bool lik_fast_tile_lds(const mmsbm_hip_ctx *c) {
+  return c->lp > 20 || c->lik_g > 1 ||
+         2 * static_cast<size_t>(c->kp) * c->lp * sizeof(double) > kScalarTileBytes;
+}
+bool lik_fast_usable(const mmsbm_hip_ctx *c) {
+  const size_t lds = lik_fast_tile_lds(c) ? 2 * static_cast<size_t>(c->kp) * c->lp * sizeof(double) : 0;
+  return c->lik_fast && c->lp <= 160 && c->n_lik_units > 0 && lds <= kLdsMax - 4096;
+}
 // likelihood of the selected slot through the logarithm tables; returns the number of partial sums
 int likelihood_fast(mmsbm_hip_ctx *c) {
   const int cur = c->cur, sl = c->sel;
@@ -2156,10 +2172,10 @@ int likelihood_fast(mmsbm_hip_ctx *c) {
   if (c->lik_g > 0) G = c->lik_g;  // tuning override
   while (G < 8 && (c->lp + G - 1) / G > 20) G *= 2;
   const int LW = ((c->lp + G - 1) / G + 3) / 4 * 4;
-  const bool tl = G > 1 || tile_in_lds(c->kp, c->lp) ||
-                  2 * static_cast<size_t>(c->kp) * c->lp * sizeof(double) > kScalarTileBytes;
+  const bool tl = lik_fast_tile_lds(c);
   const size_t lds = tl ? 2 * static_cast<size_t>(c->kp) * c->lp * sizeof(double) : 0;
 #define LIK_GO(LW_, G_, TL_)                                                                      \
+  allow_big_lds(likelihood_fast_kernel<LW_, G_, TL_>, lds);                                       \
   likelihood_fast_kernel<LW_, G_, TL_><<<nb, kLikThreads, lds, c->stream>>>(                      \
       c->lik_units.ptr, c->pair_off.ptr, c->pair_user.ptr, c->pair_item.ptr, th, lth,            \
       c->eta[cur].at(sl), c->lg_eta.ptr, c->p[cur].at(sl), c->lg_p.ptr, c->lik_part.ptr, c->k,    \
@@ -2197,7 +2213,7 @@ int mmsbm_hip_likelihood(mmsbm_hip_ctx *ctx, double *out) {
     OneSlot one(ctx);
     const int cur = ctx->cur, sl = ctx->sel;
     int nb;
-    if (ctx->lik_fast && ctx->lp <= 160 && ctx->n_lik_units > 0) {
+    if (lik_fast_usable(ctx)) {
       nb = likelihood_fast(ctx);
     } else {
     const size_t lik_lds = static_cast<size_t>(ctx->kp + ctx->lp) * kLikThreads * sizeof(double);

@@ -375,7 +375,7 @@ def test_c_abi_error_paths(hip):
         HipEM(good, 600, 2)
     assert e.value.code == _lib.E_UNSUPPORTED
     with pytest.raises(_lib.HipLibraryError) as e:
-        HipEM(good, 128, 128)                               # the 64-pair stage would need > 160 KiB of LDS
+        HipEM(good, 200, 200)                               # the 64-pair stage would need > 160 KiB of LDS
     assert e.value.code == _lib.E_UNSUPPORTED and "LDS" in e.value.message
     with pytest.raises(_lib.HipLibraryError) as e:
         HipEM(good, 2, 2, device=99)
@@ -840,3 +840,28 @@ def test_device_side_random_start_is_numpys(hip, k, l, swap):
         em.iterate(3)
         for a, b in zip(got, em.get_params()):
             assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("k,l", [(72, 80), (120, 120), (150, 40), (9, 158)])
+def test_wide_group_counts_beyond_the_lds_tile(hip, k, l):
+    """K, L up to ~150: the rating tile no longer fits in LDS beside the rows and is read through
+    scalar loads; likelihood falls back from the table form when ITS tiles do not fit."""
+    rng = np.random.default_rng(k + l)
+    n_u, n_i, n_r = 150, 90, 3
+    data = np.stack([rng.integers(0, n_u, 1200), rng.integers(0, n_i, 1200),
+                     rng.integers(0, n_r, 1200)], axis=1).astype(np.int64)
+    d_u, d_i = orc.degrees(data, n_u, n_i)
+    theta, eta, pr = orc.init_params(3, n_u, n_i, n_r, k, l, d_u, d_i)
+    want = orc.update_coefficients(data, theta, eta, pr)
+    t, e, p = theta, eta, pr
+    for _ in range(2):
+        t, e, p = orc.em_step(data, t, e, p, d_u, d_i)
+    for swap in (0, 1):
+        with make_ctx(hip, data, theta, eta, pr, swap_sides=swap) as em:
+            for got, w, nm in zip(em.update_coefficients(), want, ("n_theta", "n_eta", "n_pr")):
+                assert rel_err(got, w) < TOL_STEP, nm
+            em.iterate(2)
+            for got, w, nm in zip(em.get_params(), (t, e, p), ("theta", "eta", "pr")):
+                assert rel_err(got, w) < 1e-11, nm
+            assert em.likelihood() == pytest.approx(float(orc.compute_likelihood(data, t, e, p)), rel=1e-11)
+            assert np.allclose(em.prod_dist(data[:50]), orc.prod_dist(data[:50], t, e, p), rtol=1e-11, atol=1e-300)
