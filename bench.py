@@ -54,6 +54,19 @@ def cpu_baseline(cfg, sample_rows, iters):
             "host_cpus": os.cpu_count()}
 
 
+FP64_VALU_PEAK_TFLOPS = 78.6  # MI355X vector fp64 (MI355X_MICROARCH.md)
+
+
+def fp64_valu(n, q, k, l, its_per_gpu):
+    device = 8.0 * n * k + 6.0 * q * k * l
+    dense = 6.0 * n * k * l
+    return {"device_flops_per_iter": device, "device_tflops": device * its_per_gpu / 1e12,
+            "frac_of_peak": device * its_per_gpu / 1e12 / FP64_VALU_PEAK_TFLOPS,
+            "reference_dataflow_flops_per_iter": dense,
+            "reference_dataflow_equiv_tflops": dense * its_per_gpu / 1e12,
+            "peak_tflops": FP64_VALU_PEAK_TFLOPS}
+
+
 def batched_rate(model, train, device, slots, iters):
     """`slots` restarts of the same training set advance with one set of
     launches.  Reported beside the headline, never as `value` (whose config is sampling=1)."""
@@ -175,7 +188,11 @@ def main():
             "iteration": {"algorithmic_read_bytes": rd, "algorithmic_write_bytes": wr,
                           "achieved_gbps_per_gpu": rd * (its / world) / 1e9,
                           "frac_of_hbm_peak": rd * (its / world) / 1e9 / HBM_PEAK_GBPS,
-                          "device_ms_per_step_events": ev_ms / args.steps},
+                          "device_ms_per_step_events": ev_ms / args.steps,
+                          # secondary bound: fp64 vector ALU.  Flops the DEVICE does
+                          # (factorised form: 8NK in the two passes + 6QKL in the pair stage) and
+                          # the reference dataflow's 6KL per triple, against the 78.6 TFLOP/s peak
+                          "fp64_valu": fp64_valu(n, ctx.n_pairs, k, l, its / world)},
             "kernels_us": {nm: {"avg_us": v[0], "launches_per_iter": v[1],
                                 "gbps": (v[2] / (v[0] * 1e-6) / 1e9) if v[0] > 0 else None}
                            for nm, v in prof.items()},
