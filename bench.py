@@ -90,8 +90,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--config", default="c3", choices=["c2", "c3", "c5"])
     ap.add_argument("--profile-iters", type=int, default=20)
-    ap.add_argument("--cpu-sample-rows", type=int, default=100_000)
-    ap.add_argument("--cpu-iters", type=int, default=8)
+    ap.add_argument("--cpu-sample-rows", type=int, default=300_000)
+    ap.add_argument("--cpu-iters", type=int, default=12)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batched-restarts", type=int, default=0,
                     help="after the timed region also report the rate with this many restarts per "
