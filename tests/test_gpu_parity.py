@@ -865,3 +865,35 @@ def test_wide_group_counts_beyond_the_lds_tile(hip, k, l):
                 assert rel_err(got, w) < 1e-11, nm
             assert em.likelihood() == pytest.approx(float(orc.compute_likelihood(data, t, e, p)), rel=1e-11)
             assert np.allclose(em.prod_dist(data[:50]), orc.prod_dist(data[:50], t, e, p), rtol=1e-11, atol=1e-300)
+
+
+@pytest.mark.parametrize("n_r,k,l", [(1, 3, 4), (33, 5, 6), (100, 4, 3), (7, 20, 20)])
+def test_many_or_single_rating_values(hip, n_r, k, l):
+    """R = 1 (p stays 1 everywhere) up to R = 100 (many tiny rating-homogeneous units, several
+    passes of six ratings in p_update), some rating values unused."""
+    rng = np.random.default_rng(n_r)
+    n_u, n_i = 120, 60
+    r_col = rng.integers(0, n_r, 2500)
+    if n_r > 10:
+        r_col[r_col % 7 == 3] = 0            # leave some rating values without any row
+    data = np.stack([rng.integers(0, n_u, 2500), rng.integers(0, n_i, 2500), r_col], axis=1).astype(np.int64)
+    d_u, d_i = orc.degrees(data, n_u, n_i)
+    theta, eta, pr = orc.init_params(2, n_u, n_i, n_r, k, l, d_u, d_i)
+    want = orc.update_coefficients(data, theta, eta, pr)
+    t, e, p = theta, eta, pr
+    for _ in range(4):
+        t, e, p = orc.em_step(data, t, e, p, d_u, d_i)
+    for swap in (0, 1):
+        with make_ctx(hip, data, theta, eta, pr, swap_sides=swap) as em:
+            for got, w, nm in zip(em.update_coefficients(), want, ("n_theta", "n_eta", "n_pr")):
+                assert rel_err(got, w) < TOL_STEP, nm
+            em.iterate(4)
+            for got, w, nm in zip(em.get_params(), (t, e, p), ("theta", "eta", "pr")):
+                assert rel_err(got, w) < 1e-11, nm
+            assert em.likelihood() == pytest.approx(float(orc.compute_likelihood(data, t, e, p)), rel=1e-11)
+            test = data[:200]
+            em.predict_begin(test, np.arange(n_r, dtype=np.float64))
+            st = hip.HipEM.final_stats(em.predict_add())
+            ref = orc.score_stats(orc.prod_dist(test, t, e, p), test[:, 2], list(range(n_r)))
+            assert st["s2"] == ref["s2"] or rel_err(em.prod_dist(test), orc.prod_dist(test, t, e, p)) < 1e-11
+            em.predict_finish()
