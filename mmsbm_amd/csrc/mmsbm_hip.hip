@@ -1490,6 +1490,8 @@ struct mmsbm_hip_ctx {
   size_t lds_t = 0, lds_a = 0;
   bool tl_t = false, tl_a = false;  // rating tile staged in LDS (T+S launch / A launch)
   bool quad_t = false, quad_a = false;  // pair_quad_kernel (four units at once) for that launch
+  bool quad_a_persist = false;          // ... the A launch as a persistent prefetching pipeline
+  int n_cus = 256;
   size_t lds_qt = 0, lds_qa = 0;
   mmsbm::Layout lay;  // host copy (degrees, sizes)
   DevBuf<int32_t> pair_off, pair_user, pair_item, user_off, user_pair, item_off, item_pairs,
@@ -1563,6 +1565,150 @@ struct LaunchScope {  // optional event pair around one launch
 };
 
 void use_device(const mmsbm_hip_ctx *c) { HIP_CHECK(hipSetDevice(c->device)); }
+
+// pair_quad_a -- the A launch for long rows as a PERSISTENT pipeline: one workgroup per CU walks
+// chunks blockIdx.x, + gridDim.x, ...; while it computes chunk i from LDS, the gathered rows of
+// chunk i+1 are already on their way into registers and the item ids of chunk i+2 behind them,
+// so the dependent round trips (ids -> rows) are paid once per workgroup, not once per chunk.
+// NL = double2 per thread per chunk: 256 pairs x dinp entries / 2 / 512 threads = dinp / 4
+template <int NL>
+__global__ __launch_bounds__(kPairBlockMax) void pair_quad_a_kernel(PairBlockArgs pa,
+                                                                    const double *__restrict__ tiles0,
+                                                                    int n_chunks) {
+  constexpr int NT = kPairBlockMax;
+  const size_t slot = blockIdx.y;
+  const double *__restrict__ tiles = tiles0 + slot * pa.bs_tiles;
+  const double *__restrict__ in_tab = pa.in_tab + slot * pa.bs_in;
+  const int32_t *__restrict__ pair_item = pa.pair_item;
+  double *__restrict__ out = pa.out + slot * pa.bs_out;
+  const int dinp = pa.dinp, doutp = pa.doutp;
+  extern __shared__ double lds[];
+  constexpr int CS = kUnitPairs + 1;
+  const int ustride = dinp * CS;
+  double *cst = lds;                                                 // [4][dinp][CS]
+  double *tile_l = cst + static_cast<size_t>(kQuadUnits) * ustride;  // [dinp][doutp]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int nch = doutp >> 2;
+  const int stride = gridDim.x;
+  int ci = blockIdx.x;
+  if (ci >= n_chunks) return;
+
+  // this thread's share of a chunk: elements t_j = 2 tid + j * 2 NT of the flat (pair, entry) space
+  int pd[NL];  // (pair within the chunk) << 8 | entry   (the pair may be >= the chunk's size: masked by `total`)
+#pragma unroll
+  for (int j = 0; j < NL; ++j) {
+    const int t = tid * 2 + j * NT * 2;
+    const int pr = t / dinp;
+    pd[j] = (pr << 8) | (t - pr * dinp);
+  }
+#define PRJ(j) (pd[j] >> 8)
+#define DJ(j) (pd[j] & 255)
+  mmsbm::Chunk ch = pa.chunks[ci];
+  int ids[NL];
+  double2 v[NL];
+  {
+    const int total = (ch.q_end - ch.q_begin) * dinp;
+#pragma unroll
+    for (int j = 0; j < NL; ++j)
+      ids[j] = (tid * 2 + j * NT * 2 < total) ? pair_item[ch.q_begin + PRJ(j)] : 0;
+#pragma unroll
+    for (int j = 0; j < NL; ++j)
+      v[j] = *reinterpret_cast<const double2 *>(in_tab + static_cast<size_t>(ids[j]) * dinp + DJ(j));
+  }
+  bool has_next = ci + stride < n_chunks;
+  mmsbm::Chunk nx = has_next ? pa.chunks[ci + stride] : ch;
+  if (has_next) {
+    const int total = (nx.q_end - nx.q_begin) * dinp;
+#pragma unroll
+    for (int j = 0; j < NL; ++j)
+      ids[j] = (tid * 2 + j * NT * 2 < total) ? pair_item[nx.q_begin + PRJ(j)] : 0;
+  }
+  int tile_rating = -1;
+  while (true) {
+    const int np_all = ch.q_end - ch.q_begin;
+    const int total = np_all * dinp;
+    __syncthreads();  // the previous chunk's mat-vec is done with cst and the tile
+    if (ch.rating != tile_rating) {
+      const double *src = tiles + static_cast<size_t>(ch.rating) * dinp * doutp;
+      for (int t = tid * 2; t < dinp * doutp; t += NT * 2)
+        *reinterpret_cast<double2 *>(tile_l + t) = *reinterpret_cast<const double2 *>(src + t);
+      tile_rating = ch.rating;
+    }
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {  // (columns of pairs beyond np_all keep stale data: their outputs are never stored)
+      if (tid * 2 + j * NT * 2 < total) {
+        double *dst = cst + (PRJ(j) >> 6) * ustride + DJ(j) * CS + (PRJ(j) & 63);
+        dst[0] = v[j].x;
+        dst[CS] = v[j].y;
+      }
+    }
+    __syncthreads();
+    // prefetch: rows of the next chunk (its ids arrived during the previous iteration), then the
+    // ids of the chunk after that
+    const bool has_next2 = ci + 2 * stride < n_chunks;
+    mmsbm::Chunk nn = nx;
+    if (has_next) {
+#pragma unroll
+      for (int j = 0; j < NL; ++j)
+        v[j] = *reinterpret_cast<const double2 *>(in_tab + static_cast<size_t>(ids[j]) * dinp + DJ(j));
+      if (has_next2) {
+        nn = pa.chunks[ci + 2 * stride];
+        const int tot2 = (nn.q_end - nn.q_begin) * dinp;
+#pragma unroll
+        for (int j = 0; j < NL; ++j)
+          ids[j] = (tid * 2 + j * NT * 2 < tot2) ? pair_item[nn.q_begin + PRJ(j)] : 0;
+      }
+    }
+    // ---- mat-vec over the four units at once: lane = pair (of each unit), wave = output chunk ----
+    for (int c = __builtin_amdgcn_readfirstlane(wave); c < nch; c += NT / 64) {
+      double a[kQuadUnits][4];
+#pragma unroll
+      for (int u = 0; u < kQuadUnits; ++u)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[u][j] = 0.0;
+      for (int d = 0; d < dinp; d += 2) {
+        double2 m0[2], m1[2];
+        double x[2][kQuadUnits];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          m0[i] = *reinterpret_cast<const double2 *>(tile_l + (d + i) * doutp + c * 4);
+          m1[i] = *reinterpret_cast<const double2 *>(tile_l + (d + i) * doutp + c * 4 + 2);
+#pragma unroll
+          for (int u = 0; u < kQuadUnits; ++u) x[i][u] = cst[u * ustride + (d + i) * CS + lane];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int u = 0; u < kQuadUnits; ++u) {
+            a[u][0] = fma(x[i][u], m0[i].x, a[u][0]);
+            a[u][1] = fma(x[i][u], m0[i].y, a[u][1]);
+            a[u][2] = fma(x[i][u], m1[i].x, a[u][2]);
+            a[u][3] = fma(x[i][u], m1[i].y, a[u][3]);
+          }
+      }
+      const int j0 = c * 4, mw = pa.out_mw;
+#pragma unroll
+      for (int u = 0; u < kQuadUnits; ++u) {
+        const int pr = u * kUnitPairs + lane;
+        if (pr < np_all) {
+          const size_t q = static_cast<size_t>(ch.q_begin + pr);
+          double *dst = j0 < mw ? out + q * mw + j0 : out + pa.out_tail_off + q * (doutp - mw) + (j0 - mw);
+          double2 w0, w1;
+          w0.x = a[u][0]; w0.y = a[u][1]; w1.x = a[u][2]; w1.y = a[u][3];
+          *reinterpret_cast<double2 *>(dst) = w0;
+          *reinterpret_cast<double2 *>(dst + 2) = w1;
+        }
+      }
+    }
+    if (!has_next) break;
+    ci += stride;
+    ch = nx;
+    nx = nn;
+    has_next = has_next2;
+  }
+#undef PRJ
+#undef DJ
+}
 
 constexpr size_t kLdsBudget = 64 * 1024;  // dynamic LDS a launch may use without hipFuncSetAttribute
 
@@ -1771,7 +1917,20 @@ void stage_eta_p(mmsbm_hip_ctx *c, bool commit) {  // eta_new ; p_new, pT_new, r
 void stage_matvec_a(mmsbm_hip_ctx *c, int slot, int a_slot) {
   if (c->n_chunks == 0) return;
   LaunchScope ls(c, K_MATVEC_A);
-  if (c->quad_a) {
+  if (c->quad_a && c->quad_a_persist) {
+    const int nb = static_cast<int>(c->lay.mv_chunks.size());
+    const PairBlockArgs pa = pair_block_a_args(c, slot, a_slot);
+    const dim3 grid = slot_grid(c, std::min(nb, c->n_cus));
+#define QA(NL)                                                                                    \
+  do {                                                                                            \
+    allow_big_lds(pair_quad_a_kernel<NL>, c->lds_qa);                                             \
+    pair_quad_a_kernel<NL><<<grid, kPairBlockMax, c->lds_qa, c->stream>>>(pa, pa.tiles, nb);      \
+  } while (0)
+    const int nl = (c->lp + 3) / 4;  // dinp of the A launch = lp
+    if (nl <= 8) QA(8); else if (nl <= 10) QA(10); else if (nl <= 12) QA(12);
+    else if (nl <= 13) QA(13); else if (nl <= 14) QA(14); else QA(16);
+#undef QA
+  } else if (c->quad_a) {
     const int nb = static_cast<int>(c->lay.mv_chunks.size());
     const PairBlockArgs pa = pair_block_a_args(c, slot, a_slot);
     allow_big_lds(pair_quad_kernel<true, false, 4>, c->lds_qa);
@@ -2126,14 +2285,20 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
       };
       c->lds_qt = quad_lds(c->kp, c->lp, true);
       c->lds_qa = quad_lds(c->lp, c->kp, false);
-      c->quad_t = chunks4 && c->tl_t && c->pb_threads_t == kPairBlockMax && c->pb_nacc == 1 &&
-                  c->lds_qt <= kLdsMax - 2048;
-      c->quad_a = chunks4 && c->tl_a && c->pb_threads_a == kPairBlockMax && c->lds_qa <= kLdsMax - 2048;
+      c->quad_t = false;  // measured slower than pair_block at C5 (605 vs 560 us); option "quad" bit 0
+      c->quad_a = chunks4 && c->tl_a && c->pb_threads_a == kPairBlockMax && c->lds_qa <= kLdsMax - 2048 &&
+                  c->lp <= 64;
+      c->quad_a_persist = c->quad_a;
     }
     c->n_pairs = c->lay.n_pairs;
     c->n_chunks = static_cast<int>(c->lay.mv_chunks.size());
 
     HIP_CHECK(hipSetDevice(device));
+    {
+      int cus = 0;
+      if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
+        c->n_cus = cus;
+    }
     HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     hipStream_t s = c->stream;
     lap("device + stream");
@@ -2763,7 +2928,8 @@ int mmsbm_hip_set_option(mmsbm_hip_ctx *ctx, const char *name, double value) {
       ctx->quad_t = (v & 1) && chunks4 && ctx->tl_t && ctx->pb_threads_t == kPairBlockMax &&
                     ctx->pb_nacc == 1 && ctx->lds_qt <= kLdsMax - 2048;
       ctx->quad_a = (v & 2) && chunks4 && ctx->tl_a && ctx->pb_threads_a == kPairBlockMax &&
-                    ctx->lds_qa <= kLdsMax - 2048;
+                    ctx->lds_qa <= kLdsMax - 2048 && ctx->lp <= 64;
+      ctx->quad_a_persist = ctx->quad_a && (v & 4);
     } else {
       throw std::invalid_argument("unknown option: " + key);
     }
