@@ -586,203 +586,7 @@ __device__ __forceinline__ void pair_block_body(const PairBlockArgs &pa,
 
 constexpr int kPairBlockMax = 512;
 
-// ======================================================================================
-// pair_quad -- pair_block for long rows (K, L ~ 50; the tile lives in LDS).  There the lane-per-
-// pair mat-vec is bound by the LDS pipe: one broadcast ds_read_b128 of the tile per two FMAs.
-// Here a workgroup (8 waves) stages the transposed input rows of ALL (up to) four 64-pair units
-// of its chunk at once (every load of the chunk in flight together), so that every tile value
-// read from LDS feeds four pairs per lane (16 FMAs per 4 + 2 LDS reads instead of 4 per 1 + 2).
-// The S slabs are accumulated unit by unit before that (the gathered eta rows of one unit at a
-// time); output rows go to memory straight from registers.  One workgroup per CU (<= ~156 KB LDS).
-// ======================================================================================
-constexpr int kQuadUnits = 4;
-constexpr int kQuadLoads = 8;  // double2 loads a thread keeps in flight while staging rows
-
-template <bool GATHER, bool DO_S, int KT>
-__global__ __launch_bounds__(kPairBlockMax) void pair_quad_kernel(PairBlockArgs pa,
-                                                                  const double *__restrict__ tiles0) {
-  constexpr int NT = kPairBlockMax;
-  const int block = blockIdx.x;
-  const size_t slot = blockIdx.y;
-  const double *__restrict__ tiles = tiles0 + slot * pa.bs_tiles;
-  const double *__restrict__ in_tab = pa.in_tab + slot * pa.bs_in;
-  const double *__restrict__ e_tab = pa.e_tab + slot * pa.bs_e;
-  const int32_t *__restrict__ pair_item = pa.pair_item;
-  double *__restrict__ out = pa.out + slot * pa.bs_out;
-  double *__restrict__ partial = pa.partial + slot * pa.bs_partial;
-  const int dinp = pa.dinp, doutp = pa.doutp, spb = pa.spb, nsub = pa.nsub;
-  extern __shared__ double lds[];
-  constexpr int CS = kUnitPairs + 1;
-  const int ustride = dinp * CS;                       // doubles per unit in cst
-  double *cst = lds;                                   // [4][dinp][CS]
-  double *tile_l = cst + static_cast<size_t>(kQuadUnits) * ustride;  // [dinp][doutp]
-  double *es = tile_l + static_cast<size_t>(dinp) * doutp;           // [64][doutp], DO_S only
-  __shared__ int32_t rowid[kQuadUnits * kUnitPairs];
-  const mmsbm::Chunk ch = pa.chunks[block];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int nch = doutp >> 2;
-  const int np_all = ch.q_end - ch.q_begin;            // <= 256 pairs, one rating
-  const int nu = (np_all + kUnitPairs - 1) / kUnitPairs;
-
-  {  // tile -> LDS; item ids of every pair of the chunk
-    const double *src = tiles + static_cast<size_t>(ch.rating) * dinp * doutp;
-    for (int t = tid * 2; t < dinp * doutp; t += NT * 2)
-      *reinterpret_cast<double2 *>(tile_l + t) = *reinterpret_cast<const double2 *>(src + t);
-    if (GATHER || DO_S)
-      if (tid < kQuadUnits * kUnitPairs) rowid[tid] = pair_item[ch.q_begin + min(tid, np_all - 1)];
-  }
-  if (GATHER) __syncthreads();
-  {  // input rows of all units -> cst (transposed)
-    const int total = np_all * dinp;
-    for (int t0 = tid * 2; t0 < total; t0 += NT * 2 * kQuadLoads) {
-      double2 v[kQuadLoads];
-      int pr[kQuadLoads], d[kQuadLoads];
-#pragma unroll
-      for (int j = 0; j < kQuadLoads; ++j) {
-        const int t = min(t0 + j * NT * 2, total - 2);
-        pr[j] = t / dinp;
-        d[j] = t - pr[j] * dinp;
-        const size_t row = GATHER ? static_cast<size_t>(rowid[pr[j]]) : static_cast<size_t>(ch.q_begin + pr[j]);
-        v[j] = *reinterpret_cast<const double2 *>(in_tab + row * dinp + d[j]);
-      }
-#pragma unroll
-      for (int j = 0; j < kQuadLoads; ++j) {
-        if (t0 + j * NT * 2 < total) {
-          double *dst = cst + (pr[j] >> 6) * ustride + d[j] * CS + (pr[j] & 63);
-          dst[0] = v[j].x;
-          dst[CS] = v[j].y;
-        }
-      }
-    }
-    // columns of pairs that do not exist (ragged last unit, missing units) read as zero
-    const int missing = kQuadUnits * kUnitPairs - np_all;
-    for (int t = tid; t < missing * dinp; t += NT) {
-      const int pr = np_all + t % missing, dd = t / missing;
-      cst[(pr >> 6) * ustride + dd * CS + (pr & 63)] = 0.0;
-    }
-  }
-  // ---- S: unit by unit (thread = (k, 4 l) slot; the copies split the unit's pairs) -------------
-  constexpr int TV = KT * 4;
-  const int nslot = (dinp / KT) * nch;
-  const int sub = tid / spb, slot0 = tid % spb;
-  const bool s_active = sub < nsub;
-  const int so = min(slot0, nslot - 1);
-  const int coff = (so / nch) * KT * CS, eoff = (so % nch) * 4;
-  double sacc[TV];
-#pragma unroll
-  for (int j = 0; j < TV; ++j) sacc[j] = 0.0;
-  if (DO_S) {
-    for (int u = 0; u < nu; ++u) {
-      const int np = min(kUnitPairs, np_all - u * kUnitPairs);
-      __syncthreads();  // cst complete (u == 0) / previous unit's eta rows consumed
-      {
-        const int total = np * doutp;
-        for (int t0 = tid * 2; t0 < total; t0 += NT * 8) {
-          double2 v[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int t = min(t0 + j * NT * 2, total - 2);
-            const int pr = t / doutp;
-            v[j] = *reinterpret_cast<const double2 *>(
-                e_tab + static_cast<size_t>(rowid[u * kUnitPairs + pr]) * doutp + (t - pr * doutp));
-          }
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int t = t0 + j * NT * 2;
-            if (t < total) *reinterpret_cast<double2 *>(es + t) = v[j];
-          }
-        }
-      }
-      __syncthreads();
-      if (s_active) {
-        const double *cu = cst + u * ustride + coff;
-#pragma unroll 2
-        for (int j = sub; j < np; j += nsub) {
-          double cv[KT];
-#pragma unroll
-          for (int i = 0; i < KT; ++i) cv[i] = cu[i * CS + j];
-          const double2 e0 = *reinterpret_cast<const double2 *>(es + j * doutp + eoff);
-          const double2 e1 = *reinterpret_cast<const double2 *>(es + j * doutp + eoff + 2);
-#pragma unroll
-          for (int i = 0; i < KT; ++i) {
-            sacc[4 * i + 0] = fma(cv[i], e0.x, sacc[4 * i + 0]);
-            sacc[4 * i + 1] = fma(cv[i], e0.y, sacc[4 * i + 1]);
-            sacc[4 * i + 2] = fma(cv[i], e1.x, sacc[4 * i + 2]);
-            sacc[4 * i + 3] = fma(cv[i], e1.y, sacc[4 * i + 3]);
-          }
-        }
-      }
-    }
-  } else {
-    __syncthreads();  // cst and the tile are complete
-  }
-  // ---- mat-vec over the four units at once: lane = pair (of each unit), wave = output chunk ----
-  for (int c = __builtin_amdgcn_readfirstlane(wave); c < nch; c += NT / 64) {
-    double a[kQuadUnits][4];
-#pragma unroll
-    for (int u = 0; u < kQuadUnits; ++u)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) a[u][j] = 0.0;
-    for (int d = 0; d < dinp; d += 2) {  // dinp is a multiple of 4
-      double2 m0[2], m1[2];
-      double x[2][kQuadUnits];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        m0[i] = *reinterpret_cast<const double2 *>(tile_l + (d + i) * doutp + c * 4);
-        m1[i] = *reinterpret_cast<const double2 *>(tile_l + (d + i) * doutp + c * 4 + 2);
-#pragma unroll
-        for (int u = 0; u < kQuadUnits; ++u) x[i][u] = cst[u * ustride + (d + i) * CS + lane];
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int u = 0; u < kQuadUnits; ++u) {
-          a[u][0] = fma(x[i][u], m0[i].x, a[u][0]);
-          a[u][1] = fma(x[i][u], m0[i].y, a[u][1]);
-          a[u][2] = fma(x[i][u], m1[i].x, a[u][2]);
-          a[u][3] = fma(x[i][u], m1[i].y, a[u][3]);
-        }
-    }
-    const int j0 = c * 4, mw = pa.out_mw;
-#pragma unroll
-    for (int u = 0; u < kQuadUnits; ++u) {
-      const int pr = u * kUnitPairs + lane;
-      if (pr < np_all) {
-        const size_t q = static_cast<size_t>(ch.q_begin + pr);
-        double *dst = j0 < mw ? out + q * mw + j0 : out + pa.out_tail_off + q * (doutp - mw) + (j0 - mw);
-        double2 w0, w1;
-        w0.x = a[u][0]; w0.y = a[u][1]; w1.x = a[u][2]; w1.y = a[u][3];
-        *reinterpret_cast<double2 *>(dst) = w0;
-        *reinterpret_cast<double2 *>(dst + 2) = w1;
-      }
-    }
-  }
-  if (DO_S) {
-    if (nsub > 1) {  // the other copies hand their sums over through LDS, added in copy order
-      __syncthreads();
-      if (s_active && sub > 0 && slot0 < nslot) {
-#pragma unroll
-        for (int j = 0; j < TV; ++j) lds[(j * (nsub - 1) + sub - 1) * nslot + slot0] = sacc[j];
-      }
-      __syncthreads();
-      if (sub == 0 && slot0 < nslot) {
-        for (int o = 1; o < nsub; ++o)
-#pragma unroll
-          for (int j = 0; j < TV; ++j) sacc[j] += lds[(j * (nsub - 1) + o - 1) * nslot + slot0];
-      }
-    }
-    if (sub == 0 && slot0 < nslot) {
-      double *cell = partial + static_cast<size_t>(block) * dinp * doutp + (slot0 / nch) * KT * doutp + eoff;
-#pragma unroll
-      for (int h = 0; h < KT; ++h) {
-        double2 x, y;
-        x.x = sacc[4 * h]; x.y = sacc[4 * h + 1]; y.x = sacc[4 * h + 2]; y.y = sacc[4 * h + 3];
-        *reinterpret_cast<double2 *>(cell + h * doutp) = x;
-        *reinterpret_cast<double2 *>(cell + h * doutp + 2) = y;
-      }
-    }
-  }
-}
+constexpr int kQuadUnits = 4;  // 64-pair units a workgroup of pair_quad_a_kernel multiplies jointly
 
 template <bool GATHER, bool DO_S, int NACC, bool TLDS, int NT, int KT, bool DIRECT>
 __global__ __launch_bounds__(NT) void pair_block_kernel(PairBlockArgs pa,
@@ -1489,10 +1293,9 @@ struct mmsbm_hip_ctx {
   int pb_spb = kBlock, pb_nacc = 1, pb_nsub = 1;  // pair_block S phase: threads per slot-grid copy, slots per thread
   size_t lds_t = 0, lds_a = 0;
   bool tl_t = false, tl_a = false;  // rating tile staged in LDS (T+S launch / A launch)
-  bool quad_t = false, quad_a = false;  // pair_quad_kernel (four units at once) for that launch
-  bool quad_a_persist = false;          // ... the A launch as a persistent prefetching pipeline
+  bool quad_a = false;  // the A launch runs pair_quad_a_kernel (long rows)
   int n_cus = 256;
-  size_t lds_qt = 0, lds_qa = 0;
+  size_t lds_qa = 0;
   mmsbm::Layout lay;  // host copy (degrees, sizes)
   DevBuf<int32_t> pair_off, pair_user, pair_item, user_off, user_pair, item_off, item_pairs,
       item_deg, mv_chunk_off, orig_u, orig_i, orig_r;
@@ -1566,10 +1369,15 @@ struct LaunchScope {  // optional event pair around one launch
 
 void use_device(const mmsbm_hip_ctx *c) { HIP_CHECK(hipSetDevice(c->device)); }
 
-// pair_quad_a -- the A launch for long rows as a PERSISTENT pipeline: one workgroup per CU walks
-// chunks blockIdx.x, + gridDim.x, ...; while it computes chunk i from LDS, the gathered rows of
-// chunk i+1 are already on their way into registers and the item ids of chunk i+2 behind them,
-// so the dependent round trips (ids -> rows) are paid once per workgroup, not once per chunk.
+// pair_quad_a -- the A launch for long rows (K, L ~ 50; the tile lives in LDS).  There the lane-per-
+// pair mat-vec of pair_block is bound by the LDS pipe: one broadcast ds_read_b128 of the tile per
+// two FMAs.  Here a workgroup (8 waves, one per CU: ~130 KB of LDS) stages the transposed input
+// rows of ALL four 64-pair units of a chunk, so that every tile value read from LDS feeds four
+// pairs per lane (16 FMAs per 4 + 2 LDS reads instead of 4 per 1 + 2), and it is a PERSISTENT
+// pipeline: it walks chunks blockIdx.x, + gridDim.x, ...; while it multiplies chunk i from LDS,
+// the gathered rows of chunk i+1 are already on their way into registers and the item ids of
+// chunk i+2 behind them, so the dependent round trips (ids -> rows) are paid once per workgroup,
+// not once per chunk.  Output rows go to memory straight from registers.
 // NL = double2 per thread per chunk: 256 pairs x dinp entries / 2 / 512 threads = dinp / 4
 template <int NL>
 __global__ __launch_bounds__(kPairBlockMax) void pair_quad_a_kernel(PairBlockArgs pa,
@@ -1850,20 +1658,6 @@ void stage_seg(mmsbm_hip_ctx *c, bool commit, bool with_users) {
 
 void stage_dense(mmsbm_hip_ctx *c) {  // T = P^T C  and the K x L slabs for p
   if (c->n_chunks == 0) return;
-  if (c->quad_t) {
-    LaunchScope ls(c, K_DENSE);
-    const int nb = static_cast<int>(c->lay.mv_chunks.size());
-    const PairBlockArgs pa = pair_block_t_args(c);
-    if (c->pb_kt == 2) {
-      allow_big_lds(pair_quad_kernel<false, true, 2>, c->lds_qt);
-      pair_quad_kernel<false, true, 2><<<slot_grid(c, nb), kPairBlockMax, c->lds_qt, c->stream>>>(pa, pa.tiles);
-    } else {
-      allow_big_lds(pair_quad_kernel<false, true, 4>, c->lds_qt);
-      pair_quad_kernel<false, true, 4><<<slot_grid(c, nb), kPairBlockMax, c->lds_qt, c->stream>>>(pa, pa.tiles);
-    }
-    ls.done();
-    return;
-  }
   {
     LaunchScope ls(c, K_DENSE);
     const int nb = static_cast<int>(c->lay.mv_chunks.size());
@@ -1917,7 +1711,7 @@ void stage_eta_p(mmsbm_hip_ctx *c, bool commit) {  // eta_new ; p_new, pT_new, r
 void stage_matvec_a(mmsbm_hip_ctx *c, int slot, int a_slot) {
   if (c->n_chunks == 0) return;
   LaunchScope ls(c, K_MATVEC_A);
-  if (c->quad_a && c->quad_a_persist) {
+  if (c->quad_a) {
     const int nb = static_cast<int>(c->lay.mv_chunks.size());
     const PairBlockArgs pa = pair_block_a_args(c, slot, a_slot);
     const dim3 grid = slot_grid(c, std::min(nb, c->n_cus));
@@ -1930,11 +1724,6 @@ void stage_matvec_a(mmsbm_hip_ctx *c, int slot, int a_slot) {
     if (nl <= 8) QA(8); else if (nl <= 10) QA(10); else if (nl <= 12) QA(12);
     else if (nl <= 13) QA(13); else if (nl <= 14) QA(14); else QA(16);
 #undef QA
-  } else if (c->quad_a) {
-    const int nb = static_cast<int>(c->lay.mv_chunks.size());
-    const PairBlockArgs pa = pair_block_a_args(c, slot, a_slot);
-    allow_big_lds(pair_quad_kernel<true, false, 4>, c->lds_qa);
-    pair_quad_kernel<true, false, 4><<<slot_grid(c, nb), kPairBlockMax, c->lds_qa, c->stream>>>(pa, pa.tiles);
   } else {
     const int nb = static_cast<int>(c->lay.mv_chunks.size());
     const PairBlockArgs pa = pair_block_a_args(c, slot, a_slot);
@@ -2276,20 +2065,12 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
     // pair_block launches); short rows are cheaper transposed through LDS and copied out flat
     // (C3: direct stores cost +1.1 / +1.7 us)
     c->direct_out = c->kp * c->lp > 1024;
-    // ... and four units at a time where the tile sits in LDS and everything fits (pair_quad_kernel)
-    {
-      const bool chunks4 = c->kp * c->lp > 1024;
-      auto quad_lds = [](int dinp, int doutp, bool with_s) {
-        return (static_cast<size_t>(kQuadUnits) * dinp * (kUnitPairs + 1) + static_cast<size_t>(dinp) * doutp +
-                (with_s ? static_cast<size_t>(kUnitPairs) * doutp : 0)) * sizeof(double);
-      };
-      c->lds_qt = quad_lds(c->kp, c->lp, true);
-      c->lds_qa = quad_lds(c->lp, c->kp, false);
-      c->quad_t = false;  // measured slower than pair_block at C5 (605 vs 560 us); option "quad" bit 0
-      c->quad_a = chunks4 && c->tl_a && c->pb_threads_a == kPairBlockMax && c->lds_qa <= kLdsMax - 2048 &&
-                  c->lp <= 64;
-      c->quad_a_persist = c->quad_a;
-    }
+    // ... and the A launch as a persistent four-unit pipeline where the tile sits in LDS and
+    // everything fits (C5: 312 -> 259 us)
+    c->lds_qa = (static_cast<size_t>(kQuadUnits) * c->lp * (kUnitPairs + 1) + static_cast<size_t>(c->lp) * c->kp) *
+                sizeof(double);
+    c->quad_a = c->kp * c->lp > 1024 && c->tl_a && c->pb_threads_a == kPairBlockMax &&
+                c->lds_qa <= kLdsMax - 2048 && c->lp <= 64;
     c->n_pairs = c->lay.n_pairs;
     c->n_chunks = static_cast<int>(c->lay.mv_chunks.size());
 
@@ -2922,14 +2703,9 @@ int mmsbm_hip_set_option(mmsbm_hip_ctx *ctx, const char *name, double value) {
       ctx->lik_g = g;
     } else if (key == "direct") {
       ctx->direct_out = value != 0.0;
-    } else if (key == "quad") {  // bit 0: T+S launch, bit 1: A launch (only where create() allowed it)
-      const int v = static_cast<int>(value);
-      const bool chunks4 = ctx->kp * ctx->lp > 1024;
-      ctx->quad_t = (v & 1) && chunks4 && ctx->tl_t && ctx->pb_threads_t == kPairBlockMax &&
-                    ctx->pb_nacc == 1 && ctx->lds_qt <= kLdsMax - 2048;
-      ctx->quad_a = (v & 2) && chunks4 && ctx->tl_a && ctx->pb_threads_a == kPairBlockMax &&
-                    ctx->lds_qa <= kLdsMax - 2048 && ctx->lp <= 64;
-      ctx->quad_a_persist = ctx->quad_a && (v & 4);
+    } else if (key == "quad") {  // 0: the A launch through pair_block like every other shape
+      ctx->quad_a = value != 0.0 && ctx->kp * ctx->lp > 1024 && ctx->tl_a &&
+                    ctx->pb_threads_a == kPairBlockMax && ctx->lds_qa <= kLdsMax - 2048 && ctx->lp <= 64;
     } else {
       throw std::invalid_argument("unknown option: " + key);
     }
