@@ -24,42 +24,64 @@ struct Chunk {  // one workgroup's share of the pairs of ONE rating
   int32_t rating, q_begin, q_end, pad;
 };
 
-// A long segment (a heavy user, a popular (item, rating) pair) is cut into work items of at
-// most kMaxItemLen triples so that no group of lanes walks it alone; the items' partial sums
-// are combined afterwards in item order (deterministic).
+// A segment (the triples of a user, or of an (item, rating) pair) is walked by ONE group of lanes.
+// Where that would leave too little parallelism -- few, long segments: dense data such as 6,000
+// users with 165 ratings each -- or one segment would dominate (a heavy user), segments are cut
+// into work items of at most `item_len` triples; the items' partial sums are combined afterwards
+// in item order (deterministic).
 struct WorkItem {
   int32_t seg, begin, end, part;  // part = slot of the partial row, or -1: the item IS the segment
 };
 struct SplitSeg {
   int32_t seg, first_part, n_parts, pad;
 };
-constexpr int32_t kMaxItemLen = 64;
+constexpr int32_t kMaxItemLen = 64;       // default cut
+constexpr int64_t kTargetUnits = 65536;   // groups of lanes needed to keep the chip busy
+constexpr int32_t kSmallSplitParts = 32;  // split segments with at most this many pieces are summed by one group
 
-struct WorkList {  // empty items == no segment is longer than kMaxItemLen: use the segments as they are
+struct WorkList {  // empty items == no segment is longer than item_len: use the segments as they are
   std::vector<WorkItem> items;
-  std::vector<SplitSeg> splits;
-  int32_t n_parts = 0;
+  std::vector<SplitSeg> splits;  // those with <= kSmallSplitParts pieces first (n_small of them), then the rest
+  int32_t n_parts = 0, n_small = 0, item_len = kMaxItemLen;
 };
 
-inline void build_worklist(const std::vector<int32_t> &off, WorkList &w) {
+// Triples per work item for `nseg` segments holding `n_obs` triples in all.
+inline int32_t item_length(int64_t n_obs, int32_t nseg) {
+  if (nseg <= 0) return kMaxItemLen;
+  const int64_t mean = std::max<int64_t>(n_obs / nseg, 1);
+  // enough segments to fill the machine: cut only the outliers (load balance)
+  if (nseg >= kTargetUnits) return int32_t(std::min<int64_t>(std::max<int64_t>(kMaxItemLen, 4 * mean), 1 << 20));
+  // few segments.  Short ones: cutting adds nothing but the outliers' balance ...
+  if (mean <= 16) return kMaxItemLen;
+  // ... long ones: cut towards kTargetUnits work items, not below 16 triples
+  int64_t want = std::max<int64_t>(n_obs / kTargetUnits, 16), len = 16;
+  while (len * 2 <= want) len *= 2;
+  return int32_t(std::min<int64_t>(len, 1 << 20));
+}
+
+inline void build_worklist(const std::vector<int32_t> &off, WorkList &w, int32_t item_len = kMaxItemLen) {
   w = WorkList();
+  w.item_len = item_len;
   const int32_t nseg = int32_t(off.size()) - 1;
   bool any = false;
-  for (int32_t s = 0; s < nseg && !any; ++s) any = off[s + 1] - off[s] > kMaxItemLen;
+  for (int32_t s = 0; s < nseg && !any; ++s) any = off[s + 1] - off[s] > item_len;
   if (!any) return;
+  std::vector<SplitSeg> big;
   for (int32_t s = 0; s < nseg; ++s) {
     const int32_t len = off[s + 1] - off[s];
-    if (len <= kMaxItemLen) {
+    if (len <= item_len) {
       w.items.push_back(WorkItem{s, off[s], off[s + 1], -1});
       continue;
     }
-    const int32_t parts = (len + kMaxItemLen - 1) / kMaxItemLen;
-    w.splits.push_back(SplitSeg{s, w.n_parts, parts, 0});
+    const int32_t parts = (len + item_len - 1) / item_len;
+    (parts <= kSmallSplitParts ? w.splits : big).push_back(SplitSeg{s, w.n_parts, parts, 0});
     for (int32_t j = 0; j < parts; ++j)
-      w.items.push_back(WorkItem{s, off[s] + j * kMaxItemLen,
-                                 std::min(off[s] + (j + 1) * kMaxItemLen, off[s + 1]), w.n_parts + j});
+      w.items.push_back(WorkItem{s, off[s] + j * item_len,
+                                 std::min(off[s] + (j + 1) * item_len, off[s + 1]), w.n_parts + j});
     w.n_parts += parts;
   }
+  w.n_small = int32_t(w.splits.size());
+  w.splits.insert(w.splits.end(), big.begin(), big.end());
 }
 
 struct Layout {
@@ -206,8 +228,8 @@ inline void build_layout(int64_t n_obs, int32_t n_users, int32_t n_items, int32_
     L.chunk_off[r + 1] = int32_t(L.chunks.size());
   }
   build_mv_chunks(L, kMvChunkPairs);
-  build_worklist(L.pair_off, L.pair_work);
-  build_worklist(L.user_off, L.user_work);
+  build_worklist(L.pair_off, L.pair_work, item_length(n_obs, L.n_pairs));
+  build_worklist(L.user_off, L.user_work, item_length(n_obs, n_users));
 }
 
 }  // namespace mmsbm

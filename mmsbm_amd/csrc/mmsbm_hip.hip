@@ -325,6 +325,42 @@ __global__ __launch_bounds__(kBlock) void seg_combine_kernel(CombineArgs ca, Com
   store_vec<VEC>(rowtab_ptr(slot_tab(a.out, a.bs_out), sp.seg, lane_off), o);
 }
 
+// Split segments with few pieces (the usual case when MANY segments are cut: dense data): one group
+// of lanes per split segment adds its pieces in piece order, four loads in flight.
+template <int G, int VEC>
+__global__ __launch_bounds__(kBlock) void seg_combine_small_kernel(CombineArgs ca, CombineArgs cb,
+                                                                   int blocks_a, int dp) {
+  const bool first = static_cast<int>(blockIdx.x) < blocks_a;
+  const CombineArgs &a = first ? ca : cb;
+  const int blk = first ? blockIdx.x : blockIdx.x - blocks_a;
+  const int w = blk * (kBlock / G) + threadIdx.x / G, gl = threadIdx.x % G;
+  if (w >= a.n_splits || gl * VEC >= dp) return;
+  const int lane_off = gl * VEC;
+  const mmsbm::SplitSeg sp = a.splits[w];
+  const double *parts = a.parts + blockIdx.y * a.bs_parts + static_cast<size_t>(sp.first_part) * dp + lane_off;
+  double acc[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) acc[v] = 0.0;
+  for (int j0 = 0; j0 < sp.n_parts; j0 += 4) {
+    double t[4][VEC];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) load_vec<VEC>(parts + static_cast<size_t>(min(j0 + i, sp.n_parts - 1)) * dp, t[i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (j0 + i < sp.n_parts) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] += t[i][v];
+      }
+  }
+  double f[VEC], o[VEC];
+  load_vec<VEC>(rowtab_ptr(slot_tab(a.fixed, a.bs_fixed), sp.seg, lane_off), f);
+  const double d = static_cast<double>(max(a.off[sp.seg + 1] - a.off[sp.seg], 1));
+#pragma unroll
+  for (int v = 0; v < VEC; ++v)
+    o[v] = a.mode == 0 ? acc[v] : (a.mode == 1 ? (f[v] * acc[v]) / d : f[v] * acc[v]);
+  store_vec<VEC>(rowtab_ptr(slot_tab(a.out, a.bs_out), sp.seg, lane_off), o);
+}
+
 // ======================================================================================
 // pair_block -- the fused dense stage.  A block takes a unit of <= 64 consecutive pairs of
 // ONE rating (more if its chunk is longer) and, per unit, stages in LDS (coalesced flat copies;
@@ -1640,16 +1676,30 @@ void stage_seg(mmsbm_hip_ctx *c, bool commit, bool with_users) {
 #undef CALL
   }
   // long segments were processed in pieces: add the pieces up (fixed order) and finish them
-  const int nsp = static_cast<int>(c->lay.pair_work.splits.size());
-  const int nsu = with_users ? static_cast<int>(c->lay.user_work.splits.size()) : 0;
-  if (nsp + nsu > 0) {
-    const CombineArgs cp{c->pair_splits.ptr, sp.parts, c->pair_off.ptr, sp.fixed, sp.out, nsp,
+  // (splits with few pieces come first in the lists: one group of lanes each; the rest: a workgroup each)
+  const mmsbm::WorkList &wp = c->lay.pair_work, &wu = c->lay.user_work;
+  const int nsp_s = wp.n_small, nsp_b = static_cast<int>(wp.splits.size()) - wp.n_small;
+  const int nsu_s = with_users ? wu.n_small : 0;
+  const int nsu_b = with_users ? static_cast<int>(wu.splits.size()) - wu.n_small : 0;
+  if (nsp_s + nsu_s > 0) {
+    const CombineArgs cp{c->pair_splits.ptr, sp.parts, c->pair_off.ptr, sp.fixed, sp.out, nsp_s,
                          sp.mode, sp.bs_parts, sp.bs_fixed, sp.bs_out};
-    const CombineArgs cu{c->user_splits.ptr, su.parts, c->user_off.ptr, su.fixed, su.out, nsu,
+    const CombineArgs cu{c->user_splits.ptr, su.parts, c->user_off.ptr, su.fixed, su.out, nsu_s,
+                         su.mode, su.bs_parts, su.bs_fixed, su.bs_out};
+    const int ba = (nsp_s + per - 1) / per, bb = (nsu_s + per - 1) / per;
+#define CALL(G, V) \
+  seg_combine_small_kernel<G, V><<<slot_grid(c, ba + bb), kBlock, 0, c->stream>>>(cp, cu, ba, c->kp)
+    DISPATCH_GV(c->code_k, CALL);
+#undef CALL
+  }
+  if (nsp_b + nsu_b > 0) {
+    const CombineArgs cp{c->pair_splits.ptr + wp.n_small, sp.parts, c->pair_off.ptr, sp.fixed, sp.out, nsp_b,
+                         sp.mode, sp.bs_parts, sp.bs_fixed, sp.bs_out};
+    const CombineArgs cu{c->user_splits.ptr + wu.n_small, su.parts, c->user_off.ptr, su.fixed, su.out, nsu_b,
                          su.mode, su.bs_parts, su.bs_fixed, su.bs_out};
     const size_t lds = static_cast<size_t>(per) * c->kp * sizeof(double);
 #define CALL(G, V) \
-  seg_combine_kernel<G, V><<<slot_grid(c, nsp + nsu), kBlock, lds, c->stream>>>(cp, cu, nsp, c->kp)
+  seg_combine_kernel<G, V><<<slot_grid(c, nsp_b + nsu_b), kBlock, lds, c->stream>>>(cp, cu, nsp_b, c->kp)
     DISPATCH_GV(c->code_k, CALL);
 #undef CALL
   }

@@ -39,7 +39,7 @@ static void check(const std::vector<int32_t> &u, const std::vector<int32_t> &i, 
     const auto &off = (w == &L.pair_work) ? L.pair_off : L.user_off;
     std::vector<int> seen(static_cast<size_t>(n), 0);
     for (const auto &it : w->items) {
-      CHECK(it.end - it.begin <= mmsbm::kMaxItemLen && it.begin <= it.end);  // empty segments keep an (empty) item: their output row must still be written
+      CHECK(it.end - it.begin <= w->item_len && it.begin <= it.end);  // empty segments keep an (empty) item: their output row must still be written
       CHECK(off[it.seg] <= it.begin && it.end <= off[it.seg + 1]);
       CHECK(it.part < w->n_parts);
       for (int t = it.begin; t < it.end; ++t) seen[t]++;

@@ -897,3 +897,34 @@ def test_many_or_single_rating_values(hip, n_r, k, l):
             ref = orc.score_stats(orc.prod_dist(test, t, e, p), test[:, 2], list(range(n_r)))
             assert st["s2"] == ref["s2"] or rel_err(em.prod_dist(test), orc.prod_dist(test, t, e, p)) < 1e-11
             em.predict_finish()
+
+
+def test_dense_data_many_split_segments(hip):
+    """Dense data (few users/items, hundreds of ratings each, the MovieLens regime): every segment is
+    cut into 16-triple work items and summed by the one-group-per-segment combine; plus one heavy
+    user whose pieces go through the workgroup combine.  Parity with the oracle, reproducible."""
+    rng = np.random.default_rng(31)
+    n, n_u, n_i, n_r, k, l = 60_000, 300, 200, 5, 10, 12
+    u = np.where(rng.random(n) < 0.15, 11, rng.integers(0, n_u, n))       # user 11: ~9,000 rows -> > 32 pieces
+    data = np.stack([u, rng.integers(0, n_i, n), rng.integers(0, n_r, n)], axis=1).astype(np.int64)
+    d_u, d_i = orc.degrees(data, n_u, n_i)
+    assert d_u.max() > 32 * 16 and np.median(d_u) > 100
+    lay = hip.core.build_layout(data, n_u, n_i, n_r)
+    pieces = lay["user_splits"][:, 2]
+    assert (pieces <= 32).sum() > 250 and (pieces > 32).sum() >= 1        # both combine kernels run
+    theta, eta, pr = orc.init_params(8, n_u, n_i, n_r, k, l, d_u, d_i)
+    want = orc.update_coefficients(data, theta, eta, pr)
+    t, e, p = theta, eta, pr
+    for _ in range(3):
+        t, e, p = orc.em_step(data, t, e, p, d_u, d_i)
+    outs = []
+    for swap in (0, 1, 0):
+        with make_ctx(hip, data, theta, eta, pr, swap_sides=swap) as em:
+            for got, w, nm in zip(em.update_coefficients(), want, ("n_theta", "n_eta", "n_pr")):
+                assert rel_err(got, w) < TOL_STEP, nm
+            em.iterate(3)
+            outs.append(em.get_params())
+            for got, w, nm in zip(outs[-1], (t, e, p), ("theta", "eta", "pr")):
+                assert rel_err(got, w) < 1e-11, nm
+    for a, b in zip(outs[0], outs[2]):
+        assert np.array_equal(a, b)

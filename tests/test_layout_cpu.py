@@ -110,31 +110,78 @@ def test_factorised_form_edge_cases():
             assert np.allclose(a, want, rtol=1e-12, atol=1e-300), (tag, nm)
 
 
+def item_length(n_obs, nseg):
+    """The cut policy of layout.hpp (item_length), restated."""
+    mean = max(n_obs // nseg, 1)
+    if nseg >= 65536:
+        return min(max(64, 4 * mean), 1 << 20)
+    if mean <= 16:
+        return 64
+    want, length = max(n_obs // 65536, 16), 16
+    while length * 2 <= want:
+        length *= 2
+    return length
+
+
+def check_worklist(lay, which, off, cut):
+    items, splits = lay[f"{which}_items"], lay[f"{which}_splits"]
+    lens = np.diff(off)
+    if lens.max() <= cut:
+        assert len(items) == 0 and len(splits) == 0
+        return 0
+    assert np.all(items[:, 2] - items[:, 1] <= cut) and np.all(items[:, 2] >= items[:, 1])
+    cover = np.zeros(off[-1], dtype=int)                  # the items tile every segment exactly
+    np.add.at(cover, np.concatenate([np.arange(b, e) for _, b, e, _ in items]) if len(items) else [], 1)
+    assert np.all(cover == 1)
+    for seg, b, e, part in items[:: max(1, len(items) // 500)]:
+        assert off[seg] <= b and e <= off[seg + 1] and (part >= 0) == (lens[seg] > cut)
+    assert sorted(splits[:, 0].tolist()) == np.nonzero(lens > cut)[0].tolist()
+    pieces = splits[:, 2]
+    assert np.array_equal(pieces, -(-lens[splits[:, 0]] // cut))
+    small = pieces <= 32                                   # few pieces first, then the rest
+    n_small = int(small.sum())
+    assert small[:n_small].all() and not small[n_small:].any()
+    for seg, first, cnt, _ in splits[:: max(1, len(splits) // 200)]:
+        mine = items[items[:, 0] == seg]
+        assert mine[:, 3].tolist() == list(range(first, first + cnt))
+    return len(splits)
+
+
 def test_long_segments_become_work_items():
-    """Heavy users / popular pairs are cut into pieces of <= 64 triples, combined in piece order."""
+    """Heavy users / popular pairs are cut into pieces, combined in piece order."""
     rng = np.random.default_rng(9)
     n = 5000
     u = np.where(rng.random(n) < 0.4, 3, rng.integers(0, 300, n))      # user 3 holds ~40 % of the rows
     i = np.where(rng.random(n) < 0.3, 1, rng.integers(0, 40, n))
     data = np.stack([u, i, rng.integers(0, 3, n)], axis=1).astype(np.int64)
     lay = build_layout(data, 300, 40, 3)
-    for which, off in (("user", lay["user_off"]), ("pair", lay["pair_off"])):
-        items, splits = lay[f"{which}_items"], lay[f"{which}_splits"]
-        lens = np.diff(off)
-        assert lens.max() > 64 and len(items) > len(lens)
-        assert np.all(items[:, 2] - items[:, 1] <= 64) and np.all(items[:, 2] >= items[:, 1])
-        # the items tile every non-empty segment exactly, in order
-        cover = np.zeros(off[-1], dtype=int)
-        for seg, b, e, part in items:
-            assert off[seg] <= b < e <= off[seg + 1]
-            cover[b:e] += 1
-            assert (part >= 0) == (lens[seg] > 64)
-        assert np.all(cover == 1)
-        assert sorted(splits[:, 0].tolist()) == np.nonzero(lens > 64)[0].tolist()
-        for seg, first, cnt, _ in splits:
-            assert cnt == -(-lens[seg] // 64)
-            mine = items[items[:, 0] == seg]
-            assert mine[:, 3].tolist() == list(range(first, first + cnt))
-    # uniform data: no items at all (segments are used as they are)
+    assert check_worklist(lay, "user", lay["user_off"], item_length(n, 300)) > 0
+    assert check_worklist(lay, "pair", lay["pair_off"], item_length(n, len(lay["pair_item"]))) > 0
+    # uniform sparse data: no items at all (segments are used as they are)
     flat = build_layout(random_triples(rng, 3000, 400, 50, 4), 400, 50, 4)
     assert len(flat["user_items"]) == 0 and len(flat["pair_splits"]) == 0
+
+
+def test_cut_policy_for_sparse_dense_and_skewed_data():
+    """Sparse data with many segments (BASELINE's configs): nothing is cut.  Dense data (few users
+    with hundreds of ratings each): cut towards 65,536 work items, never below 16 triples.  Many
+    segments plus a heavy one: only the outlier is cut."""
+    assert item_length(1_000_000, 100_000) == 64 and item_length(10_000_000, 1_000_000) == 64
+    assert item_length(100_000, 10_000) == 64                       # C2: short segments, leave them
+    assert item_length(1_000_000, 6040) == 16 and item_length(20_000_000, 27_000) == 256
+    assert item_length(20_000_000, 138_000) == 4 * 144
+    rng = np.random.default_rng(4)
+    dense = random_triples(rng, 60_000, 400, 300, 5)                # 150 ratings per user
+    lay = build_layout(dense, 400, 300, 5)
+    cut = item_length(60_000, 400)
+    assert cut == 16
+    n_split = check_worklist(lay, "user", lay["user_off"], cut)
+    assert n_split >= 390 and len(lay["user_items"]) >= 60_000 // 16
+    check_worklist(lay, "pair", lay["pair_off"], item_length(60_000, len(lay["pair_item"])))
+    many = random_triples(rng, 700_000, 70_000, 5_000, 5)           # >= 65,536 users, 10 ratings each
+    many[:40_000, 0] = 7                                            # ... and one with 40,000
+    lay = build_layout(many, 70_000, 5_000, 5)
+    cut = item_length(700_000, 70_000)
+    assert cut == 64
+    assert check_worklist(lay, "user", lay["user_off"], cut) == 1
+    assert lay["user_splits"][0, 2] == -(-np.diff(lay["user_off"])[7] // 64) > 32
