@@ -16,6 +16,7 @@
 #include <cstdint>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace mmsbm {
@@ -123,6 +124,63 @@ inline void build_mv_chunks(Layout &L, int32_t pairs) {
   }
 }
 
+// Host threads for the sorts below: one for small inputs, up to 8 for millions of triples.
+inline int &layout_threads_override() {  // tests: force a thread count (0 = automatic)
+  static int v = 0;
+  return v;
+}
+inline int layout_threads(int64_t n_obs) {
+  if (layout_threads_override() > 0) return layout_threads_override();
+  if (n_obs < (int64_t(1) << 20)) return 1;
+  return int(std::min<unsigned>(8, std::max<unsigned>(1, std::thread::hardware_concurrency())));
+}
+
+// fn(t, begin, end) over `threads` contiguous slices of [0, n)
+template <class F>
+inline void parallel_slices(int64_t n, int threads, F &&fn) {
+  if (threads <= 1) {
+    fn(0, int64_t(0), n);
+    return;
+  }
+  std::vector<std::thread> th;
+  const int64_t per = (n + threads - 1) / threads;
+  for (int t = 0; t < threads; ++t) {
+    const int64_t a = std::min<int64_t>(n, t * per), b = std::min<int64_t>(n, a + per);
+    th.emplace_back([&fn, t, a, b] { fn(t, a, b); });
+  }
+  for (auto &x : th) x.join();
+}
+
+// Stable counting sort of the elements j = 0..n-1 by key(j) in [0, nkeys): calls emit(j, position)
+// with the element's rank; `totals` (nkeys + 1) receives the exclusive prefix sums of the key
+// counts.  Slices of the input get private histograms, so threads never share a counter and
+// the order of equal keys is the input order.
+template <class KeyFn, class EmitFn>
+inline void counting_sort(int64_t n, size_t nkeys, int threads, KeyFn &&key, EmitFn &&emit,
+                          std::vector<int32_t> &totals) {
+  while (threads > 1 && uint64_t(threads) * nkeys > (uint64_t(1) << 26)) threads /= 2;  // <= 256 MB of counters
+  std::vector<std::vector<uint32_t>> hist(size_t(threads), std::vector<uint32_t>(nkeys, 0));
+  parallel_slices(n, threads, [&](int t, int64_t a, int64_t b) {
+    uint32_t *h = hist[size_t(t)].data();
+    for (int64_t j = a; j < b; ++j) h[key(j)]++;
+  });
+  totals.assign(nkeys + 1, 0);
+  uint32_t run = 0;
+  for (size_t k = 0; k < nkeys; ++k) {  // histogram -> first position of (key k, slice t)
+    totals[k] = int32_t(run);
+    for (int t = 0; t < threads; ++t) {
+      const uint32_t c = hist[size_t(t)][k];
+      hist[size_t(t)][k] = run;
+      run += c;
+    }
+  }
+  totals[nkeys] = int32_t(run);
+  parallel_slices(n, threads, [&](int t, int64_t a, int64_t b) {
+    uint32_t *h = hist[size_t(t)].data();
+    for (int64_t j = a; j < b; ++j) emit(j, int64_t(h[key(j)]++));
+  });
+}
+
 inline void build_layout(int64_t n_obs, int32_t n_users, int32_t n_items, int32_t n_ratings,
                          const int32_t *user, const int32_t *item, const int32_t *rating,
                          int32_t target_chunks, Layout &out) {
@@ -132,10 +190,19 @@ inline void build_layout(int64_t n_obs, int32_t n_users, int32_t n_items, int32_
     throw std::invalid_argument("n_users, n_items and n_ratings must be positive");
   if (n_obs > 0 && (!user || !item || !rating))
     throw std::invalid_argument("null triple array");
-  for (int64_t n = 0; n < n_obs; ++n) {
-    if (user[n] < 0 || user[n] >= n_users || item[n] < 0 || item[n] >= n_items ||
-        rating[n] < 0 || rating[n] >= n_ratings)
-      throw std::invalid_argument("triple " + std::to_string(n) + " has an id out of range");
+  const int threads = layout_threads(n_obs);
+  {
+    std::vector<int64_t> bad(size_t(threads), -1);  // first offending triple of each slice
+    parallel_slices(n_obs, threads, [&](int t, int64_t a, int64_t b) {
+      for (int64_t n = a; n < b; ++n)
+        if (user[n] < 0 || user[n] >= n_users || item[n] < 0 || item[n] >= n_items ||
+            rating[n] < 0 || rating[n] >= n_ratings) {
+          bad[size_t(t)] = n;
+          return;
+        }
+    });
+    for (int64_t n : bad)
+      if (n >= 0) throw std::invalid_argument("triple " + std::to_string(n) + " has an id out of range");
   }
   Layout &L = out;
   L = Layout();
@@ -149,20 +216,17 @@ inline void build_layout(int64_t n_obs, int32_t n_users, int32_t n_items, int32_
   const uint64_t key_space = uint64_t(n_ratings) * uint64_t(n_items);
   if (key_space <= (uint64_t(1) << 26)) {
     std::vector<uint32_t> by_user(static_cast<size_t>(n_obs));
-    {
-      std::vector<int64_t> cnt(size_t(n_users) + 1, 0);
-      for (int64_t n = 0; n < n_obs; ++n) cnt[size_t(user[n]) + 1]++;
-      for (int u = 0; u < n_users; ++u) cnt[u + 1] += cnt[u];
-      for (int64_t n = 0; n < n_obs; ++n) by_user[size_t(cnt[user[n]]++)] = uint32_t(n);
-    }
-    std::vector<int64_t> cnt(size_t(key_space) + 1, 0);
-    for (int64_t n = 0; n < n_obs; ++n) cnt[size_t(rating[n]) * n_items + item[n] + 1]++;
-    for (uint64_t k = 0; k < key_space; ++k) cnt[k + 1] += cnt[k];
-    for (int64_t j = 0; j < n_obs; ++j) {
-      const uint32_t n = by_user[size_t(j)];
-      const uint64_t pk = uint64_t(rating[n]) * uint64_t(n_items) + uint64_t(item[n]);
-      keys[size_t(cnt[pk]++)] = Key{pk, uint32_t(user[n])};
-    }
+    std::vector<int32_t> unused;
+    counting_sort(n_obs, size_t(n_users), threads, [&](int64_t n) { return size_t(user[n]); },
+                  [&](int64_t n, int64_t pos) { by_user[size_t(pos)] = uint32_t(n); }, unused);
+    auto pk_of = [&](uint32_t n) { return uint64_t(rating[n]) * uint64_t(n_items) + uint64_t(item[n]); };
+    counting_sort(n_obs, size_t(key_space), threads,
+                  [&](int64_t j) { return size_t(pk_of(by_user[size_t(j)])); },
+                  [&](int64_t j, int64_t pos) {
+                    const uint32_t n = by_user[size_t(j)];
+                    keys[size_t(pos)] = Key{pk_of(n), uint32_t(user[n])};
+                  },
+                  unused);
   } else {
     for (int64_t n = 0; n < n_obs; ++n)
       keys[n] = Key{uint64_t(rating[n]) * uint64_t(n_items) + uint64_t(item[n]), uint32_t(user[n])};
@@ -192,14 +256,9 @@ inline void build_layout(int64_t n_obs, int32_t n_users, int32_t n_items, int32_
   for (int r = 0; r < n_ratings; ++r) L.rating_off[r + 1] = L.rating_off[r] + pairs_per_rating[r];
 
   // ---- user order: stable counting sort of the pair-ordered triples by user ---------
-  L.user_off.assign(size_t(n_users) + 1, 0);
-  for (int64_t n = 0; n < n_obs; ++n) L.user_off[size_t(L.pair_user[n]) + 1]++;
-  for (int u = 0; u < n_users; ++u) L.user_off[u + 1] += L.user_off[u];
   L.user_pair.resize(n_obs);
-  {
-    std::vector<int32_t> cur(L.user_off.begin(), L.user_off.end() - 1);
-    for (int64_t n = 0; n < n_obs; ++n) L.user_pair[cur[L.pair_user[n]]++] = triple_pair[n];
-  }
+  counting_sort(n_obs, size_t(n_users), threads, [&](int64_t n) { return size_t(L.pair_user[size_t(n)]); },
+                [&](int64_t n, int64_t pos) { L.user_pair[size_t(pos)] = triple_pair[size_t(n)]; }, L.user_off);
 
   // ---- pairs of each item + item degrees ----------------------------------------------
   L.item_off.assign(size_t(n_items) + 1, 0);

@@ -65,6 +65,32 @@ int main() {
     }
     check(u, i, r, U, I, R, 1 + static_cast<int>(rng() % 50));
   }
+  {  // the threaded sorts (forced on a mid-sized input) must give exactly the single-thread layout
+    const int n = 300000, U = 5000, I = 700, R = 6;
+    std::vector<int32_t> u(n), i(n), r(n);
+    for (int t = 0; t < n; ++t) {
+      u[t] = (rng() % 5 == 0) ? 3 : static_cast<int32_t>(rng() % U);
+      i[t] = static_cast<int32_t>(rng() % I);
+      r[t] = static_cast<int32_t>(rng() % R);
+    }
+    mmsbm::Layout a, b, c;
+    mmsbm::layout_threads_override() = 1;
+    mmsbm::build_layout(n, U, I, R, u.data(), i.data(), r.data(), 64, a);
+    mmsbm::layout_threads_override() = 8;
+    mmsbm::build_layout(n, U, I, R, u.data(), i.data(), r.data(), 64, b);
+    mmsbm::layout_threads_override() = 3;
+    mmsbm::build_layout(n, U, I, R, u.data(), i.data(), r.data(), 64, c);
+    mmsbm::layout_threads_override() = 0;
+    for (const mmsbm::Layout *x : {&b, &c}) {
+      CHECK(a.pair_off == x->pair_off && a.pair_user == x->pair_user && a.pair_item == x->pair_item);
+      CHECK(a.user_off == x->user_off && a.user_pair == x->user_pair && a.rating_off == x->rating_off);
+      CHECK(a.item_off == x->item_off && a.item_pairs == x->item_pairs && a.item_deg == x->item_deg);
+    }
+    check(u, i, r, U, I, R, 64);
+    mmsbm::layout_threads_override() = 8;
+    check(u, i, r, U, I, R, 64);
+    mmsbm::layout_threads_override() = 0;
+  }
   check({}, {}, {}, 3, 2, 2, 8);            // empty
   check({0}, {0}, {0}, 1, 1, 1, 1);          // single triple
   {                                          // invalid ids must throw, not scribble

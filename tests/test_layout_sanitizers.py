@@ -14,7 +14,7 @@ def test_layout_builder_under_asan_ubsan(tmp_path):
     exe = tmp_path / "layout_sanitize"
     src = os.path.join(ROOT, "tests", "native", "layout_sanitize.cpp")
     build = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined",
-                            "-fno-sanitize-recover=all", "-o", str(exe), src],
+                            "-fno-sanitize-recover=all", "-pthread", "-o", str(exe), src],
                            capture_output=True, text=True)
     assert build.returncode == 0, build.stderr[-3000:]
     run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300,
