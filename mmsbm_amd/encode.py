@@ -31,15 +31,16 @@ def _as_str(col):
     return np.array([str(v) for v in col], dtype=object).astype(str) if len(col) else np.array([], dtype=str)
 
 
-def _factorize_as_str(col):
+def _factorize_as_str(col, out=None):
     """(ids, labels): labels = sorted distinct str(value); ids[n] = rank of str(col[n]).
 
     Hash-factorises the raw values first (pandas, O(N)) and stringifies only the distinct
-    ones, so a million-row column costs milliseconds instead of a Python call per cell."""
+    ones, so a million-row column costs milliseconds instead of a Python call per cell.
+    ``out``: optional int32 array the ids are written into (no temporaries)."""
     import pandas as pd
 
     if len(col) == 0:
-        return np.zeros(0, dtype=np.int64), np.array([], dtype=str)
+        return np.zeros(0, dtype=np.int32), np.array([], dtype=str)
     col = np.asarray(col)
     if col.dtype.kind in "US":  # fixed-width numpy strings hash slowly: go through object
         col = col.astype(object)
@@ -48,7 +49,11 @@ def _factorize_as_str(col):
         raise AssertionError("Data contains missing values. Aborting.")  # data_handler.py:24
     as_str = np.array([str(v) for v in uniq.tolist()], dtype=object).astype(str)
     labels, inv = np.unique(as_str, return_inverse=True)  # distinct raw values may share a string
-    return inv[codes].astype(np.int64), labels
+    inv = inv.astype(np.int32)
+    if out is None:
+        return inv[codes], labels
+    np.take(inv, codes, out=out)
+    return out, labels
 
 
 class Encoder:
@@ -58,13 +63,15 @@ class Encoder:
         self.labels = None  # three sorted arrays of str: id -> original label
 
     def fit_transform(self, data):
+        """(N,3) int32 ids [user, item, rating], column-major so that each column is contiguous
+        (what the device library takes)."""
         cols, _ = _columns(data)
-        self.labels, out = [], []
-        for col in cols:
-            ids, uniq = _factorize_as_str(col)
+        out = np.empty((len(cols[0]), 3), dtype=np.int32, order="F")
+        self.labels = []
+        for j, col in enumerate(cols):
+            _, uniq = _factorize_as_str(col, out=out[:, j] if len(col) else None)
             self.labels.append(uniq)
-            out.append(ids)
-        return np.stack(out, axis=1) if len(out[0]) else np.zeros((0, 3), dtype=np.int64)
+        return out
 
     def transform(self, data, logger=None):
         if self.labels is None:
@@ -86,8 +93,11 @@ class Encoder:
                 log.warning(f"The {name} {', '.join(missing)} are in the test set but weren't in "
                             f"the train set so I'll remove them.")
             keep &= hit
-            ids.append(pos.astype(np.int64))
-        return np.stack(ids, axis=1)[keep]
+            ids.append(pos.astype(np.int32))
+        out = np.empty((int(keep.sum()), 3), dtype=np.int32, order="F")
+        for j in range(3):
+            out[:, j] = ids[j][keep]
+        return out
 
     # decoding helpers (data_handler.py:74-99)
     def user_labels(self):

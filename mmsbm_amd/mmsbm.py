@@ -79,7 +79,8 @@ class MMSBM:
         *_, self._backend = load_backend(self.backend)
         train = np.asarray(train)
         self.train = train
-        self.ratings = np.unique(train[:, 2]).tolist()  # = sorted(set(...)), src/mmsbm.py:95
+        # = sorted(set(train[:, 2])), src/mmsbm.py:95 (ids are small non-negative ints: one counting pass)
+        self.ratings = (np.flatnonzero(np.bincount(train[:, 2])).tolist() if len(train) else [])
         self.r = max(self.ratings)
         self.p = int(train[:, 0].max())
         self.m = int(train[:, 1].max())
