@@ -632,14 +632,15 @@ __global__ __launch_bounds__(NT) void pair_block_kernel(PairBlockArgs pa,
 
 // ======================================================================================
 // kernel 4: p_update -- n_p[r][k][l] = p[r][k][l] * sum_{chunks c of r} S_c[k][l] (fixed
-// order: 128 strided partial sums, then 8 sums of 16, then a sum of 8), followed by
+// order: 64 strided partial sums, then 8 sums of 8, then a sum of 8), followed by
 // normalize_with_self over r (src/expectation_maximization.py:152-155; zero rows stay
-// zero).  One block owns 8 (k,l) columns for ALL ratings (measured: 16 x 64 rows 8.4 us for
-// the launch at C3, 8 x 128 rows 7.9, 4 x 256 rows 10.8), so no inter-block hand-off is
+// zero).  One block owns 16 (k,l) columns for ALL ratings (8 x 128 rows is 0.5 us faster launched
+// back to back but 0.5 us slower inside the iteration; 4 x 256 rows is slower either way), so no
+// inter-block hand-off is
 // needed; every thread's slab loads are independent and issued back to back.  Writes
 // p_new as [R][Kp][Lp] and transposed [R][Lp][Kp]; optionally the raw numerators.
 // ======================================================================================
-constexpr int kRedCols = 8, kRedRows = 128, kRedGroup = 6;  // ratings per LDS pass
+constexpr int kRedCols = 16, kRedRows = 64, kRedGroup = 6;  // ratings per LDS pass
 constexpr int kRedThreads = kRedCols * kRedRows, kRedBatch = 4;
 
 template <int ROWS>
