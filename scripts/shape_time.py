@@ -1,10 +1,11 @@
-"""EM iteration time at an arbitrary synthetic shape: shape_time.py N U I R K L [zipf]"""
+"""EM iteration time at an arbitrary synthetic shape: shape_time.py N U I R K L [zipf] [swap0|swap1]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from mmsbm_amd import HipEM, _lib
 n, u, i, r, k, l = (int(x) for x in sys.argv[1:7])
-zipf = len(sys.argv) > 7
+zipf = "zipf" in sys.argv[7:]
+swap = 0 if "swap0" in sys.argv[7:] else (1 if "swap1" in sys.argv[7:] else -1)
 rng = np.random.default_rng(0)
 if zipf:
     uu = (rng.zipf(1.2, n) - 1) % u
@@ -14,7 +15,7 @@ else:
 cols = [np.unique(c, return_inverse=True)[1] for c in (uu, ii, rng.integers(0, r, n))]
 train = np.stack(cols, axis=1).astype(np.int64)
 nu, ni, nr = (int(train[:, j].max()) + 1 for j in range(3))
-em = HipEM(train, k, l, nu, ni, nr)
+em = HipEM(train, k, l, nu, ni, nr, swap_sides=swap)
 em.init_params(np.random.SeedSequence(1))
 em.iterate(20)
 iters = 500 if n <= 2_000_000 else 50
