@@ -131,8 +131,7 @@ def main():
     ctx.iterate(args.warmup)
 
     def fence():
-        if world > 1:
-            dist.barrier()
+        restarts.barrier(device)
         ctx.synchronize()
         torch.cuda.synchronize()
 

@@ -41,7 +41,7 @@ def main():
         print(f"maximum-likelihood restart: {best} ({best_lik:.3f}); {len(model.results)} result sets gathered")
     if world > 1:
         import torch.distributed as dist
-        dist.barrier()
+        restarts.barrier(device)
         dist.destroy_process_group()
 
 

@@ -48,6 +48,16 @@ def init_from_env(backend=None):
     return rank, world, local, (torch.device("cuda", local) if use_gpu else torch.device("cpu"))
 
 
+def barrier(device=None):
+    """dist.barrier() that tells RCCL which GPU this rank owns (avoids its device guess)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    if dist.get_backend() == "nccl" and device is not None and device.type == "cuda":
+        dist.barrier(device_ids=[device.index])
+    else:
+        dist.barrier()
+
+
 def check_single_hip_runtime():
     libs = _lib.loaded_hip_runtimes()
     if len(libs) > 1:
