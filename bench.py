@@ -88,7 +88,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--config", default="c3", choices=["c2", "c3", "c5"])
+    ap.add_argument("--config", default="c3", choices=["c1", "c2", "c3", "c5"])
     ap.add_argument("--profile-iters", type=int, default=20)
     ap.add_argument("--cpu-sample-rows", type=int, default=300_000)
     ap.add_argument("--cpu-iters", type=int, default=12)
