@@ -85,6 +85,96 @@ inline void build_worklist(const std::vector<int32_t> &off, WorkList &w, int32_t
   w.splits.insert(w.splits.end(), big.begin(), big.end());
 }
 
+// ---- XCD-local work lists (dense data) -------------------------------------------------------
+// MI355X has 8 XCDs with a 4 MiB L2 each, and workgroups are dealt to them round-robin (blocks b
+// and b + 8 share an XCD).  A gathered table (theta, A) larger than one L2 misses on almost every
+// row.  With long segments it pays to cut every segment at fixed borders of the GATHERED index
+// (the triples of a segment are sorted by it), give range r of the table to XCD r mod 8, and order
+// the work items so that every workgroup holds items of one range only and lands on that range's
+// XCD: each L2 then serves a slice of the table that fits it.  The price is one partial row per
+// (segment, range) piece, combined in piece order like any other split segment.
+constexpr int32_t kXcds = 8;
+constexpr size_t kRangeSliceBytes = size_t(3) << 20;  // table slice one XCD's 4 MiB L2 is asked to serve
+constexpr int32_t kRangeMinMeanLen = 96;              // pieces of fewer than ~12 triples cost more than they save
+
+// Number of ranges for a gathered table of `table_bytes` and segments of `mean_len` triples (1 = off).
+// Measured (MI355X, 160-byte rows): 20M ratings x 138k users (145 each) gathering a 43 MB table: 8
+// ranges -18 %, 16 ranges +18 %; the other pass of the same data (74 per segment): no gain at 8; 50M
+// ratings x 88k pairs (565 each) gathering a 46 MB table: 8 ranges -21 %, 16 ranges -27 %, 32 -22 %.
+inline int32_t range_count(size_t table_bytes, int64_t mean_len) {
+  if (mean_len < kRangeMinMeanLen || table_bytes <= kRangeSliceBytes) return 1;
+  int64_t n = kXcds;
+  while (table_bytes / size_t(n) > kRangeSliceBytes && n < 64 && mean_len / (2 * n) >= 16) n *= 2;
+  return int32_t(n);
+}
+
+// off: segment offsets; idx: gathered row of every triple (ascending inside a segment);
+// per_block: work items (groups of lanes) per workgroup of the pass.
+inline void build_worklist_ranges(const std::vector<int32_t> &off, const int32_t *idx, int32_t table_rows,
+                                  int32_t n_ranges, int32_t item_len, int32_t per_block, WorkList &w) {
+  w = WorkList();
+  w.item_len = item_len;
+  const int32_t nseg = int32_t(off.size()) - 1;
+  // range of row r: r * n_ranges / table_rows; its first row:
+  auto range_of = [&](int32_t r) { return int32_t(int64_t(r) * n_ranges / std::max(table_rows, 1)); };
+  std::vector<std::vector<WorkItem>> bucket;
+  bucket.resize(static_cast<size_t>(n_ranges));
+  std::vector<SplitSeg> big;
+  std::vector<std::pair<int32_t, int32_t>> pieces;  // (begin, range) of the current segment's pieces
+  for (int32_t s = 0; s < nseg; ++s) {
+    const int32_t b = off[s], e = off[s + 1];
+    pieces.clear();
+    if (b == e) {  // empty segment: its (zero) output row must still be written
+      bucket[0].push_back(WorkItem{s, b, e, -1});
+      continue;
+    }
+    int32_t t = b;
+    while (t < e) {  // next border: first triple whose row leaves range r (binary search: rows ascend)
+      const int32_t r = range_of(idx[t]);
+      int32_t lo = t, hi = e;
+      while (hi - lo > 1) {
+        const int32_t mid = lo + (hi - lo) / 2;
+        if (range_of(idx[mid]) == r) lo = mid; else hi = mid;
+      }
+      for (int32_t c = t; c < hi; c += item_len) pieces.emplace_back(c, r);  // long pieces are cut again
+      t = hi;
+    }
+    const int32_t np = int32_t(pieces.size());
+    if (np == 1) {
+      bucket[size_t(pieces[0].second)].push_back(WorkItem{s, b, e, -1});
+      continue;
+    }
+    (np <= kSmallSplitParts ? w.splits : big).push_back(SplitSeg{s, w.n_parts, np, 0});
+    for (int32_t j = 0; j < np; ++j) {
+      const int32_t pb = pieces[size_t(j)].first;
+      int32_t pe = (j + 1 < np) ? pieces[size_t(j) + 1].first : e;
+      bucket[size_t(pieces[size_t(j)].second)].push_back(WorkItem{s, pb, pe, w.n_parts + j});
+    }
+    w.n_parts += np;
+  }
+  w.n_small = int32_t(w.splits.size());
+  w.splits.insert(w.splits.end(), big.begin(), big.end());
+  // Per XCD x: the blocks of ranges x, x + 8, x + 16, ... one after the other; then deal the eight
+  // lists out round-robin (block j of XCD x becomes block 8 j + x).  Null items (seg = -1) pad.
+  const WorkItem null_item{-1, 0, 0, -1};
+  std::vector<std::vector<WorkItem>> per_xcd;
+  per_xcd.resize(static_cast<size_t>(kXcds));
+  for (int32_t r = 0; r < n_ranges; ++r) {
+    auto &dst = per_xcd[size_t(r % kXcds)];
+    dst.insert(dst.end(), bucket[size_t(r)].begin(), bucket[size_t(r)].end());
+    while (dst.size() % size_t(per_block)) dst.push_back(null_item);
+  }
+  size_t rounds = 0;
+  for (auto &v : per_xcd) rounds = std::max(rounds, v.size() / size_t(per_block));
+  w.items.reserve(rounds * size_t(kXcds) * size_t(per_block));
+  for (size_t j = 0; j < rounds; ++j)
+    for (int32_t x = 0; x < kXcds; ++x) {
+      const auto &v = per_xcd[size_t(x)];
+      for (int32_t k = 0; k < per_block; ++k)
+        w.items.push_back(j * size_t(per_block) + size_t(k) < v.size() ? v[j * size_t(per_block) + size_t(k)] : null_item);
+    }
+}
+
 struct Layout {
   int64_t n_obs = 0;
   int32_t n_users = 0, n_items = 0, n_ratings = 0, n_pairs = 0;

@@ -185,6 +185,7 @@ __device__ __forceinline__ void seg_body(const SegArgs &a, int unit, int dp) {
   if (a.items) {
     const mmsbm::WorkItem it = a.items[unit];
     seg = it.seg; beg = it.begin; end = it.end; part = it.part;
+    if (seg < 0) return;  // padding of an XCD-local work list
   } else {
     beg = a.off[unit];
     end = a.off[unit + 1];
@@ -1331,6 +1332,7 @@ struct mmsbm_hip_ctx {
   size_t lds_t = 0, lds_a = 0;
   bool tl_t = false, tl_a = false;  // rating tile staged in LDS (T+S launch / A launch)
   bool quad_a = false;  // the A launch runs pair_quad_a_kernel (long rows)
+  int ranges_pairs = 1, ranges_users = 1;  // XCD-local work lists: ranges the gathered table is cut into
   int n_cus = 256;
   size_t lds_qa = 0;
   mmsbm::Layout lay;  // host copy (degrees, sizes)
@@ -2124,6 +2126,28 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
                 c->lds_qa <= kLdsMax - 2048 && c->lp <= 64;
     c->n_pairs = c->lay.n_pairs;
     c->n_chunks = static_cast<int>(c->lay.mv_chunks.size());
+    // dense data: XCD-local work lists (layout.hpp) -- every segment cut at fixed borders of the
+    // gathered index, each range's work on one XCD, whose L2 then holds that slice of the table
+    if (std::getenv("MMSBM_HIP_NO_RANGES") == nullptr) {
+      const int per = kBlock / group_lanes(c->code_k);
+      const size_t row_bytes = static_cast<size_t>(c->kp) * sizeof(double);
+      const int64_t mean_p = c->n_pairs > 0 ? n_obs / c->n_pairs : 0, mean_u = n_obs / std::max(c->n_users, 1);
+      int rp = mmsbm::range_count(static_cast<size_t>(c->n_users) * row_bytes, mean_p);   // pair pass gathers theta
+      int ru = mmsbm::range_count(static_cast<size_t>(c->n_pairs) * row_bytes, mean_u);   // user pass gathers A
+      if (const char *f = std::getenv("MMSBM_HIP_RANGES")) {  // tuning: "pairs,users" forced range counts
+        int a = 0, b = 0;
+        if (std::sscanf(f, "%d,%d", &a, &b) == 2 && a >= 1 && b >= 1 && a <= 512 && b <= 512) { rp = a; ru = b; }
+      }
+      if (rp > 1)
+        mmsbm::build_worklist_ranges(c->lay.pair_off, c->lay.pair_user.data(), c->n_users, rp,
+                                     mmsbm::item_length(n_obs, c->n_pairs), per, c->lay.pair_work);
+      if (ru > 1)
+        mmsbm::build_worklist_ranges(c->lay.user_off, c->lay.user_pair.data(), c->n_pairs, ru,
+                                     mmsbm::item_length(n_obs, c->n_users), per, c->lay.user_work);
+      c->ranges_pairs = rp;
+      c->ranges_users = ru;
+    }
+    lap("xcd-local work lists");
 
     HIP_CHECK(hipSetDevice(device));
     {

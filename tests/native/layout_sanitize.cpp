@@ -49,6 +49,43 @@ static void check(const std::vector<int32_t> &u, const std::vector<int32_t> &i, 
   }
   mmsbm::build_mv_chunks(L, 4 * mmsbm::kMvChunkPairs);
   CHECK(L.mv_chunk_off.back() == static_cast<int>(L.mv_chunks.size()));
+  // XCD-local work lists: both passes, 8 and 24 ranges, workgroups of 8 and 32 items
+  for (int side = 0; side < 2; ++side)
+    for (int n_ranges : {8, 24})
+      for (int per_block : {8, 32}) {
+        const auto &off = side ? L.user_off : L.pair_off;
+        const int32_t *idx = side ? L.user_pair.data() : L.pair_user.data();
+        const int rows = side ? L.n_pairs : L.n_users;
+        mmsbm::WorkList w;
+        mmsbm::build_worklist_ranges(off, idx, rows, n_ranges, 50, per_block, w);
+        const int nseg = static_cast<int>(off.size()) - 1;
+        CHECK(w.items.size() % (static_cast<size_t>(per_block) * mmsbm::kXcds) == 0);
+        std::vector<int> seen(static_cast<size_t>(n), 0), out_rows(static_cast<size_t>(std::max(nseg, 1)), 0);
+        std::vector<int> part_owner(static_cast<size_t>(w.n_parts), -1);
+        for (size_t k = 0; k < w.items.size(); ++k) {
+          const auto &it = w.items[k];
+          if (it.seg < 0) continue;
+          CHECK(it.seg < nseg && off[it.seg] <= it.begin && it.begin <= it.end && it.end <= off[it.seg + 1]);
+          CHECK(it.end - it.begin <= 50);
+          const int block = static_cast<int>(k / static_cast<size_t>(per_block));
+          for (int t = it.begin; t < it.end; ++t) {
+            seen[t]++;
+            const int r = static_cast<int>(static_cast<int64_t>(idx[t]) * n_ranges / std::max(rows, 1));
+            CHECK(r % mmsbm::kXcds == block % mmsbm::kXcds);  // the workgroup lands on its range's XCD
+          }
+          if (it.part < 0) out_rows[it.seg]++;
+          else { CHECK(it.part < w.n_parts && part_owner[it.part] == -1); part_owner[it.part] = it.seg; }
+        }
+        for (int64_t t = 0; t < n; ++t) CHECK(seen[t] == 1);
+        for (const auto &sp : w.splits) {
+          CHECK(sp.n_parts >= 2 && out_rows[sp.seg] == 0);
+          for (int j = 0; j < sp.n_parts; ++j) CHECK(part_owner[sp.first_part + j] == sp.seg);
+          out_rows[sp.seg] = 1;
+        }
+        for (int s2 = 0; s2 < nseg; ++s2) CHECK(out_rows[s2] == 1);  // every segment's row is written exactly once
+        for (int k = 0; k < w.n_small; ++k) CHECK(w.splits[k].n_parts <= mmsbm::kSmallSplitParts);
+        for (size_t k = w.n_small; k < w.splits.size(); ++k) CHECK(w.splits[k].n_parts > mmsbm::kSmallSplitParts);
+      }
 }
 
 int main() {

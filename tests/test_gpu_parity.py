@@ -928,3 +928,39 @@ def test_dense_data_many_split_segments(hip):
                 assert rel_err(got, w) < 1e-11, nm
     for a, b in zip(outs[0], outs[2]):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("ranges", ["8,8", "16,24", "1,8"])
+def test_xcd_local_work_lists(hip, ranges, monkeypatch):
+    """Dense data with the segments cut at fixed borders of the gathered index (one range of the
+    table per XCD; forced here through MMSBM_HIP_RANGES since the tables of a test-sized problem
+    fit any L2): same results as the oracle, reproducible, with restart slots too."""
+    monkeypatch.setenv("MMSBM_HIP_RANGES", ranges)
+    rng = np.random.default_rng(41)
+    n, n_u, n_i, n_r, k, l = 50_000, 260, 180, 4, 12, 9
+    u = np.where(rng.random(n) < 0.1, 7, rng.integers(0, n_u, n))
+    data = np.stack([u, rng.integers(0, n_i, n), rng.integers(0, n_r, n)], axis=1).astype(np.int64)
+    data = data[data[:, 0] != 100]                                     # an id that never occurs
+    d_u, d_i = orc.degrees(data, n_u, n_i)
+    theta, eta, pr = orc.init_params(6, n_u, n_i, n_r, k, l, d_u, d_i)
+    want = orc.update_coefficients(data, theta, eta, pr)
+    t, e, p = theta, eta, pr
+    for _ in range(3):
+        t, e, p = orc.em_step(data, t, e, p, d_u, d_i)
+    outs = []
+    for swap in (0, 1, 0):
+        with make_ctx(hip, data, theta, eta, pr, swap_sides=swap) as em:
+            for got, w, nm in zip(em.update_coefficients(), want, ("n_theta", "n_eta", "n_pr")):
+                assert rel_err(got, w) < TOL_STEP, nm
+            em.iterate(3)
+            outs.append(em.get_params())
+            for got, w, nm in zip(outs[-1], (t, e, p), ("theta", "eta", "pr")):
+                assert rel_err(got, w) < 1e-11, nm
+    for a, b in zip(outs[0], outs[2]):
+        assert np.array_equal(a, b)
+    with hip.HipEM(data, k, l, n_u, n_i, n_r, swap_sides=0, slots=2) as em:
+        em.select(0).set_params(theta, eta, pr)
+        em.select(1).set_params(theta * 1.01, eta, pr)
+        em.iterate(3)
+        for a, b in zip(em.select(0).get_params(), outs[0]):
+            assert np.array_equal(a, b)
