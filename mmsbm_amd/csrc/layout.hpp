@@ -108,6 +108,23 @@ inline int32_t range_count(size_t table_bytes, int64_t mean_len) {
   return int32_t(n);
 }
 
+// Share of all gathers that go to the `rows_fit` most frequently gathered rows (the rows an L2 would
+// keep by itself).  off = offsets of the segments whose length is the row's gather count.  Heavy-
+// tailed data has a hot set that already lives in L2: cutting by range then only adds partial rows
+// (measured, Zipf(1.2) degrees, 20M ratings: 618 us without ranges, 764 us with).
+inline double hot_fraction(const std::vector<int32_t> &off, int64_t rows_fit) {
+  const int64_t rows = int64_t(off.size()) - 1;
+  if (rows <= 0 || off.back() <= 0) return 1.0;
+  if (rows_fit >= rows) return 1.0;
+  std::vector<int32_t> deg(static_cast<size_t>(rows));
+  for (int64_t r = 0; r < rows; ++r) deg[size_t(r)] = off[size_t(r) + 1] - off[size_t(r)];
+  std::nth_element(deg.begin(), deg.begin() + rows_fit, deg.end(), [](int32_t a, int32_t b) { return a > b; });
+  int64_t top = 0;
+  for (int64_t r = 0; r < rows_fit; ++r) top += deg[size_t(r)];
+  return double(top) / double(off.back());
+}
+constexpr double kRangeSkewRatio = 3.0;  // hot share / (share of the table that fits): ~1.1 uniform, ~4.5 log-normal(1), >> Zipf
+
 // off: segment offsets; idx: gathered row of every triple (ascending inside a segment);
 // per_block: work items (groups of lanes) per workgroup of the pass.
 inline void build_worklist_ranges(const std::vector<int32_t> &off, const int32_t *idx, int32_t table_rows,
@@ -128,6 +145,10 @@ inline void build_worklist_ranges(const std::vector<int32_t> &off, const int32_t
       bucket[0].push_back(WorkItem{s, b, e, -1});
       continue;
     }
+    if (e - b < 2 * n_ranges && e - b <= item_len) {  // a handful of triples: pieces of one or two would cost
+      bucket[size_t(range_of(idx[b + (e - b) / 2]))].push_back(WorkItem{s, b, e, -1});  // more than they save
+      continue;  // (only these: a whole segment gathers from every range and pollutes its XCD's L2 --
+    }            //  leaving all segments under 12 triples per range whole turned -33 % into +6 %)
     int32_t t = b;
     while (t < e) {  // next border: first triple whose row leaves range r (binary search: rows ascend)
       const int32_t r = range_of(idx[t]);

@@ -10,6 +10,11 @@ rng = np.random.default_rng(0)
 if zipf:
     uu = (rng.zipf(1.2, n) - 1) % u
     ii = (rng.zipf(1.2, n) - 1) % i
+elif "lognorm" in sys.argv[7:]:  # MovieLens-like: log-normal activity / popularity (sigma = 1)
+    def draw(m):
+        w = rng.lognormal(0.0, 1.0, m)
+        return rng.choice(m, size=n, p=w / w.sum())
+    uu, ii = draw(u), draw(i)
 else:
     uu, ii = rng.integers(0, u, n), rng.integers(0, i, n)
 cols = [np.unique(c, return_inverse=True)[1] for c in (uu, ii, rng.integers(0, r, n))]
@@ -22,6 +27,6 @@ iters = 500 if n <= 2_000_000 else 50
 us = min(em.time_iterations(iters) for _ in range(3)) * 1000 / iters
 prof = em.profile_iterations(20)
 rd = n * (12 + 8 * k + 8 * l) + 8 * k * l * nr
-print(f"N={n} U={nu} I={ni} R={nr} K={k} L={l}{' zipf' if zipf else ''}: {us:8.2f} us/iteration = {1e6 / us:9.1f} it/s, "
+print(f"N={n} U={nu} I={ni} R={nr} K={k} L={l}{' zipf' if zipf else (' lognorm' if 'lognorm' in sys.argv[7:] else '')}: {us:8.2f} us/iteration = {1e6 / us:9.1f} it/s, "
       f"{rd / us / 1e3:7.1f} GB/s algorithmic ({rd / us / 1e3 / 80:.1f} % of 8 TB/s); pairs {em.n_pairs}, swapped {em.swapped}\n   " +
       "  ".join(f"{nm} {v[0]:.1f}x{v[1]}" for nm, v in prof.items()))

@@ -68,10 +68,11 @@ static void check(const std::vector<int32_t> &u, const std::vector<int32_t> &i, 
           CHECK(it.seg < nseg && off[it.seg] <= it.begin && it.begin <= it.end && it.end <= off[it.seg + 1]);
           CHECK(it.end - it.begin <= 50);
           const int block = static_cast<int>(k / static_cast<size_t>(per_block));
+          const bool whole_short = it.part < 0 && it.end - it.begin < 2 * n_ranges;  // a handful of triples: not cut
           for (int t = it.begin; t < it.end; ++t) {
             seen[t]++;
             const int r = static_cast<int>(static_cast<int64_t>(idx[t]) * n_ranges / std::max(rows, 1));
-            CHECK(r % mmsbm::kXcds == block % mmsbm::kXcds);  // the workgroup lands on its range's XCD
+            if (!whole_short) CHECK(r % mmsbm::kXcds == block % mmsbm::kXcds);  // the workgroup lands on its range's XCD
           }
           if (it.part < 0) out_rows[it.seg]++;
           else { CHECK(it.part < w.n_parts && part_owner[it.part] == -1); part_owner[it.part] = it.seg; }
