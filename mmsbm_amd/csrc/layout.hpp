@@ -80,9 +80,24 @@ inline void sort_items_by_length(std::vector<WorkItem> &items) {
   // Items of similar length side by side, longest first: the groups of a wave then finish together
   // instead of idling until its longest segment is done, and the long pieces start early
   // (20M ratings with log-normal degrees: 1.33 -> 0.99 ms per iteration).
-  std::stable_sort(items.begin(), items.end(), [](const WorkItem &a, const WorkItem &b) {
-    return a.end - a.begin > b.end - b.begin;
-  });
+  // By length CLASS (powers of two), segment order kept inside a class: pieces of nearly equal length
+  // stay in the order of their segments, whose fixed rows and partial rows are neighbours in memory
+  // (sorting by exact length scattered them: uniform 50M x 480k, 1.29 -> 1.46 ms).
+  {  // only where the lengths really differ (coefficient of variation > 0.5)
+    double n = 0.0, sum = 0.0, sq = 0.0;
+    for (const WorkItem &w : items) {
+      if (w.seg < 0) continue;
+      const double len = double(w.end - w.begin);
+      n += 1.0; sum += len; sq += len * len;
+    }
+    if (n < 2.0 || sq / n - (sum / n) * (sum / n) <= 0.25 * (sum / n) * (sum / n)) return;
+  }
+  auto cls = [](const WorkItem &w) {
+    int32_t len = w.end - w.begin, c = 0;
+    while (len > 1) { len >>= 1; ++c; }
+    return c;
+  };
+  std::stable_sort(items.begin(), items.end(), [&](const WorkItem &a, const WorkItem &b) { return cls(a) > cls(b); });
 }
 
 inline void build_worklist(const std::vector<int32_t> &off, WorkList &w, int32_t item_len = kMaxItemLen,
@@ -150,7 +165,6 @@ inline double hot_fraction(const std::vector<int32_t> &off, int64_t rows_fit) {
   for (int64_t r = 0; r < rows_fit; ++r) top += deg[size_t(r)];
   return double(top) / double(off.back());
 }
-constexpr double kRangeSkewRatio = 3.0;  // hot share / (share of the table that fits): ~1.1 uniform, ~4.5 log-normal(1), >> Zipf
 
 // off: segment offsets; idx: gathered row of every triple (ascending inside a segment);
 // per_block: work items (groups of lanes) per workgroup of the pass.

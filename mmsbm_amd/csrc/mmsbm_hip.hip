@@ -2136,21 +2136,12 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
       int ru = mmsbm::range_count(static_cast<size_t>(c->n_pairs) * row_bytes, mean_u);   // user pass gathers A
       // ... unless the table's hot rows (what one L2 keeps by itself) already take most of the gathers:
       // theta rows are gathered once per triple of that user, A rows once per triple of that pair
-      // With skewed gather counts (log-normal, Zipf) the hot rows serve a multiple of their share of the
-      // table; cutting then pays only with long pieces (measured, log-normal sigma 1: pieces of 18
-      // triples +7 %, pieces of 35 triples -13 %; Zipf(1.2), pieces of 18: +24 %).
+      // Where the rows one L2 keeps by itself already take half of the gathers (heavy-tailed gather
+      // counts, or a table only a few times an L2) there is little left to win: measured +16 % (50M
+      // ratings, log-normal item popularity, 8.5 MB table) and +24 % (Zipf(1.2) degrees) if cut anyway.
       const int64_t fit = static_cast<int64_t>(mmsbm::kRangeSliceBytes / row_bytes);
-      // And where the rows one L2 keeps by itself already take half of the gathers there is little left
-      // to win (50M ratings, log-normal item popularity, 8.5 MB table: +16 % with ranges).
-      auto keep = [&](const std::vector<int32_t> &off, int64_t piece_len) {
-        const double rows = static_cast<double>(off.size()) - 1.0;
-        const double hot = mmsbm::hot_fraction(off, fit);
-        if (hot > 0.5) return false;
-        const bool skewed = hot >= mmsbm::kRangeSkewRatio * std::min(1.0, fit / std::max(rows, 1.0));
-        return !(skewed && piece_len < 32);
-      };
-      if (rp > 1 && !keep(c->lay.user_off, mean_p / rp)) rp = 1;
-      if (ru > 1 && !keep(c->lay.pair_off, mean_u / ru)) ru = 1;
+      if (rp > 1 && mmsbm::hot_fraction(c->lay.user_off, fit) > 0.5) rp = 1;
+      if (ru > 1 && mmsbm::hot_fraction(c->lay.pair_off, fit) > 0.5) ru = 1;
       if (const char *f = std::getenv("MMSBM_HIP_RANGES")) {  // tuning: "pairs,users" forced range counts
         int a = 0, b = 0;
         if (std::sscanf(f, "%d,%d", &a, &b) == 2 && a >= 1 && b >= 1 && a <= 512 && b <= 512) { rp = a; ru = b; }
