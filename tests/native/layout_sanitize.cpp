@@ -129,6 +129,34 @@ int main() {
     check(u, i, r, U, I, R, 64);
     mmsbm::layout_threads_override() = 0;
   }
+  {  // the policies, at the shapes they were tuned on
+    const size_t MB = size_t(1) << 20;
+    CHECK(mmsbm::range_count(43 * MB, 145) == 8);    // 20M ratings x 138k users: the user pass
+    CHECK(mmsbm::range_count(22 * MB, 74) == 1);     // ... its pair pass: segments too short
+    CHECK(mmsbm::range_count(46 * MB, 565) == 16);   // 50M ratings x 88k pairs
+    CHECK(mmsbm::range_count(17 * MB / 2, 104) == 8);
+    CHECK(mmsbm::range_count(2 * MB, 5000) == 1);    // the table fits an L2 anyway
+    CHECK(mmsbm::range_count(16 * MB, 10) == 1);     // BASELINE's sparse configs
+    CHECK(mmsbm::item_length(1000000, 100000) == 64 && mmsbm::item_length(1000000, 6040) == 16);
+    std::vector<int32_t> flat{0}, skew{0};
+    for (int s = 0; s < 4000; ++s) flat.push_back(flat.back() + 8 + static_cast<int>(rng() % 5));
+    for (int s = 0; s < 4000; ++s) skew.push_back(skew.back() + (s % 50 == 0 ? 900 : 3 + static_cast<int>(rng() % 4)));
+    CHECK(!mmsbm::lengths_vary(flat) && mmsbm::lengths_vary(skew));
+    const double hf = mmsbm::hot_fraction(flat, 400), hs = mmsbm::hot_fraction(skew, 400);
+    CHECK(hf > 0.10 && hf < 0.13 && hs > 0.7 && mmsbm::hot_fraction(flat, 5000) == 1.0);
+    mmsbm::WorkList w;
+    mmsbm::build_worklist(skew, w, 64, true);
+    CHECK(!w.items.empty());
+    int prev = 1 << 30;                                 // length classes descend through the list
+    for (const auto &it : w.items) {
+      int len = it.end - it.begin, c = 0;
+      while (len > 1) { len >>= 1; ++c; }
+      CHECK(c <= prev);
+      prev = c;
+    }
+    mmsbm::build_worklist(flat, w, 64, true);           // nearly equal lengths: segment order is kept
+    for (size_t k = 1; k < w.items.size(); ++k) CHECK(w.items[k - 1].seg < w.items[k].seg);
+  }
   check({}, {}, {}, 3, 2, 2, 8);            // empty
   check({0}, {0}, {0}, 1, 1, 1, 1);          // single triple
   {                                          // invalid ids must throw, not scribble
