@@ -173,8 +173,10 @@ int mmsbm_hip_kernel_bytes(const mmsbm_hip_ctx *ctx, int index, int64_t *bytes_r
  * stage's outputs overwrite scratch/next buffers: call set_params again before trusting the
  * context's state. */
 int mmsbm_hip_time_stage(mmsbm_hip_ctx *ctx, int stage, int reps, float *mean_us);
-/* Named tuning knobs (defaults are right for normal use); currently "graph" 0/1, the same
- * switch as mmsbm_hip_set_graph_mode. */
+/* Named tuning knobs (defaults are right for normal use): "graph" 0/1 (the same switch as
+ * mmsbm_hip_set_graph_mode), "direct" 0/1 (pair stage: output rows stored from registers),
+ * "quad" 0/1 (long rows: the A launch as a persistent four-unit pipeline), "lik_fast" 0/1
+ * (likelihood through logarithm tables), "lik_g" 0/1/2/4/8 (its lanes per triple, 0 = automatic). */
 int mmsbm_hip_set_option(mmsbm_hip_ctx *ctx, const char *name, double value);
 /* How em_iterate launches: 0 (default) = eager launches on the context's stream; 1 = replay
  * a captured hipGraph of two iterations. */
