@@ -144,7 +144,11 @@ constexpr int32_t kRangeMinMeanLen = 96;              // pieces of fewer than ~1
 // ranges -18 %, 16 ranges +18 %; the other pass of the same data (74 per segment): no gain at 8; 50M
 // ratings x 88k pairs (565 each) gathering a 46 MB table: 8 ranges -21 %, 16 ranges -27 %, 32 -22 %.
 inline int32_t range_count(size_t table_bytes, int64_t mean_len) {
-  if (mean_len < kRangeMinMeanLen || table_bytes <= kRangeSliceBytes) return 1;
+  if (table_bytes <= kRangeSliceBytes) return 1;
+  // shorter segments: fewer, wider ranges, each shared by 2 or 4 XCDs (pieces of >= ~12-18 triples);
+  // 20M ratings, 74 per segment, 22 MB table: 4 ranges -10 %, 2 ranges -7.5 %, 8 ranges -1 %
+  // (25 per segment, 2 ranges: +3 %; 50 per segment, 4 ranges: -13 %)
+  if (mean_len < kRangeMinMeanLen) return mean_len >= 40 ? 4 : (mean_len >= 32 ? 2 : 1);
   int64_t n = kXcds;
   while (table_bytes / size_t(n) > kRangeSliceBytes && n < 64 && mean_len / (2 * n) >= 16) n *= 2;
   return int32_t(n);
@@ -221,11 +225,18 @@ inline void build_worklist_ranges(const std::vector<int32_t> &off, const int32_t
   const WorkItem null_item{-1, 0, 0, -1};
   std::vector<std::vector<WorkItem>> per_xcd;
   per_xcd.resize(static_cast<size_t>(kXcds));
+  // (fewer ranges than XCDs -- 4 or 2: range r is served by the XCDs r, r + n_ranges, ..., its
+  // workgroups dealt out among them)
+  const int32_t share = n_ranges < kXcds ? kXcds / n_ranges : 1;
   for (int32_t r = 0; r < n_ranges; ++r) {
-    auto &dst = per_xcd[size_t(r % kXcds)];
-    sort_items_by_length(bucket[size_t(r)]);
-    dst.insert(dst.end(), bucket[size_t(r)].begin(), bucket[size_t(r)].end());
-    while (dst.size() % size_t(per_block)) dst.push_back(null_item);
+    auto &src = bucket[size_t(r)];
+    sort_items_by_length(src);
+    while (src.size() % size_t(per_block)) src.push_back(null_item);
+    const size_t nblk = src.size() / size_t(per_block);
+    for (size_t j = 0; j < nblk; ++j) {
+      auto &dst = per_xcd[size_t((r + int32_t(j % size_t(share)) * n_ranges) % kXcds)];
+      dst.insert(dst.end(), src.begin() + j * size_t(per_block), src.begin() + (j + 1) * size_t(per_block));
+    }
   }
   size_t rounds = 0;
   for (auto &v : per_xcd) rounds = std::max(rounds, v.size() / size_t(per_block));

@@ -51,7 +51,7 @@ static void check(const std::vector<int32_t> &u, const std::vector<int32_t> &i, 
   CHECK(L.mv_chunk_off.back() == static_cast<int>(L.mv_chunks.size()));
   // XCD-local work lists: both passes, 8 and 24 ranges, workgroups of 8 and 32 items
   for (int side = 0; side < 2; ++side)
-    for (int n_ranges : {8, 24})
+    for (int n_ranges : {4, 8, 24})
       for (int per_block : {8, 32}) {
         const auto &off = side ? L.user_off : L.pair_off;
         const int32_t *idx = side ? L.user_pair.data() : L.pair_user.data();
@@ -72,7 +72,7 @@ static void check(const std::vector<int32_t> &u, const std::vector<int32_t> &i, 
           for (int t = it.begin; t < it.end; ++t) {
             seen[t]++;
             const int r = static_cast<int>(static_cast<int64_t>(idx[t]) * n_ranges / std::max(rows, 1));
-            if (!whole_short) CHECK(r % mmsbm::kXcds == block % mmsbm::kXcds);  // the workgroup lands on its range's XCD
+            if (!whole_short) CHECK(r % std::min(n_ranges, mmsbm::kXcds) == (block % mmsbm::kXcds) % std::min(n_ranges, mmsbm::kXcds));  // the workgroup lands on (one of) its range's XCD(s)
           }
           if (it.part < 0) out_rows[it.seg]++;
           else { CHECK(it.part < w.n_parts && part_owner[it.part] == -1); part_owner[it.part] = it.seg; }
@@ -132,7 +132,8 @@ int main() {
   {  // the policies, at the shapes they were tuned on
     const size_t MB = size_t(1) << 20;
     CHECK(mmsbm::range_count(43 * MB, 145) == 8);    // 20M ratings x 138k users: the user pass
-    CHECK(mmsbm::range_count(22 * MB, 74) == 1);     // ... its pair pass: segments too short
+    CHECK(mmsbm::range_count(22 * MB, 74) == 4);     // ... its pair pass: shorter segments, wider ranges
+    CHECK(mmsbm::range_count(22 * MB, 35) == 2 && mmsbm::range_count(22 * MB, 25) == 1);
     CHECK(mmsbm::range_count(46 * MB, 565) == 16);   // 50M ratings x 88k pairs
     CHECK(mmsbm::range_count(17 * MB / 2, 104) == 8);
     CHECK(mmsbm::range_count(2 * MB, 5000) == 1);    // the table fits an L2 anyway
