@@ -67,10 +67,16 @@ class Encoder:
         (what the device library takes)."""
         cols, _ = _columns(data)
         out = np.empty((len(cols[0]), 3), dtype=np.int32, order="F")
-        self.labels = []
-        for j, col in enumerate(cols):
-            _, uniq = _factorize_as_str(col, out=out[:, j] if len(col) else None)
-            self.labels.append(uniq)
+
+        def one(j):
+            return _factorize_as_str(cols[j], out=out[:, j] if len(cols[j]) else None)[1]
+
+        if len(cols[0]) >= 1_000_000:  # the hash passes release the GIL: one thread per column
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(3) as pool:
+                self.labels = list(pool.map(one, range(3)))
+        else:
+            self.labels = [one(j) for j in range(3)]
         return out
 
     def transform(self, data, logger=None):

@@ -147,3 +147,19 @@ def test_single_process_pick_without_process_group():
     best, lik, liks = restarts.pick_max_likelihood({0: -5.0, 1: -2.5, 2: -9.0}, 3)
     assert best == 1 and lik == -2.5 and liks.tolist() == [-5.0, -2.5, -9.0]
     assert restarts.shard_restarts(8, 3, 4) == [3, 7] and restarts.shard_restarts(2, 5, 8) == []
+
+
+def test_encoder_threaded_columns_match_the_sequential_path():
+    """From a million rows on the three columns are factorised on three threads."""
+    import pandas as pd
+    import mmsbm_amd.encode as enc_mod
+    rng = np.random.default_rng(1)
+    n = 1_000_050
+    df = pd.DataFrame({"users": rng.integers(0, 5000, n), "items": rng.integers(0, 700, n).astype(str),
+                       "ratings": rng.integers(1, 6, n)})
+    enc = enc_mod.Encoder()
+    got = enc.fit_transform(df)
+    assert got.dtype == np.int32 and got.flags["F_CONTIGUOUS"]
+    for j in range(3):
+        ids, labels = enc_mod._factorize_as_str(df.iloc[:, j].to_numpy())
+        assert np.array_equal(got[:, j], ids) and enc.labels[j].tolist() == labels.tolist()
