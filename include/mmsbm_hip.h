@@ -178,6 +178,10 @@ int mmsbm_hip_time_stage(mmsbm_hip_ctx *ctx, int stage, int reps, float *mean_us
  * "quad" 0/1 (long rows: the A launch as a persistent four-unit pipeline), "lik_fast" 0/1
  * (likelihood through logarithm tables), "lik_g" 0/1/2/4/8 (its lanes per triple, 0 = automatic). */
 int mmsbm_hip_set_option(mmsbm_hip_ctx *ctx, const char *name, double value);
+/* Reads a knob back; also the read-only "ranges_pairs" / "ranges_users" (ranges the XCD-local work
+ * list of that pass uses, 1 = off) and "items_pairs" / "items_users" (work items, 0 = segments as
+ * they are). */
+int mmsbm_hip_get_option(const mmsbm_hip_ctx *ctx, const char *name, double *value);
 /* How em_iterate launches: 0 (default) = eager launches on the context's stream; 1 = replay
  * a captured hipGraph of two iterations. */
 int mmsbm_hip_set_graph_mode(mmsbm_hip_ctx *ctx, int enabled);

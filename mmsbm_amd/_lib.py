@@ -51,6 +51,7 @@ SIGNATURES = {
     "mmsbm_hip_kernel_bytes": (C.c_int, [C.c_void_p, C.c_int, c_i64p, c_i64p]),
     "mmsbm_hip_time_stage": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_f32p]),
     "mmsbm_hip_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_double]),
+    "mmsbm_hip_get_option": (C.c_int, [C.c_void_p, C.c_char_p, c_f64p]),
     "mmsbm_hip_set_graph_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "mmsbm_hip_layout_build": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_int32, c_i32p, c_i32p,
                                          c_i32p, C.c_int32, C.POINTER(C.c_void_p)]),

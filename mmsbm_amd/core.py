@@ -271,6 +271,11 @@ class HipEM:
         """Named tuning knob of the library (currently "graph")."""
         _lib.call("mmsbm_hip_set_option", self._h, name.encode(), float(value))
 
+    def get_option(self, name):
+        v = C.c_double(0.0)
+        _lib.call("mmsbm_hip_get_option", self._h, name.encode(), C.byref(v))
+        return float(v.value)
+
     def set_graph_mode(self, mode):
         """0 eager launches (default), 1 replay a captured hipGraph of two iterations."""
         _lib.call("mmsbm_hip_set_graph_mode", self._h, int(mode))

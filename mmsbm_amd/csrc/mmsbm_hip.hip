@@ -2796,6 +2796,23 @@ int mmsbm_hip_set_option(mmsbm_hip_ctx *ctx, const char *name, double value) {
   });
 }
 
+int mmsbm_hip_get_option(const mmsbm_hip_ctx *ctx, const char *name, double *value) {
+  return guarded([&] {
+    if (!ctx || !name || !value) throw std::invalid_argument("null argument");
+    const std::string key(name);
+    if (key == "graph") *value = ctx->graph_mode;
+    else if (key == "direct") *value = ctx->direct_out;
+    else if (key == "quad") *value = ctx->quad_a;
+    else if (key == "lik_fast") *value = ctx->lik_fast;
+    else if (key == "lik_g") *value = ctx->lik_g;
+    else if (key == "ranges_pairs") *value = ctx->ranges_pairs;   // read-only: XCD-local work lists,
+    else if (key == "ranges_users") *value = ctx->ranges_users;   // ranges per pass (1 = off)
+    else if (key == "items_pairs") *value = static_cast<double>(ctx->lay.pair_work.items.size());
+    else if (key == "items_users") *value = static_cast<double>(ctx->lay.user_work.items.size());
+    else throw std::invalid_argument("unknown option: " + key);
+  });
+}
+
 int mmsbm_hip_set_graph_mode(mmsbm_hip_ctx *ctx, int enabled) {
   return guarded([&] {
     if (!ctx) throw std::invalid_argument("null context");

@@ -964,3 +964,25 @@ def test_xcd_local_work_lists(hip, ranges, monkeypatch):
         em.iterate(3)
         for a, b in zip(em.select(0).get_params(), outs[0]):
             assert np.array_equal(a, b)
+
+
+def test_xcd_local_work_lists_chosen_by_the_data(hip):
+    """A shape for which the policy itself turns the XCD-local lists on (no environment override):
+    40 (item, rating) pairs with 15,000 ratings each gather a 9.6 MB theta table."""
+    rng = np.random.default_rng(12)
+    n, n_u, n_i, n_r, k, l = 600_000, 60_000, 10, 4, 20, 3
+    data = np.stack([rng.integers(0, n_u, n), rng.integers(0, n_i, n), rng.integers(0, n_r, n)], axis=1).astype(np.int64)
+    d_u, d_i = orc.degrees(data, n_u, n_i)
+    theta, eta, pr = orc.init_params(4, n_u, n_i, n_r, k, l, d_u, d_i)
+    want = orc.update_coefficients(data, theta, eta, pr)
+    t, e, p = orc.em_step(data, theta, eta, pr, d_u, d_i)
+    t, e, p = orc.em_step(data, t, e, p, d_u, d_i)
+    with make_ctx(hip, data, theta, eta, pr, swap_sides=0) as em:
+        assert em.get_option("ranges_pairs") == 8 and em.get_option("ranges_users") == 1
+        assert em.get_option("items_pairs") > 8 * 40 and em.get_option("items_users") == 0
+        for got, w, nm in zip(em.update_coefficients(), want, ("n_theta", "n_eta", "n_pr")):
+            assert rel_err(got, w) < TOL_STEP, nm
+        em.iterate(2)
+        for got, w, nm in zip(em.get_params(), (t, e, p), ("theta", "eta", "pr")):
+            assert rel_err(got, w) < 1e-11, nm
+        assert em.likelihood() == pytest.approx(float(orc.compute_likelihood(data, t, e, p)), rel=1e-11)
