@@ -842,7 +842,7 @@ def test_device_side_random_start_is_numpys(hip, k, l, swap):
             assert np.array_equal(a, b)
 
 
-@pytest.mark.parametrize("k,l", [(72, 80), (120, 120), (150, 40), (9, 158)])
+@pytest.mark.parametrize("k,l", [(64, 64), (60, 56), (72, 80), (120, 120), (150, 40), (9, 158)])
 def test_wide_group_counts_beyond_the_lds_tile(hip, k, l):
     """K, L up to ~150: the rating tile no longer fits in LDS beside the rows and is read through
     scalar loads; likelihood falls back from the table form when ITS tiles do not fit."""
