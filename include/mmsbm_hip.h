@@ -57,6 +57,9 @@ int mmsbm_hip_device_count(int *count);
 /* name: caller buffer of name_len bytes; arch e.g. "gfx950:sramecc+:xnack-". */
 int mmsbm_hip_device_info(int device, char *name, int name_len, int *compute_units,
                           int64_t *global_mem_bytes);
+/* Device memory that is free right now / in total (hipMemGetInfo): what batches of restart
+ * slots are sized from -- other contexts and processes on the same GPU already count. */
+int mmsbm_hip_device_mem(int device, int64_t *free_bytes, int64_t *total_bytes);
 
 /* ---- context = (device, encoded training triples) -------------------------------- */
 /* Replaces the per-call re-gathering of `data` in src/kernels_numpy.py:26-28 and the

@@ -22,6 +22,7 @@ SIGNATURES = {
     "mmsbm_hip_last_error": (C.c_char_p, []),
     "mmsbm_hip_device_count": (C.c_int, [c_intp]),
     "mmsbm_hip_device_info": (C.c_int, [C.c_int, C.c_char_p, C.c_int, c_intp, c_i64p]),
+    "mmsbm_hip_device_mem": (C.c_int, [C.c_int, c_i64p, c_i64p]),
     "mmsbm_hip_create": (C.c_int, [C.c_int, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                    C.c_int32, c_i32p, c_i32p, c_i32p, C.c_int,
                                    C.POINTER(C.c_void_p)]),

@@ -6,6 +6,7 @@ between calls; the EM loop of src/mmsbm.py:243-250 runs there without host round
 from __future__ import annotations
 
 import ctypes as C
+import hashlib
 
 import numpy as np
 
@@ -60,6 +61,25 @@ def split_triples(data):
     return _i32(d[:, 0]), _i32(d[:, 1]), _i32(d[:, 2])
 
 
+try:  # 128-bit XXH3: ~10 GB/s (2 ms per million (N,3) int64 rows); blake2b does ~1 GB/s
+    from xxhash import xxh3_128 as _digest128
+except ImportError:  # pragma: no cover - depends on the environment
+    def _digest128(buf):
+        return hashlib.blake2b(buf, digest_size=16)
+
+
+def data_key(data):
+    """Exact identity of a set of encoded triples: (shape, dtype, 128-bit digest over EVERY byte of
+    the first three columns).  Two training sets that differ anywhere -- two rows swapped, two
+    ratings exchanged, a re-shuffled fold -- get different keys (the level-1 cache of kernels_hip
+    and ``MMSBM.compute_likelihood`` rely on that).  Pure host code."""
+    d = np.asarray(data)
+    if d.ndim != 2 or d.shape[1] < 3:
+        raise ValueError("data must have shape (N, 3): [user_idx, item_idx, rating_idx]")
+    d = np.ascontiguousarray(d[:, :3])
+    return (d.shape, d.dtype.str, _digest128(memoryview(d).cast("B")).hexdigest())
+
+
 class HipEM:
     """Device-resident EM state for one (GPU, training set, K, L)."""
 
@@ -106,9 +126,15 @@ class HipEM:
     def set_slots(self, n_slots):
         """Hold ``n_slots`` independent restarts (parameter sets) over the same triples;
         ``iterate`` advances all of them with one set of launches, everything else acts on
-        the selected slot.  Drops all parameters and selects slot 0."""
-        _lib.call("mmsbm_hip_set_slots", self._h, int(n_slots))
-        self.slots = int(n_slots)
+        the selected slot.  Drops all parameters and selects slot 0.  If the device runs out of
+        memory the library falls back to ONE slot and this raises; ``slots`` always reports
+        what the context really holds."""
+        try:
+            _lib.call("mmsbm_hip_set_slots", self._h, int(n_slots))
+        finally:
+            n = C.c_int(1)
+            _lib.call("mmsbm_hip_slots", self._h, C.byref(n), None, None)
+            self.slots = int(n.value)
 
     def select(self, slot):
         _lib.call("mmsbm_hip_select_slot", self._h, int(slot))
@@ -127,11 +153,16 @@ class HipEM:
         _lib.call("mmsbm_hip_slots", self._h, None, None, C.byref(b))
         return int(b.value)
 
-    def max_slots(self, fraction=0.5):
-        """How many slots fit in `fraction` of the device's memory (at least 1)."""
-        mem = C.c_int64(0)
-        _lib.call("mmsbm_hip_device_info", self.device, None, 0, None, C.byref(mem))
-        return max(1, int(fraction * mem.value) // max(self.bytes_per_slot, 1))
+    def max_slots(self, fraction=0.5, sharers=1):
+        """How many slots fit in `fraction` of the memory that is FREE on the device right now
+        (hipMemGetInfo: other contexts and processes already count) plus what this context's own
+        slots hold, divided among `sharers` workers that size their batches at the same time
+        (contexts_per_device, cv_fit lanes that repeat a GPU).  At least 1."""
+        free = C.c_int64(0)
+        _lib.call("mmsbm_hip_device_mem", self.device, C.byref(free), None)
+        per = max(self.bytes_per_slot, 1)
+        mine = per * self.slots  # re-used by the next set_slots
+        return max(1, int(fraction * (free.value / max(int(sharers), 1) + mine)) // per)
 
     # -- parameters ----------------------------------------------------------------------
     def _shapes(self):

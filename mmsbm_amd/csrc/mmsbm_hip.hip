@@ -2033,6 +2033,24 @@ int mmsbm_hip_device_info(int device, char *name, int name_len, int *compute_uni
   });
 }
 
+int mmsbm_hip_device_mem(int device, int64_t *free_bytes, int64_t *total_bytes) {
+  return guarded([&] {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+      throw ApiError(MMSBM_E_NODEVICE, "no HIP device available");
+    if (device < 0 || device >= ndev) throw std::invalid_argument("device index out of range");
+    int prev = 0;
+    HIP_CHECK(hipGetDevice(&prev));
+    HIP_CHECK(hipSetDevice(device));
+    size_t f = 0, t = 0;
+    const hipError_t e = hipMemGetInfo(&f, &t);
+    (void)hipSetDevice(prev);
+    if (e != hipSuccess) throw ApiError(MMSBM_E_HIP, std::string("hipMemGetInfo: ") + hipGetErrorString(e));
+    if (free_bytes) *free_bytes = static_cast<int64_t>(f);
+    if (total_bytes) *total_bytes = static_cast<int64_t>(t);
+  });
+}
+
 int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items,
                      int32_t n_ratings, int32_t k_groups, int32_t l_groups,
                      const int32_t *user, const int32_t *item, const int32_t *rating,

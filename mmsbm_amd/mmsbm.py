@@ -22,7 +22,8 @@ from datetime import datetime
 import numpy as np
 
 from .backend import load_backend
-from .core import HipEM, normalize_with_self  # noqa: F401  (re-exported)
+from ._lib import HipLibraryError
+from .core import HipEM, data_key, normalize_with_self  # noqa: F401  (re-exported)
 from .encode import Encoder
 
 
@@ -101,6 +102,11 @@ class MMSBM:
             self._ctxs[(device, slot)] = ctx
         return ctx
 
+    def _sharers(self, device):
+        """Workers that may size a batch of restart slots on `device` at the same time."""
+        lanes = list(self.devices) if self.devices is not None else [0]
+        return max(1, self.contexts_per_device * max(1, sum(1 for d in lanes if int(d) == int(device))))
+
     def _release(self):
         for ctx in self._ctxs.values():
             ctx.close()
@@ -161,21 +167,38 @@ class MMSBM:
         ids = list(ids)
         seeds = [self.child_states[i] for i in ids] if seeds is None else list(seeds)
         if len(ids) > 1:
-            fit_in = ctx.max_slots(0.5)
-            if len(ids) > fit_in:  # memory: run what fits, then the rest
+            # memory: what is FREE on the device now, shared with the other workers on this GPU
+            fit_in = ctx.max_slots(0.5, sharers=self._sharers(device))
+            if len(ids) > fit_in:  # run what fits, then the rest
                 return (self.run_samplings(ids[:fit_in], device, slot, seeds[:fit_in]) +
                         self.run_samplings(ids[fit_in:], device, slot, seeds[fit_in:]))
-        ctx.set_slots(len(ids))
+        try:
+            ctx.set_slots(len(ids))
+        except HipLibraryError:
+            # the device ran out of memory after all (another worker got there first): the
+            # context is back to one slot; halve the batch and try again
+            if len(ids) == 1:
+                raise
+            half = len(ids) // 2
+            return (self.run_samplings(ids[:half], device, slot, seeds[:half]) +
+                    self.run_samplings(ids[half:], device, slot, seeds[half:]))
         for s, seed in enumerate(seeds):  # theta0, eta0 are drawn on the device (same PCG64 stream)
             ctx.select(s).init_params(seed)
         done = 0
         if self.debug or self.tol is not None:
-            every = 50 if self.tol is None else self.check_every  # src/mmsbm.py:252-254: every 50
+            # src/mmsbm.py:252-254 evaluates the likelihood inside the loop when j % 50 == 0, i.e.
+            # after iterations 1, 51, 101, ...; the convergence monitor (tol) checks every
+            # `check_every` iterations instead.
             last = None
             while done < self.iterations:
-                step = min(every, self.iterations - done)
+                if self.tol is None:
+                    step = min(1 if done == 0 else 50, self.iterations - done)
+                else:
+                    step = min(self.check_every, self.iterations - done)
                 ctx.iterate(step)
                 done += step
+                if self.tol is None and (done - 1) % 50 != 0:
+                    break  # the tail after the last hook: the reference logs nothing there
                 liks = np.array([ctx.select(s).likelihood() for s in range(len(ids))])
                 if self.debug:
                     for i, lik in zip(ids, liks):
@@ -293,12 +316,30 @@ class MMSBM:
                 "s2pond": rat["s2pond"].sum()}
 
     def compute_likelihood(self, data, theta, eta, pr):
-        """src/mmsbm.py:541-553 on explicit parameters (device evaluation)."""
+        """src/mmsbm.py:541-553: the likelihood of ``data`` (encoded triples -- the training set
+        or any other, e.g. a held-out split) under explicit parameters, evaluated on the device.
+        The training set re-uses the resident context; other data gets a context of its own for
+        the call."""
+        theta, eta, pr = (np.asarray(a, dtype=np.float64) for a in (theta, eta, pr))
         dev = self._device_list()[0]
-        ctx = self._ctx(dev)
-        self._resident.pop((dev, 0), None)  # slot 0 is overwritten
-        ctx.select(0).set_params(theta, eta, pr)
-        return ctx.likelihood()
+        train = getattr(self, "train", None)
+        if train is not None and (data is train or data_key(data) == self._train_key()):
+            ctx = self._ctx(dev)
+            self._resident.pop((dev, 0), None)  # slot 0 is overwritten
+            ctx.select(0).set_params(theta, eta, pr)
+            return ctx.likelihood()
+        ctx = HipEM(data, theta.shape[1], eta.shape[1], n_users=theta.shape[0], n_items=eta.shape[0],
+                    n_ratings=pr.shape[2], device=dev)
+        try:
+            ctx.set_params(theta, eta, pr)
+            return ctx.likelihood()
+        finally:
+            ctx.close()
+
+    def _train_key(self):
+        if getattr(self, "_train_key_cache", None) is None or self._train_key_cache[0] is not self.train:
+            self._train_key_cache = (self.train, data_key(self.train))
+        return self._train_key_cache[1]
 
     # ------------------------------------------------------------------ cross-validation (src/mmsbm.py:371-472)
     def cv_fit(self, data, folds=5):

@@ -28,9 +28,11 @@ def shard_restarts(sampling, rank, world):
     return list(range(rank, sampling, world))
 
 
-def init_from_env(backend=None):
+def init_from_env(backend=None, force_init=False):
     """Initialise torch.distributed from RANK/WORLD_SIZE/MASTER_* (torchrun); returns
-    (rank, world, local_rank, device).  Single process when WORLD_SIZE is unset or 1."""
+    (rank, world, local_rank, device).  Single process when WORLD_SIZE is unset or 1: no process
+    group is made then, unless ``force_init`` asks for a one-rank group (so that the collective
+    backend -- RCCL for ``nccl`` -- really runs even on one GPU)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -38,9 +40,16 @@ def init_from_env(backend=None):
     if use_gpu:
         torch.cuda.set_device(local)
     backend = backend or ("nccl" if use_gpu else "gloo")
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force_init) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
+        if "MASTER_PORT" not in os.environ:
+            if world > 1:
+                os.environ["MASTER_PORT"] = "29500"
+            else:  # a one-rank group needs no agreed port: take a free one
+                import socket
+                with socket.socket() as sock:
+                    sock.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(sock.getsockname()[1])
         dist.init_process_group(backend, rank=rank, world_size=world)
     # tensors for the collectives live where the backend wants them
     coll = torch.device("cuda", local) if (use_gpu and backend == "nccl") else torch.device("cpu")
@@ -50,7 +59,7 @@ def init_from_env(backend=None):
 
 def barrier(device=None):
     """dist.barrier() that tells RCCL which GPU this rank owns (avoids its device guess)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return
     if dist.get_backend() == "nccl" and device is not None and device.type == "cuda":
         dist.barrier(device_ids=[device.index])
@@ -78,9 +87,16 @@ def all_likelihoods(local, sampling, device=None):
                      device=_collective_device(device))
     for i, lik in local.items():
         vec[i] = float(lik)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():  # (a one-rank group still goes through RCCL)
         dist.all_reduce(vec, op=dist.ReduceOp.MAX)
     return vec.cpu().numpy()
+
+
+def collective_info():
+    """{"backend", "world_size"} of the process group the collectives run on (None: no group)."""
+    if dist.is_available() and dist.is_initialized():
+        return {"backend": dist.get_backend(), "world_size": dist.get_world_size()}
+    return {"backend": None, "world_size": 1}
 
 
 def pick_max_likelihood(local, sampling, device=None):
@@ -94,7 +110,7 @@ def pick_max_likelihood(local, sampling, device=None):
 def gather_results(local_results, sampling):
     """local_results: {restart index: result dict}.  Every rank gets the list of all
     ``sampling`` results in restart order."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return [local_results[i] for i in range(sampling)]
     parts = [None] * dist.get_world_size()
     dist.all_gather_object(parts, local_results)

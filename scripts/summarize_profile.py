@@ -5,7 +5,7 @@ committed summaries under profiles/:  <tag>_kernel_stats.csv (the --stats table,
 corrected as /opt/skills/guides/MI355X_MICROARCH.md section HBM prescribes: FETCH_SIZE and
 WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies 128-byte requests at 64 bytes, so the
 read side is doubled; WRITE_SIZE is exact)."""
-import csv, glob, json, os, sys, collections
+import csv, glob, hashlib, json, os, sys, collections
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
 config = sys.argv[2] if len(sys.argv) > 2 else "c3"
@@ -16,7 +16,8 @@ os.makedirs(dst, exist_ok=True)
 
 def short(name):
     for key, nm in (("seg_pass_kernel", "seg_pass_kernel"), ("pair_block_kernel<false", "pair_block_kernel(T+S)"),
-                    ("pair_block_kernel<true", "pair_block_kernel(A)"), ("eta_p_kernel", "eta_p_kernel"),
+                    ("pair_block_kernel<true", "pair_block_kernel(A)"), ("pair_quad_a_kernel", "pair_block_kernel(A)"),
+                    ("eta_p_kernel", "eta_p_kernel"), ("seg_combine_small_kernel", "seg_combine_small_kernel"),
                     ("seg_combine_kernel", "seg_combine_kernel"), ("likelihood_fast_kernel", "likelihood_fast_kernel"), ("log_table_kernel", "log_table_kernel"),
                     ("init_rows_kernel", "init_rows_kernel"), ("likelihood_units_kernel", "likelihood_units_kernel"),
                     ("likelihood_kernel", "likelihood_kernel"), ("prod_dist_kernel", "prod_dist_kernel")):
@@ -39,7 +40,7 @@ if stats:
         w = csv.DictWriter(fh, fieldnames=list(rows[0].keys())); w.writeheader(); w.writerows(rows)
 
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
-for part in ("fetch", "write", "l2", "sq"):
+for part in ("fetch", "write", "l2", "sq", "lds_a", "lds_b"):
     for f in newest(os.path.join(src, f"prof_{tag}_{part}", "*", "*_counter_collection.csv")):
         for r in csv.DictReader(open(f)):
             nm = short(r["Kernel_Name"])
@@ -51,9 +52,20 @@ with open(os.path.join(dst, f"{tag}_pmc.csv"), "w", newline="") as fh:
         for cn in sorted(agg[nm]):
             v = agg[nm][cn]; w.writerow([nm, cn, f"{sum(v) / len(v):.1f}", len(v)])
 
+def kernel_source_sha16():  # the same identity bench.py computes: a profile is only valid for these sources
+    h = hashlib.sha256()
+    for rel in ("mmsbm_amd/csrc/mmsbm_hip.hip", "mmsbm_amd/csrc/layout.hpp"):
+        with open(os.path.join(root, rel), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
 summary_path = os.path.join(dst, "pmc_summary.json")
 summary = json.load(open(summary_path)) if os.path.exists(summary_path) else {}
-summary.setdefault(config, {})
+summary[config] = {}
+summary.setdefault("_meta", {})[config] = {"tag": tag, "kernel_source_sha16": kernel_source_sha16(),
+                                            "stats_file": f"profiles/{tag}_kernel_stats.csv",
+                                            "pmc_file": f"profiles/{tag}_pmc.csv"}
+avg_us = {r["kernel"]: float(r["avg_us"]) for r in rows}
 for nm, cs in agg.items():
     if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
         fetch = sum(cs["FETCH_SIZE"]) / len(cs["FETCH_SIZE"]) * 1024.0
@@ -64,6 +76,12 @@ for nm, cs in agg.items():
         if "TCC_HIT_sum" in cs:
             h = sum(cs["TCC_HIT_sum"]) / len(cs["TCC_HIT_sum"]); m = sum(cs["TCC_MISS_sum"]) / len(cs["TCC_MISS_sum"])
             ent["l2_hit_rate"] = h / (h + m) if h + m else None
+        ent["avg_us"] = avg_us.get(nm)
+        for key in ("SQ_INSTS_LDS", "SQ_ACTIVE_INST_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_WAIT_INST_LDS",
+                    "SQ_LDS_IDX_ACTIVE", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU",
+                    "SQ_ACTIVE_INST_ANY"):
+            if key in cs:
+                ent[key] = sum(cs[key]) / len(cs[key])
         summary[config][nm] = ent
 json.dump(summary, open(summary_path, "w"), indent=1, sort_keys=True)
 for r in rows:

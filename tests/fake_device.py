@@ -44,7 +44,7 @@ class FakeHipEM:
     def selected(self):
         return self._sel
 
-    def max_slots(self, fraction=0.5):
+    def max_slots(self, fraction=0.5, sharers=1):
         return getattr(FakeHipEM, "MAX_SLOTS", 1 << 20)
 
     # -- parameters
