@@ -201,6 +201,11 @@ def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
+    # stdout carries exactly ONE line (rank 0's JSON): whatever libraries print while the job runs
+    # (RCCL's version banner, for one) goes to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import numpy as np  # noqa: F401
     import torch  # (before the HIP library: one HIP runtime per process)
@@ -303,10 +308,12 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cfg, rows, args.cpu_iters)
             out["gpu_over_cpu"] = its / out["cpu_baseline"]["value"]
     fence()
-    if rank == 0:
-        print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
+    if rank == 0:
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    os.close(json_fd)
 
 
 if __name__ == "__main__":

@@ -2397,6 +2397,16 @@ int mmsbm_hip_synchronize(mmsbm_hip_ctx *ctx) {
   return guarded([&] {
     if (!ctx) throw std::invalid_argument("null context");
     use_device(ctx);
+    // Short waits are polled (hipStreamQuery returns within a microsecond or two of the last kernel;
+    // a blocking wait is woken by an interrupt tens of microseconds later, which is several percent
+    // of a 2 ms run of 20 iterations); after 50 ms the thread blocks like any other waiter.
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+      const hipError_t e = hipStreamQuery(ctx->stream);
+      if (e == hipSuccess) return;
+      if (e != hipErrorNotReady) HIP_CHECK(e);
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) break;
+    }
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
   });
 }
