@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG_DIR, "libmmsbm_hip.so")
+# (MMSBM_HIP_LIBRARY: a diagnostic build of the same ABI, e.g. the phase-stamp build of scripts/)
+LIB_PATH = os.environ.get("MMSBM_HIP_LIBRARY") or os.path.join(PKG_DIR, "libmmsbm_hip.so")
 
 OK, E_INVALID, E_HIP, E_NODEVICE, E_UNSUPPORTED, E_TOOLARGE, E_INTERNAL = range(7)
 

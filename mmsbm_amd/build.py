@@ -11,6 +11,8 @@ DEPS = [SRC, os.path.join(PKG_DIR, "csrc", "layout.hpp"),
         os.path.join(os.path.dirname(PKG_DIR), "include", "mmsbm_hip.h")]
 LIB = os.path.join(PKG_DIR, "libmmsbm_hip.so")
 ARCH = "gfx950"
+# MMSBM_HIPCC_FLAGS: extra compiler flags for experiments (e.g. "-mllvm -amdgpu-kernarg-preload-count=16")
+EXTRA_FLAGS = os.environ.get("MMSBM_HIPCC_FLAGS", "").split()
 
 
 def hipcc_path() -> str:
@@ -32,7 +34,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     if not force and not is_stale():
         return LIB
     cmd = [hipcc_path(), "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-shared",
-           "-Wall", "-Wno-unused-function", "-Wl,-rpath,/opt/rocm/lib", "-o", LIB, SRC]
+           "-Wall", "-Wno-unused-function", *EXTRA_FLAGS, "-Wl,-rpath,/opt/rocm/lib", "-o", LIB, SRC]
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)

@@ -379,6 +379,20 @@ __global__ __launch_bounds__(kBlock) void seg_combine_small_kernel(CombineArgs c
 // ======================================================================================
 constexpr int kUnitPairs = 64;
 
+// Diagnostic build only (-DMMSBM_STAMPS): thread 0 of every workgroup of the pair stage records the
+// 100 MHz wall clock at its phase borders; nothing else in the kernels reads the buffer.
+#ifdef MMSBM_STAMPS
+constexpr int kStampSlots = 16, kStampBlocks = 8192;
+__device__ unsigned long long g_stamps[kStampBlocks * kStampSlots];
+#define STAMP(i)                                                                             \
+  do {                                                                                       \
+    if (threadIdx.x == 0 && blockIdx.x < kStampBlocks && blockIdx.y == 0)                    \
+      g_stamps[blockIdx.x * kStampSlots + (i)] = wall_clock64();                             \
+  } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
+
 struct PairBlockArgs {
   const double *tiles; const double *in_tab; const double *e_tab; const int32_t *pair_item;
   const mmsbm::Chunk *chunks; double *out; double *partial;
@@ -407,7 +421,10 @@ __device__ __forceinline__ void pair_block_body(const PairBlockArgs &pa,
   double *cst = lds;                                  // [dinp][CS]
   double *es = cst + static_cast<size_t>(dinp) * CS;  // [64][doutp]  gathered eta rows (DO_S) ...
   double *tout = es;                                  // ... then the mat-vec's output rows
-  __shared__ int32_t rowid[kUnitPairs];
+  STAMP(0);
+  // (the descriptor comes from memory: passing the unit -> pair-range map with the kernel arguments
+  // instead was measured slower at C3 -- A launch 11.4 vs 10.0 us -- bigger argument blocks cost more
+  // than the one dependent load they save)
   const mmsbm::Chunk ch = pa.chunks[block];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   constexpr int nthr = NT;  // 256, or 512 for long rows (more waves to share the output chunks)
@@ -448,56 +465,61 @@ __device__ __forceinline__ void pair_block_body(const PairBlockArgs &pa,
 
   for (int q0 = ch.q_begin; q0 < ch.q_end; q0 += kUnitPairs) {
     const int np = min(kUnitPairs, ch.q_end - q0);
-    __syncthreads();  // previous unit fully consumed
-    if (GATHER || DO_S) {
-      if (tid < kUnitPairs) rowid[tid] = pair_item[q0 + min(tid, np - 1)];
-      if (GATHER) __syncthreads();
-    }
-    if (!(abl & 1)) {  // input rows -> cst (transposed).  Two double2 per thread in flight.
-      const int total = np * dinp;
-      for (int t0 = tid * 2; t0 < total; t0 += nthr * 4) {
-        double2 v[2];
-        int pr[2], d[2];
+    if (q0 != ch.q_begin) __syncthreads();  // previous unit fully consumed
+    STAMP(1);
+    STAMP(2);
+    // input rows -> cst (transposed) and, for S, the gathered eta rows -> es (row-major).  Every
+    // thread fetches the item ids of its own elements itself (L1/L2 hits, no LDS hand-over and no
+    // barrier between ids and rows) and all loads of a round -- two double2 of each table per thread
+    // -- are in flight before any of them is stored to LDS.
+    {
+      const int tot_c = (abl & 1) ? 0 : np * dinp;
+      const int tot_e = (DO_S && !(abl & 2)) ? np * doutp : 0;
+      for (int t0 = tid * 2; t0 < max(tot_c, tot_e); t0 += nthr * 4) {
+        double2 v[2], w[2];
+        int pr[2], d[2], te[2];
+        size_t row_c[2], row_e[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          const int t = min(t0 + j * nthr * 2, total - 2);
+          const int t = min(t0 + j * nthr * 2, max(tot_c - 2, 0));
           pr[j] = t / dinp;
           d[j] = t - pr[j] * dinp;
-          const size_t row = GATHER ? static_cast<size_t>(rowid[pr[j]]) : static_cast<size_t>(q0 + pr[j]);
-          v[j] = *reinterpret_cast<const double2 *>(in_tab + row * dinp + d[j]);
+          row_c[j] = GATHER ? static_cast<size_t>(pair_item[q0 + pr[j]]) : static_cast<size_t>(q0 + pr[j]);
+          if (DO_S) {
+            te[j] = min(t0 + j * nthr * 2, max(tot_e - 2, 0));
+            row_e[j] = static_cast<size_t>(pair_item[q0 + te[j] / doutp]);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          v[j] = *reinterpret_cast<const double2 *>(in_tab + row_c[j] * dinp + d[j]);
+        if (DO_S) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            w[j] = *reinterpret_cast<const double2 *>(e_tab + row_e[j] * doutp + te[j] % doutp);
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          if (t0 + j * nthr * 2 < total) {
+          if (t0 + j * nthr * 2 < tot_c) {
             cst[d[j] * CS + pr[j]] = v[j].x;
             cst[(d[j] + 1) * CS + pr[j]] = v[j].y;
           }
         }
+        if (DO_S) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int t = t0 + j * nthr * 2;
+            if (t < tot_e) *reinterpret_cast<double2 *>(es + t) = w[j];
+          }
+        }
       }
-      if (np < kUnitPairs)  // ragged tail of a rating: zero the missing columns
+      if (np < kUnitPairs && !(abl & 1))  // ragged tail of a rating: zero the missing columns
         for (int t = tid; t < (kUnitPairs - np) * dinp; t += nthr)
           cst[(t / (kUnitPairs - np)) * CS + np + t % (kUnitPairs - np)] = 0.0;
     }
-    if (DO_S && !GATHER) __syncthreads();  // item ids visible
-    if (DO_S && !(abl & 2)) {  // gathered eta rows -> es (row-major)
-      const int total = np * doutp;
-      for (int t0 = tid * 2; t0 < total; t0 += nthr * 4) {
-        double2 v[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int t = min(t0 + j * nthr * 2, total - 2);
-          const int pr = t / doutp;
-          v[j] = *reinterpret_cast<const double2 *>(
-              e_tab + static_cast<size_t>(rowid[pr]) * doutp + (t - pr * doutp));
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int t = t0 + j * nthr * 2;
-          if (t < total) *reinterpret_cast<double2 *>(es + t) = v[j];
-        }
-      }
-    }
+    STAMP(3);
     __syncthreads();
+    STAMP(4);
     // ---- S: thread = (k, 4 l) slot, copies split the unit's pairs --------------------------------
     if (DO_S) {
       if (!(abl & 4) && s_active) {
@@ -522,6 +544,7 @@ __device__ __forceinline__ void pair_block_body(const PairBlockArgs &pa,
       }
       if (!DIRECT) __syncthreads();  // es is dead: its space becomes tout
     }
+    STAMP(5);
     // ---- mat-vec: lane = pair, wave = output chunk ------------------------------------------
     // (readfirstlane: tell the compiler the wave index is uniform so the tile loads scalarise)
     for (int c = __builtin_amdgcn_readfirstlane(wave); c < nch && !(abl & 8); c += nthr / 64) {
@@ -568,6 +591,7 @@ __device__ __forceinline__ void pair_block_body(const PairBlockArgs &pa,
     }
     if (DIRECT) continue;
     __syncthreads();
+    STAMP(6);
     if (!(abl & 16)) {  // the unit's 64 output rows are contiguous in memory: flat coalesced copy
       const int total = np * doutp;
       if (pa.out_mw == doutp) {
@@ -586,6 +610,7 @@ __device__ __forceinline__ void pair_block_body(const PairBlockArgs &pa,
       }
     }
   }
+  STAMP(7);
   if (DO_S) {
     if (nsub > 1) {  // the other copies hand their sums over through LDS, added in copy order
       __syncthreads();
@@ -619,14 +644,25 @@ __device__ __forceinline__ void pair_block_body(const PairBlockArgs &pa,
       }
     }
   }
+#ifdef MMSBM_STAMPS
+  __syncthreads();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  STAMP(8);
+#endif
 }
 
 constexpr int kPairBlockMax = 512;
 
 constexpr int kQuadUnits = 4;  // 64-pair units a workgroup of pair_quad_a_kernel multiplies jointly
 
+// (amdgpu_num_sgpr: a 256-thread workgroup is admitted floor(800 / (ceil(sgpr/16)*16 + 16)) times per
+// CU -- 106 SGPRs: 6, 96: 7 (MI355X_MICROARCH.md, residency).  At C3 the stage has 1,565 workgroups:
+// with 6 per CU (1,536 slots) 29 of them ran as a second round that doubled the launch's time.)
+// (second launch bound: the small-tile instantiations must stay at 7 waves per SIMD, i.e. <= 72 VGPRs,
+// for the same reason.)
 template <bool GATHER, bool DO_S, int NACC, bool TLDS, int NT, int KT, bool DIRECT>
-__global__ __launch_bounds__(NT) void pair_block_kernel(PairBlockArgs pa,
+__global__ __launch_bounds__(NT, (NACC == 1 && KT == 2 && !TLDS) ? 7 : 1)
+__attribute__((amdgpu_num_sgpr(96))) void pair_block_kernel(PairBlockArgs pa,
                                                         const double *__restrict__ tiles) {
   pair_block_body<GATHER, DO_S, NACC, TLDS, NT, KT, DIRECT>(pa, tiles, blockIdx.x);
 }
@@ -755,7 +791,7 @@ __device__ __forceinline__ void item_sum_block(
     int block, const double *__restrict__ ttab, const int32_t *__restrict__ item_off,
     const int32_t *__restrict__ item_pairs, const int32_t *__restrict__ item_deg,
     const double *__restrict__ eta, double *__restrict__ eta_new, int n_items, int lp,
-    int normalize) {
+    int normalize, const int32_t *__restrict__ item_grid, int n_ratings) {
   constexpr int B = 8;
   const int it = block * (static_cast<int>(blockDim.x) / G) + threadIdx.x / G;
   const int gl = threadIdx.x % G;
@@ -764,8 +800,29 @@ __device__ __forceinline__ void item_sum_block(
   double acc[VEC], e[VEC];
 #pragma unroll
   for (int v = 0; v < VEC; ++v) acc[v] = 0.0;
-  const int beg = item_off[it], end = item_off[it + 1];
   load_vec<VEC>(eta + static_cast<size_t>(it) * lp + lane_off, e);
+  if (item_grid) {
+    // dense data (most (item, rating) combinations occur): the item's pairs sit in a fixed-width
+    // grid row (-1: no such pair; ascending rating like the CSR list, so the sums are the same), one
+    // dependent load level less than offsets -> pair ids -> rows
+    const int32_t *row = item_grid + static_cast<size_t>(it) * n_ratings;
+    for (int j = 0; j < n_ratings; j += B) {
+      int id[B];
+      double t[B][VEC];
+#pragma unroll
+      for (int b = 0; b < B; ++b) id[b] = row[min(j + b, n_ratings - 1)];
+#pragma unroll
+      for (int b = 0; b < B; ++b) load_vec<VEC>(ttab + static_cast<size_t>(max(id[b], 0)) * lp + lane_off, t[b]);
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+        if (j + b < n_ratings && id[b] >= 0) {
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) acc[v] += t[b][v];
+        }
+      }
+    }
+  }
+  const int beg = item_grid ? 0 : item_off[it], end = item_grid ? 0 : item_off[it + 1];
   for (int j = beg; j < end; j += B) {
     int id[B];
     double t[B][VEC];
@@ -796,6 +853,7 @@ struct EtaPArgs {
   const double *eta; double *eta_new;
   int n_ratings, kp, lp, n_items, normalize, nb_p, abl;
   size_t bs_partial, bs_p, bs_t, bs_eta;  // restart slots (blockIdx.y): table strides
+  const int32_t *item_grid;               // [n_items][n_ratings] pair id or -1 (dense data), else null
 };
 
 template <int G, int VEC>
@@ -811,7 +869,7 @@ __global__ __launch_bounds__(kRedThreads) void eta_p_kernel(EtaPArgs a) {
   else
     item_sum_block<G, VEC>(blockIdx.x - a.nb_p, a.ttab + slot * a.bs_t, a.item_off, a.item_pairs,
                            a.item_deg, a.eta + slot * a.bs_eta, a.eta_new + slot * a.bs_eta,
-                           a.n_items, a.lp, a.normalize);
+                           a.n_items, a.lp, a.normalize, a.item_grid, a.n_ratings);
 }
 
 // ======================================================================================
@@ -1338,6 +1396,7 @@ struct mmsbm_hip_ctx {
   mmsbm::Layout lay;  // host copy (degrees, sizes)
   DevBuf<int32_t> pair_off, pair_user, pair_item, user_off, user_pair, item_off, item_pairs,
       item_deg, mv_chunk_off, orig_u, orig_i, orig_r;
+  DevBuf<int32_t> item_grid;  // [n_items][n_ratings] pair ids (-1: none); only for dense (item, rating) grids
   DevBuf<mmsbm::Chunk> mv_chunks;
   DevBuf<mmsbm::Chunk> lik_units;  // 64-pair units for the likelihood kernel (mv_chunks may hold 256)
   int n_lik_units = 0;
@@ -1663,25 +1722,29 @@ EtaPArgs eta_p_args(const mmsbm_hip_ctx *c, bool commit, int cols_per_block) {
   a.normalize = commit ? 1 : 0;
   a.abl = c->ablate;
   a.nb_p = (c->kp * c->lp + cols_per_block - 1) / cols_per_block;
+  a.item_grid = c->item_grid.count ? c->item_grid.ptr : nullptr;
   return a;
 }
 
-void stage_seg(mmsbm_hip_ctx *c, bool commit, bool with_users) {
+// The two triple passes.  with_pairs / with_users select the segment sets of this launch (both: one
+// launch, the pair segments' workgroups first); `st` is the stream it goes to.
+void stage_seg(mmsbm_hip_ctx *c, bool commit, bool with_pairs, bool with_users, hipStream_t st) {
   LaunchScope ls(c, K_SEG);
   const SegArgs sp = seg_pairs_args(c), su = seg_users_args(c, commit, c->n_users);
   const int per = kBlock / group_lanes(c->code_k);
-  const int bp = (sp.nseg + per - 1) / per;
+  const int bp = with_pairs ? (sp.nseg + per - 1) / per : 0;
   const int bu = with_users ? (su.nseg + per - 1) / per : 0;
   if (bp + bu > 0) {
 #define CALL(G, V) \
-  seg_pass_kernel<G, V, 4><<<slot_grid(c, bp + bu), kBlock, 0, c->stream>>>(sp, su, bp, c->kp)
+  seg_pass_kernel<G, V, 4><<<slot_grid(c, bp + bu), kBlock, 0, st>>>(sp, su, bp, c->kp)
     DISPATCH_GV(c->code_k, CALL);
 #undef CALL
   }
   // long segments were processed in pieces: add the pieces up (fixed order) and finish them
   // (splits with few pieces come first in the lists: one group of lanes each; the rest: a workgroup each)
   const mmsbm::WorkList &wp = c->lay.pair_work, &wu = c->lay.user_work;
-  const int nsp_s = wp.n_small, nsp_b = static_cast<int>(wp.splits.size()) - wp.n_small;
+  const int nsp_s = with_pairs ? wp.n_small : 0;
+  const int nsp_b = with_pairs ? static_cast<int>(wp.splits.size()) - wp.n_small : 0;
   const int nsu_s = with_users ? wu.n_small : 0;
   const int nsu_b = with_users ? static_cast<int>(wu.splits.size()) - wu.n_small : 0;
   if (nsp_s + nsu_s > 0) {
@@ -1691,7 +1754,7 @@ void stage_seg(mmsbm_hip_ctx *c, bool commit, bool with_users) {
                          su.mode, su.bs_parts, su.bs_fixed, su.bs_out};
     const int ba = (nsp_s + per - 1) / per, bb = (nsu_s + per - 1) / per;
 #define CALL(G, V) \
-  seg_combine_small_kernel<G, V><<<slot_grid(c, ba + bb), kBlock, 0, c->stream>>>(cp, cu, ba, c->kp)
+  seg_combine_small_kernel<G, V><<<slot_grid(c, ba + bb), kBlock, 0, st>>>(cp, cu, ba, c->kp)
     DISPATCH_GV(c->code_k, CALL);
 #undef CALL
   }
@@ -1702,7 +1765,7 @@ void stage_seg(mmsbm_hip_ctx *c, bool commit, bool with_users) {
                          su.mode, su.bs_parts, su.bs_fixed, su.bs_out};
     const size_t lds = static_cast<size_t>(per) * c->kp * sizeof(double);
 #define CALL(G, V) \
-  seg_combine_kernel<G, V><<<slot_grid(c, nsp_b + nsu_b), kBlock, lds, c->stream>>>(cp, cu, nsp_b, c->kp)
+  seg_combine_kernel<G, V><<<slot_grid(c, nsp_b + nsu_b), kBlock, lds, st>>>(cp, cu, nsp_b, c->kp)
     DISPATCH_GV(c->code_k, CALL);
 #undef CALL
   }
@@ -1801,7 +1864,7 @@ void stage_matvec_a(mmsbm_hip_ctx *c, int slot, int a_slot) {
 }
 
 void launch_iteration(mmsbm_hip_ctx *c, bool commit) {
-  stage_seg(c, commit, true);
+  stage_seg(c, commit, true, true, c->stream);
   stage_dense(c);
   stage_eta_p(c, commit);
   if (commit) {
@@ -2192,6 +2255,16 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
     c->item_off.upload(c->lay.item_off, s);
     c->item_pairs.upload(c->lay.item_pairs, s);
     c->item_deg.upload(c->lay.item_deg, s);
+    // at least half of all (item, rating) combinations occur and R is small: fixed-width grid of pair ids
+    if (n_ratings <= 16 && static_cast<int64_t>(c->n_pairs) * 2 >= static_cast<int64_t>(c->n_items) * n_ratings &&
+        std::getenv("MMSBM_HIP_NO_ITEMGRID") == nullptr) {
+      std::vector<int32_t> grid(static_cast<size_t>(c->n_items) * n_ratings, -1);
+      for (int r = 0; r < n_ratings; ++r)
+        for (int32_t q = c->lay.rating_off[static_cast<size_t>(r)]; q < c->lay.rating_off[static_cast<size_t>(r) + 1]; ++q)
+          grid[static_cast<size_t>(c->lay.pair_item[static_cast<size_t>(q)]) * n_ratings + r] = q;
+      c->item_grid.upload(grid, s);
+      HIP_CHECK(hipStreamSynchronize(s));  // `grid` is a local
+    }
     c->mv_chunks.upload(c->lay.mv_chunks, s);
     c->lik_units.upload(units64, s);
     c->mv_chunk_off.upload(c->lay.mv_chunk_off, s);
@@ -2778,7 +2851,7 @@ int mmsbm_hip_time_stage(mmsbm_hip_ctx *ctx, int stage, int reps, float *mean_us
     use_device(ctx);
     auto one = [&] {
       switch (stage) {
-        case K_SEG: stage_seg(ctx, true, true); break;
+        case K_SEG: stage_seg(ctx, true, true, true, ctx->stream); break;
         case K_DENSE: stage_dense(ctx); break;
         case K_ETAP: stage_eta_p(ctx, true); break;
         default: stage_matvec_a(ctx, ctx->cur, ctx->cur ^ 1); break;
@@ -2806,6 +2879,7 @@ int mmsbm_hip_set_option(mmsbm_hip_ctx *ctx, const char *name, double value) {
     const std::string key(name);
     if (key == "graph") {
       ctx->graph_mode = value != 0.0;
+
     } else if (key == "lik_fast") {
       ctx->lik_fast = value != 0.0;
     } else if (key == "lik_g") {
@@ -2848,6 +2922,16 @@ int mmsbm_hip_set_graph_mode(mmsbm_hip_ctx *ctx, int enabled) {
     ctx->drop_graphs();
   });
 }
+
+#ifdef MMSBM_STAMPS
+// diagnostic build: copy the phase stamps of the last pair-stage launch (blocks x 16 words)
+int mmsbm_hip_debug_stamps(unsigned long long *out, int n_words) {
+  return guarded([&] {
+    HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * n_words));
+  });
+}
+#endif
 
 // ---- host-only layout helpers (no device needed; used by the CPU tests) --------------------
 struct mmsbm_hip_layout {
