@@ -1250,9 +1250,9 @@ __global__ __launch_bounds__(kBlock) void omegas_kernel(
 // host side
 // ======================================================================================
 int pad_dim(int d) {  // multiples of 4: 32-byte row granules, whole chunks of 4 outputs
-  if (d <= 128) return (d + 3) / 4 * 4;
   if (d <= 256) return (d + 3) / 4 * 4;
-  return (d + 7) / 8 * 8;
+  if (d <= 512) return (d + 7) / 8 * 8;
+  return (d + 15) / 16 * 16;
 }
 
 // (G, VEC) instantiation for a padded row length: code 0..6
@@ -1264,10 +1264,11 @@ int group_code(int dp) {
   if (dp <= 64) return 2;   // G=16 VEC=4
   if (dp <= 128) return 3;  // G=32 VEC=4
   if (dp <= 256) return 4;  // G=64 VEC=4
-  return 5;                 // G=64 VEC=8
+  if (dp <= 512) return 5;  // G=64 VEC=8
+  return 6;                 // G=64 VEC=16 (up to 1,024 groups)
 }
 int group_lanes(int code) {
-  static const int g[6] = {4, 8, 16, 32, 64, 64};
+  static const int g[7] = {4, 8, 16, 32, 64, 64, 64};
   return g[code];
 }
 
@@ -1278,7 +1279,8 @@ int group_lanes(int code) {
     case 2: CALL(16, 4); break;                                   \
     case 3: CALL(32, 4); break;                                   \
     case 4: CALL(64, 4); break;                                   \
-    default: CALL(64, 8); break;                                  \
+    case 5: CALL(64, 8); break;                                   \
+    default: CALL(64, 16); break;                                 \
   }
 
 template <class T>
@@ -1390,6 +1392,7 @@ struct mmsbm_hip_ctx {
   size_t lds_t = 0, lds_a = 0;
   bool tl_t = false, tl_a = false;  // rating tile staged in LDS (T+S launch / A launch)
   bool quad_a = false;  // the A launch runs pair_quad_a_kernel (long rows)
+  bool wide = false;    // K, L beyond the LDS stage: wide_matvec / wide_slab kernels (any size)
   int ranges_pairs = 1, ranges_users = 1;  // XCD-local work lists: ranges the gathered table is cut into
   int n_cus = 256;
   size_t lds_qa = 0;
@@ -1616,6 +1619,77 @@ __global__ __launch_bounds__(kPairBlockMax) void pair_quad_a_kernel(PairBlockArg
 #undef DJ
 }
 
+// ======================================================================================
+// wide rows (K, L beyond what the 64-pair LDS stage holds: roughly K + L > 300): the pair stage in its
+// plain form, so that every (K, L) the reference accepts runs (src/kernels_numpy.py:21-79 has no size
+// limit).  Same tables, same chunk list (chunks of up to kWideChunkPairs pairs of one rating), same
+// eta_p launch behind it; only the two mat-vecs and the slab sums are done differently:
+//   wide_matvec : a workgroup takes 8 pairs, parks their input rows in LDS and walks the outputs
+//                 j = tid, tid + 256, ...: out[q, j] = sum_d in[q, d] tile[d, j] (tile rows read
+//                 coalesced from global memory / L2, each value feeding 8 pairs);
+//   wide_slab   : thread = one (k, l) column of one chunk: S[k, l] = sum_q C[q, k] eta[i_q, l].
+// Per output the association order is the LDS stage's (d ascending, one accumulator).
+// ======================================================================================
+constexpr int kWidePairs = 8, kWideChunkPairs = 1024;
+
+template <bool GATHER>
+__global__ __launch_bounds__(kBlock) void wide_matvec_kernel(PairBlockArgs pa, int subs_per_chunk) {
+  extern __shared__ double lds[];  // [kWidePairs][dinp]
+  const size_t slot = blockIdx.y;
+  const mmsbm::Chunk ch = pa.chunks[blockIdx.x / subs_per_chunk];
+  const int q0 = ch.q_begin + static_cast<int>(blockIdx.x % subs_per_chunk) * kWidePairs;
+  if (q0 >= ch.q_end) return;
+  const int np = min(kWidePairs, ch.q_end - q0);
+  const int dinp = pa.dinp, doutp = pa.doutp, tid = threadIdx.x;
+  const double *__restrict__ in_tab = pa.in_tab + slot * pa.bs_in;
+  const double *__restrict__ tile = pa.tiles + slot * pa.bs_tiles + static_cast<size_t>(ch.rating) * dinp * doutp;
+  double *__restrict__ out = pa.out + slot * pa.bs_out;
+  for (int t = tid; t < kWidePairs * dinp; t += kBlock) {
+    const int pr = t / dinp, d = t - pr * dinp;
+    double v = 0.0;
+    if (pr < np) {
+      const size_t row = GATHER ? static_cast<size_t>(pa.pair_item[q0 + pr]) : static_cast<size_t>(q0 + pr);
+      v = in_tab[row * dinp + d];
+    }
+    lds[t] = v;
+  }
+  __syncthreads();
+  const int mw = pa.out_mw, tw = doutp - mw;
+  for (int j = tid; j < doutp; j += kBlock) {
+    double acc[kWidePairs];
+#pragma unroll
+    for (int pr = 0; pr < kWidePairs; ++pr) acc[pr] = 0.0;
+    for (int d = 0; d < dinp; ++d) {
+      const double m = tile[static_cast<size_t>(d) * doutp + j];
+#pragma unroll
+      for (int pr = 0; pr < kWidePairs; ++pr) acc[pr] = fma(lds[pr * dinp + d], m, acc[pr]);
+    }
+#pragma unroll
+    for (int pr = 0; pr < kWidePairs; ++pr) {
+      if (pr < np) {
+        const size_t q = static_cast<size_t>(q0 + pr);
+        *(j < mw ? out + q * mw + j : out + pa.out_tail_off + q * tw + (j - mw)) = acc[pr];
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void wide_slab_kernel(PairBlockArgs pa, int col_blocks) {
+  const size_t slot = blockIdx.y;
+  const int chunk = blockIdx.x / col_blocks;
+  const int col = static_cast<int>(blockIdx.x % col_blocks) * kBlock + threadIdx.x;
+  const int kp = pa.dinp, lp = pa.doutp, kl = kp * lp;
+  if (col >= kl) return;
+  const mmsbm::Chunk ch = pa.chunks[chunk];
+  const double *__restrict__ ctab = pa.in_tab + slot * pa.bs_in;
+  const double *__restrict__ eta = pa.e_tab + slot * pa.bs_e;
+  const int k = col / lp, l = col - k * lp;
+  double acc = 0.0;
+  for (int q = ch.q_begin; q < ch.q_end; ++q)
+    acc = fma(ctab[static_cast<size_t>(q) * kp + k], eta[static_cast<size_t>(pa.pair_item[q]) * lp + l], acc);
+  pa.partial[slot * pa.bs_partial + static_cast<size_t>(chunk) * kl + col] = acc;
+}
+
 constexpr size_t kLdsBudget = 64 * 1024;  // dynamic LDS a launch may use without hipFuncSetAttribute
 
 constexpr size_t kLdsMax = 160 * 1024;  // with hipFuncAttributeMaxDynamicSharedMemorySize
@@ -1774,6 +1848,17 @@ void stage_seg(mmsbm_hip_ctx *c, bool commit, bool with_pairs, bool with_users, 
 
 void stage_dense(mmsbm_hip_ctx *c) {  // T = P^T C  and the K x L slabs for p
   if (c->n_chunks == 0) return;
+  if (c->wide) {
+    LaunchScope ls(c, K_DENSE);
+    const int nb = static_cast<int>(c->lay.mv_chunks.size());
+    const PairBlockArgs pa = pair_block_t_args(c);
+    const int subs = kWideChunkPairs / kWidePairs, colb = (c->kp * c->lp + kBlock - 1) / kBlock;
+    const size_t lds = static_cast<size_t>(kWidePairs) * c->kp * sizeof(double);
+    wide_matvec_kernel<false><<<slot_grid(c, nb * subs), kBlock, lds, c->stream>>>(pa, subs);
+    wide_slab_kernel<<<slot_grid(c, nb * colb), kBlock, 0, c->stream>>>(pa, colb);
+    ls.done();
+    return;
+  }
   {
     LaunchScope ls(c, K_DENSE);
     const int nb = static_cast<int>(c->lay.mv_chunks.size());
@@ -1827,7 +1912,13 @@ void stage_eta_p(mmsbm_hip_ctx *c, bool commit) {  // eta_new ; p_new, pT_new, r
 void stage_matvec_a(mmsbm_hip_ctx *c, int slot, int a_slot) {
   if (c->n_chunks == 0) return;
   LaunchScope ls(c, K_MATVEC_A);
-  if (c->quad_a) {
+  if (c->wide) {
+    const int nb = static_cast<int>(c->lay.mv_chunks.size());
+    const PairBlockArgs pa = pair_block_a_args(c, slot, a_slot);
+    const int subs = kWideChunkPairs / kWidePairs;
+    const size_t lds = static_cast<size_t>(kWidePairs) * c->lp * sizeof(double);
+    wide_matvec_kernel<true><<<slot_grid(c, nb * subs), kBlock, lds, c->stream>>>(pa, subs);
+  } else if (c->quad_a) {
     const int nb = static_cast<int>(c->lay.mv_chunks.size());
     const PairBlockArgs pa = pair_block_a_args(c, slot, a_slot);
     const dim3 grid = slot_grid(c, std::min(nb, c->n_cus));
@@ -2122,8 +2213,8 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
     if (!out) throw std::invalid_argument("null out");
     *out = nullptr;
     if (k_groups <= 0 || l_groups <= 0) throw std::invalid_argument("K and L must be positive");
-    if (k_groups > 512 || l_groups > 512)
-      throw ApiError(MMSBM_E_UNSUPPORTED, "K and L are limited to 512 groups");
+    if (k_groups > 1024 || l_groups > 1024)
+      throw ApiError(MMSBM_E_UNSUPPORTED, "K and L are limited to 1024 groups (64 lanes x 16 doubles per row)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
       throw ApiError(MMSBM_E_NODEVICE, "no HIP device available (this library has no CPU path)");
@@ -2179,11 +2270,9 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
     c->lds_a = pair_block_lds(c->lp, c->kp, c->tl_a);
     if (c->lds_t > kLdsMax) { c->tl_t = false; c->lds_t = pair_block_lds(c->kp, c->lp, false); }
     if (c->lds_a > kLdsMax) { c->tl_a = false; c->lds_a = pair_block_lds(c->lp, c->kp, false); }
-    if (c->lds_t > kLdsMax || c->lds_a > kLdsMax || c->pb_nacc > 4)
-      throw ApiError(MMSBM_E_UNSUPPORTED,
-                     "K and L too large: the 64-pair stage needs " +
-                         std::to_string(std::max(c->lds_t, c->lds_a) / 1024) +
-                         " KiB of LDS (limit 160; roughly K, L <= 150 together, or one of them small)");
+    // still too large for the 64-pair LDS stage (roughly K + L > 300): the plain wide-row kernels
+    c->wide = c->lds_t > kLdsMax || c->lds_a > kLdsMax || c->pb_nacc > 4 ||
+              std::getenv("MMSBM_HIP_FORCE_WIDE") != nullptr;
     c->split_rows = true;
     if (n_ratings > 65535)
       throw ApiError(MMSBM_E_UNSUPPORTED, "more than 65535 distinct ratings are not supported");
@@ -2194,7 +2283,8 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
     // big K x L tiles: four 64-pair units per pair_block workgroup (4x fewer slabs to write + add)
     const std::vector<mmsbm::Chunk> units64 = c->lay.mv_chunks;  // likelihood_units_kernel: <= 64 pairs
     c->n_lik_units = static_cast<int>(units64.size());
-    if (c->kp * c->lp > 1024) mmsbm::build_mv_chunks(c->lay, 4 * mmsbm::kMvChunkPairs);
+    if (c->wide) mmsbm::build_mv_chunks(c->lay, kWideChunkPairs);
+    else if (c->kp * c->lp > 1024) mmsbm::build_mv_chunks(c->lay, 4 * mmsbm::kMvChunkPairs);
     // long rows: the mat-vec's outputs go to memory straight from registers (C5: -6 % on both
     // pair_block launches); short rows are cheaper transposed through LDS and copied out flat
     // (C3: direct stores cost +1.1 / +1.7 us)
@@ -2203,7 +2293,7 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
     // everything fits (C5: 312 -> 259 us)
     c->lds_qa = (static_cast<size_t>(kQuadUnits) * c->lp * (kUnitPairs + 1) + static_cast<size_t>(c->lp) * c->kp) *
                 sizeof(double);
-    c->quad_a = c->kp * c->lp > 1024 && c->tl_a && c->pb_threads_a == kPairBlockMax &&
+    c->quad_a = !c->wide && c->kp * c->lp > 1024 && c->tl_a && c->pb_threads_a == kPairBlockMax &&
                 c->lds_qa <= kLdsMax - 2048 && c->lp <= 64;
     c->n_pairs = c->lay.n_pairs;
     c->n_chunks = static_cast<int>(c->lay.mv_chunks.size());
@@ -2889,7 +2979,7 @@ int mmsbm_hip_set_option(mmsbm_hip_ctx *ctx, const char *name, double value) {
     } else if (key == "direct") {
       ctx->direct_out = value != 0.0;
     } else if (key == "quad") {  // 0: the A launch through pair_block like every other shape
-      ctx->quad_a = value != 0.0 && ctx->kp * ctx->lp > 1024 && ctx->tl_a &&
+      ctx->quad_a = value != 0.0 && !ctx->wide && ctx->kp * ctx->lp > 1024 && ctx->tl_a &&
                     ctx->pb_threads_a == kPairBlockMax && ctx->lds_qa <= kLdsMax - 2048 && ctx->lp <= 64;
     } else {
       throw std::invalid_argument("unknown option: " + key);
@@ -2905,6 +2995,7 @@ int mmsbm_hip_get_option(const mmsbm_hip_ctx *ctx, const char *name, double *val
     if (key == "graph") *value = ctx->graph_mode;
     else if (key == "direct") *value = ctx->direct_out;
     else if (key == "quad") *value = ctx->quad_a;
+    else if (key == "wide") *value = ctx->wide;
     else if (key == "lik_fast") *value = ctx->lik_fast;
     else if (key == "lik_g") *value = ctx->lik_g;
     else if (key == "ranges_pairs") *value = ctx->ranges_pairs;   // read-only: XCD-local work lists,

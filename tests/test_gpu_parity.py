@@ -372,11 +372,10 @@ def test_c_abi_error_paths(hip):
         HipEM(np.array([[0, 0, 0], [7, 0, 0]]), 2, 2, n_users=2, n_items=1, n_ratings=1)
     assert e.value.code == _lib.E_INVALID and "out of range" in e.value.message
     with pytest.raises(_lib.HipLibraryError) as e:
-        HipEM(good, 600, 2)
-    assert e.value.code == _lib.E_UNSUPPORTED
-    with pytest.raises(_lib.HipLibraryError) as e:
-        HipEM(good, 200, 200)                               # the 64-pair stage would need > 160 KiB of LDS
-    assert e.value.code == _lib.E_UNSUPPORTED and "LDS" in e.value.message
+        HipEM(good, 1025, 2)                                # 64 lanes x 16 doubles per row is the widest form
+    assert e.value.code == _lib.E_UNSUPPORTED and "1024" in e.value.message
+    with HipEM(good, 200, 200) as em:                       # beyond the 64-pair LDS stage: wide-row kernels,
+        assert em.get_option("wide") == 1.0                 # no longer refused
     with pytest.raises(_lib.HipLibraryError) as e:
         HipEM(good, 2, 2, device=99)
     assert e.value.code == _lib.E_INVALID
@@ -865,6 +864,66 @@ def test_wide_group_counts_beyond_the_lds_tile(hip, k, l):
                 assert rel_err(got, w) < 1e-11, nm
             assert em.likelihood() == pytest.approx(float(orc.compute_likelihood(data, t, e, p)), rel=1e-11)
             assert np.allclose(em.prod_dist(data[:50]), orc.prod_dist(data[:50], t, e, p), rtol=1e-11, atol=1e-300)
+
+
+@pytest.mark.parametrize("k,l,n", [(200, 200, 3000), (170, 160, 1500), (300, 24, 1500), (8, 520, 1200), (600, 5, 900),
+                                   (1024, 3, 400)])
+def test_any_group_count_runs_wide_rows(hip, k, l, n):
+    """K, L beyond the 64-pair LDS stage (K = L = 200 and up to 1,024 groups): the reference's numpy
+    backend has no size limit (src/kernels_numpy.py:21-79); the library switches to its wide-row
+    kernels instead of refusing.  Same checks as every other shape: numerators after one step,
+    parameters + likelihood + predictions after a few iterations, either side paired with the rating."""
+    rng = np.random.default_rng(k * 7 + l)
+    n_u, n_i, n_r = 90, 40, 3
+    data = np.stack([rng.integers(0, n_u, n), rng.integers(0, n_i, n), rng.integers(0, n_r, n)], axis=1).astype(np.int64)
+    d_u, d_i = orc.degrees(data, n_u, n_i)
+    theta, eta, pr = orc.init_params(5, n_u, n_i, n_r, k, l, d_u, d_i)
+    want = orc.update_coefficients(data, theta, eta, pr)
+    t, e, p = theta, eta, pr
+    for _ in range(2):
+        t, e, p = orc.em_step(data, t, e, p, d_u, d_i)
+    for swap in (0, 1):
+        with make_ctx(hip, data, theta, eta, pr, swap_sides=swap) as em:
+            assert em.get_option("wide") == 1.0
+            assert np.array_equal(em.compute_omegas(), orc.compute_omegas(data, theta, eta, pr))   # same inputs: bit exact
+            for got, w, nm in zip(em.update_coefficients(), want, ("n_theta", "n_eta", "n_pr")):
+                assert rel_err(got, w) < TOL_STEP, (nm, rel_err(got, w))
+            em.iterate(2)
+            for got, w, nm in zip(em.get_params(), (t, e, p), ("theta", "eta", "pr")):
+                assert rel_err(got, w) < 1e-11, nm
+            assert em.likelihood() == pytest.approx(float(orc.compute_likelihood(data, t, e, p)), rel=1e-11)
+            assert np.allclose(em.prod_dist(data[:50]), orc.prod_dist(data[:50], t, e, p), rtol=1e-11, atol=1e-300)
+
+
+def test_wide_row_kernels_agree_with_the_lds_stage(hip, monkeypatch):
+    """The wide-row form forced on a shape the LDS stage handles (K=20, L=24, restart slots, long and
+    empty segments): same results to rounding (the slab sums are associated differently), same
+    mat-vec results bit for bit."""
+    rng = np.random.default_rng(3)
+    n_u, n_i, n_r, k, l = 400, 130, 5, 20, 24
+    users = np.minimum((rng.pareto(1.2, 9000) * 4).astype(np.int64), n_u - 1)
+    data = np.stack([users, rng.integers(0, n_i, 9000), rng.integers(0, n_r, 9000)], axis=1).astype(np.int64)
+    d_u, d_i = orc.degrees(data, n_u, n_i)
+    theta, eta, pr = orc.init_params(9, n_u, n_i, n_r, k, l, d_u, d_i)
+    outs = []
+    for force in (False, True):
+        if force:
+            monkeypatch.setenv("MMSBM_HIP_FORCE_WIDE", "1")
+        with hip.HipEM(data, k, l, n_u, n_i, n_r, slots=2) as em:
+            assert em.get_option("wide") == (1.0 if force else 0.0)
+            em.select(0).set_params(theta, eta, pr)
+            em.select(1).set_params(theta[::-1].copy() / 1.0, eta, pr)
+            em.iterate(3)
+            outs.append([em.select(s).get_params() for s in range(2)])
+    monkeypatch.delenv("MMSBM_HIP_FORCE_WIDE")
+    for s in range(2):
+        for a, b, nm in zip(outs[0][s], outs[1][s], ("theta", "eta", "pr")):
+            assert rel_err(b, a) < 1e-12, (s, nm)
+    t, e, p = theta, eta, pr
+    for _ in range(3):
+        t, e, p = orc.em_step(data, t, e, p, d_u, d_i)
+    for got, w in zip(outs[1][0], (t, e, p)):
+        assert rel_err(got, w) < 1e-11
 
 
 @pytest.mark.parametrize("n_r,k,l", [(1, 3, 4), (33, 5, 6), (100, 4, 3), (7, 20, 20)])
