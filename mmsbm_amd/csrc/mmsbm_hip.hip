@@ -149,12 +149,19 @@ __device__ __forceinline__ void store_vec(double *__restrict__ p, const double (
 // (tw = Kp - mw doubles per row), so a gather misses on one line of the big main part and
 // hits the small, cache-resident tail part.  mw == row width and tw == 0 describes a plain table.
 struct RowTab {
-  double *base;       // main part: row r at base + r * mw
-  size_t tail_off;    // tail part: row r at base + tail_off + r * tw
-  int mw, tw;
+  double *main;      // row r, off < mw:  main + r * rs_m + off
+  double *tail;      // row r, off >= mw: tail + r * rs_t + (off - mw)
+  int mw, tw;        // widths of the two parts (tw == 0: a plain table)
+  int rs_m, rs_t;    // row strides in doubles
+  size_t so_m, so_t; // distance between the copies of two consecutive restart slots (see below)
 };
+// Restart slots.  The two GATHERED tables (theta, A) keep the slots' copies of a row side by side:
+// row r = [slot 0 | slot 1 | ...], so rs_m = n_slots * mw, so_m = mw (and the same for the tail part).
+// One index then serves every slot and a gather of row r for all slots is ONE contiguous piece of
+// n_slots * 160 bytes at K = 20 -- whole 128-byte lines, no separate 32-byte tail access.  Streamed
+// tables (C, T, eta) are plain per-slot copies: rs_m = width, so_m = the table's size.
 __device__ __forceinline__ double *rowtab_ptr(const RowTab &t, size_t row, int off) {
-  return off < t.mw ? t.base + row * t.mw + off : t.base + t.tail_off + row * t.tw + (off - t.mw);
+  return off < t.mw ? t.main + row * t.rs_m + off : t.tail + row * t.rs_t + (off - t.mw);
 }
 
 struct SegArgs {
@@ -167,11 +174,11 @@ struct SegArgs {
   int32_t mode;  // 0: out = acc   1: out = fixed*acc/max(len,1)   2: out = fixed*acc
   const mmsbm::WorkItem *items;  // null: unit w is segment w.  Else unit w is a piece of a segment
   double *parts;                 // [n_parts][dp] partial rows of the split segments
-  // restart slots (blockIdx.y): distance in doubles between the slots' copies of each table
-  size_t bs_fixed, bs_gath, bs_out, bs_parts;
+  size_t bs_parts;               // restart slots: distance in doubles between the slots' partial rows
 };
-__device__ __forceinline__ RowTab slot_tab(RowTab t, size_t stride) {
-  t.base += static_cast<size_t>(blockIdx.y) * stride;
+__device__ __forceinline__ RowTab slot_tab(RowTab t, size_t slot) {
+  t.main += slot * t.so_m;
+  t.tail += slot * t.so_t;
   return t;
 }
 
@@ -179,8 +186,8 @@ template <int G, int VEC, int B>
 __device__ __forceinline__ void seg_body(const SegArgs &a, int unit, int dp) {
   const int gl = threadIdx.x % G;
   if (unit >= a.nseg) return;  // whole groups leave together
-  const RowTab fixed = slot_tab(a.fixed, a.bs_fixed), gath = slot_tab(a.gath, a.bs_gath),
-               outt = slot_tab(a.out, a.bs_out);
+  const RowTab fixed = slot_tab(a.fixed, blockIdx.y), gath = slot_tab(a.gath, blockIdx.y),
+               outt = slot_tab(a.out, blockIdx.y);
   int seg = unit, beg, end, part = -1;
   if (a.items) {
     const mmsbm::WorkItem it = a.items[unit];
@@ -207,9 +214,8 @@ __device__ __forceinline__ void seg_body(const SegArgs &a, int unit, int dp) {
   // dependent chain is offsets -> indices -> rows instead of one index load per batch.
   // this lane's part of every gathered row: main or tail, fixed for the whole kernel
   const bool g_main = lane_off < gath.mw;
-  const double *gbase = g_main ? gath.base + lane_off
-                               : gath.base + gath.tail_off + (lane_off - gath.mw);
-  const size_t gstride = g_main ? gath.mw : gath.tw;
+  const double *gbase = g_main ? gath.main + lane_off : gath.tail + (lane_off - gath.mw);
+  const size_t gstride = g_main ? gath.rs_m : gath.rs_t;
   constexpr int CH = (G < 16) ? 2 * G : G;  // indices fetched per chunk (two per lane in small groups)
   for (int c0 = beg; c0 < end; c0 += CH) {
     const int cnt = min(CH, end - c0);
@@ -267,6 +273,100 @@ __global__ __launch_bounds__(kBlock) void seg_pass_kernel(SegArgs sa, SegArgs sb
   seg_body<G, VEC, B>(first ? sa : sb, blk * (kBlock / G) + threadIdx.x / G, dp);
 }
 
+// The same passes for SEVERAL restart slots at once: a "super-group" of SW x G lanes walks one
+// segment for SW slots (lane = slot * G + gl).  The slots' copies of a gathered row are neighbours
+// in memory (RowTab), so one index load serves all of them and the gather of a row is one contiguous
+// piece of SW * 8 * dp bytes -- whole cache lines, no separate 32-byte tail access.  Per (segment,
+// slot) the arithmetic is exactly seg_body's (same triple order, same in-group reduction): slot s of
+// a batch is bitwise what a one-slot context computes.  blockIdx.y = group of SW slots.
+template <int G, int VEC, int B, int SW>
+__device__ __forceinline__ void seg_body_slots(const SegArgs &a, int unit, int dp, int n_slots) {
+  constexpr int GS = G * SW;
+  const int sl = threadIdx.x % GS, gl = sl % G;
+  const int slot = static_cast<int>(blockIdx.y) * SW + sl / G;
+  if (unit >= a.nseg) return;  // whole super-groups leave together
+  const bool slot_ok = slot < n_slots;
+  const size_t sidx = slot_ok ? slot : 0;
+  const RowTab fixed = slot_tab(a.fixed, sidx), gath = slot_tab(a.gath, sidx), outt = slot_tab(a.out, sidx);
+  int seg = unit, beg, end, part = -1;
+  if (a.items) {
+    const mmsbm::WorkItem it = a.items[unit];
+    seg = it.seg; beg = it.begin; end = it.end; part = it.part;
+    if (seg < 0) return;  // padding of an XCD-local work list
+  } else {
+    beg = a.off[unit];
+    end = a.off[unit + 1];
+  }
+  const bool act = gl * VEC < dp && slot_ok;
+  const int lane_off = gl * VEC < dp ? gl * VEC : 0;
+
+  double f[VEC], acc[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) acc[v] = 0.0;
+  load_vec<VEC>(rowtab_ptr(fixed, seg, lane_off), f);
+  if (!act) {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) f[v] = 0.0;
+  }
+  const bool g_main = lane_off < gath.mw;
+  const double *gbase = g_main ? gath.main + lane_off : gath.tail + (lane_off - gath.mw);
+  const size_t gstride = g_main ? gath.rs_m : gath.rs_t;
+  constexpr int CH = (GS < 16) ? 2 * GS : GS;  // indices fetched per chunk: one (or two) per lane of the super-group
+  for (int c0 = beg; c0 < end; c0 += CH) {
+    const int cnt = min(CH, end - c0);
+    const int mine0 = a.idx[c0 + min(sl, cnt - 1)];
+    const int mine1 = (CH > GS) ? a.idx[c0 + min(GS + sl, cnt - 1)] : 0;
+    for (int n = 0; n < cnt; n += B) {
+      double g[B][VEC];
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+        const int j = min(n + b, cnt - 1);
+        const int id = __shfl((CH > GS && j >= GS) ? mine1 : mine0, j, GS);
+        load_vec<VEC>(gbase + static_cast<size_t>(id) * gstride, g[b]);
+      }
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+        if (n + b < cnt) {
+          double pt = 0.0;
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) pt = fma(g[b][v], f[v], pt);
+          const double s = group_sum<G>(pt);
+          const double w = 1.0 / fmax(s, kEps);
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) acc[v] = fma(g[b][v], w, acc[v]);
+        }
+      }
+    }
+  }
+
+  if (!act) return;
+  if (part >= 0) {
+    store_vec<VEC>(a.parts + sidx * a.bs_parts + static_cast<size_t>(part) * dp + lane_off, acc);
+    return;
+  }
+  double o[VEC];
+  if (a.mode == 0) {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) o[v] = acc[v];
+  } else if (a.mode == 1) {
+    const double d = static_cast<double>(max(end - beg, 1));
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) o[v] = (f[v] * acc[v]) / d;
+  } else {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) o[v] = f[v] * acc[v];
+  }
+  store_vec<VEC>(rowtab_ptr(outt, seg, lane_off), o);
+}
+
+template <int G, int VEC, int B, int SW>
+__global__ __launch_bounds__(kBlock) void seg_pass_slots_kernel(SegArgs sa, SegArgs sb, int blocks_a,
+                                                                int dp, int n_slots) {
+  const bool first = static_cast<int>(blockIdx.x) < blocks_a;
+  const int blk = first ? blockIdx.x : blockIdx.x - blocks_a;
+  seg_body_slots<G, VEC, B, SW>(first ? sa : sb, blk * (kBlock / (G * SW)) + threadIdx.x / (G * SW), dp, n_slots);
+}
+
 // Long segments: add the pieces' partial rows in piece order and apply the epilogue.
 struct CombineArgs {
   const mmsbm::SplitSeg *splits;
@@ -274,7 +374,7 @@ struct CombineArgs {
   const int32_t *off;
   RowTab fixed, out;
   int32_t n_splits, mode;
-  size_t bs_parts, bs_fixed, bs_out;  // restart slots, as in SegArgs
+  size_t bs_parts;  // restart slots, as in SegArgs
 };
 
 // One workgroup per split segment: its kBlock/G groups add the pieces j = g, g + NG, ... (four
@@ -318,12 +418,12 @@ __global__ __launch_bounds__(kBlock) void seg_combine_kernel(CombineArgs ca, Com
     for (int v = 0; v < VEC; ++v) acc[v] += t[v];
   }
   double f[VEC], o[VEC];
-  load_vec<VEC>(rowtab_ptr(slot_tab(a.fixed, a.bs_fixed), sp.seg, lane_off), f);
+  load_vec<VEC>(rowtab_ptr(slot_tab(a.fixed, blockIdx.y), sp.seg, lane_off), f);
   const double d = static_cast<double>(max(a.off[sp.seg + 1] - a.off[sp.seg], 1));
 #pragma unroll
   for (int v = 0; v < VEC; ++v)
     o[v] = a.mode == 0 ? acc[v] : (a.mode == 1 ? (f[v] * acc[v]) / d : f[v] * acc[v]);
-  store_vec<VEC>(rowtab_ptr(slot_tab(a.out, a.bs_out), sp.seg, lane_off), o);
+  store_vec<VEC>(rowtab_ptr(slot_tab(a.out, blockIdx.y), sp.seg, lane_off), o);
 }
 
 // Split segments with few pieces (the usual case when MANY segments are cut: dense data): one group
@@ -354,12 +454,12 @@ __global__ __launch_bounds__(kBlock) void seg_combine_small_kernel(CombineArgs c
       }
   }
   double f[VEC], o[VEC];
-  load_vec<VEC>(rowtab_ptr(slot_tab(a.fixed, a.bs_fixed), sp.seg, lane_off), f);
+  load_vec<VEC>(rowtab_ptr(slot_tab(a.fixed, blockIdx.y), sp.seg, lane_off), f);
   const double d = static_cast<double>(max(a.off[sp.seg + 1] - a.off[sp.seg], 1));
 #pragma unroll
   for (int v = 0; v < VEC; ++v)
     o[v] = a.mode == 0 ? acc[v] : (a.mode == 1 ? (f[v] * acc[v]) / d : f[v] * acc[v]);
-  store_vec<VEC>(rowtab_ptr(slot_tab(a.out, a.bs_out), sp.seg, lane_off), o);
+  store_vec<VEC>(rowtab_ptr(slot_tab(a.out, blockIdx.y), sp.seg, lane_off), o);
 }
 
 // ======================================================================================
@@ -397,10 +497,17 @@ struct PairBlockArgs {
   const double *tiles; const double *in_tab; const double *e_tab; const int32_t *pair_item;
   const mmsbm::Chunk *chunks; double *out; double *partial;
   int din, dinp, doutp, spb, nsub, abl;
-  int out_mw;           // output rows: main width (== doutp: plain table) ...
-  size_t out_tail_off;  // ... and where the tail part starts (RowTab layout)
-  size_t bs_tiles, bs_in, bs_e, bs_out, bs_partial;  // restart slots (blockIdx.y): table strides
+  // output rows: `out` is a plain [rows][doutp] table (T: out_mw == doutp, out_rs == doutp) or the
+  // main part of a RowTab whose tail part starts at out_tail (A)
+  int out_mw, out_rs_m, out_rs_t;
+  double *out_tail;
+  size_t bs_tiles, bs_in, bs_e, bs_out, bs_out_t, bs_partial;  // restart slots (blockIdx.y): offsets
 };
+// element j (a multiple of 2) of output row q
+__device__ __forceinline__ double *pair_out_ptr(const PairBlockArgs &pa, double *out, double *out_tail,
+                                                size_t q, int j) {
+  return j < pa.out_mw ? out + q * pa.out_rs_m + j : out_tail + q * pa.out_rs_t + (j - pa.out_mw);
+}
 
 template <bool GATHER, bool DO_S, int NACC, bool TLDS, int NT, int KT, bool DIRECT>
 __device__ __forceinline__ void pair_block_body(const PairBlockArgs &pa,
@@ -411,6 +518,7 @@ __device__ __forceinline__ void pair_block_body(const PairBlockArgs &pa,
   const double *__restrict__ e_tab = pa.e_tab + slot * pa.bs_e;
   const int32_t *__restrict__ pair_item = pa.pair_item;
   double *__restrict__ out = pa.out + slot * pa.bs_out;
+  double *__restrict__ out_tail = pa.out_tail + slot * pa.bs_out_t;
   double *__restrict__ partial = pa.partial + slot * pa.bs_partial;
   const int dinp = pa.dinp, doutp = pa.doutp, spb = pa.spb, abl = pa.abl;  // (rows >= din are zero)
   const int nsub = pa.nsub;
@@ -578,9 +686,7 @@ __device__ __forceinline__ void pair_block_body(const PairBlockArgs &pa,
       w0.x = a0; w0.y = a1; w1.x = a2; w1.y = a3;
       if (DIRECT) {  // each lane stores its 32 bytes of row q0 + lane straight from registers
         if (lane < np && !(abl & 16)) {
-          const int j = c * 4, mw = pa.out_mw;
-          double *dst = j < mw ? out + static_cast<size_t>(q0 + lane) * mw + j
-                               : out + pa.out_tail_off + static_cast<size_t>(q0 + lane) * (doutp - mw) + (j - mw);
+          double *dst = pair_out_ptr(pa, out, out_tail, static_cast<size_t>(q0 + lane), c * 4);
           *reinterpret_cast<double2 *>(dst) = w0;
           *reinterpret_cast<double2 *>(dst + 2) = w1;
         }
@@ -594,18 +700,15 @@ __device__ __forceinline__ void pair_block_body(const PairBlockArgs &pa,
     STAMP(6);
     if (!(abl & 16)) {  // the unit's 64 output rows are contiguous in memory: flat coalesced copy
       const int total = np * doutp;
-      if (pa.out_mw == doutp) {
+      if (pa.out_mw == doutp && pa.out_rs_m == doutp) {  // plain table: the unit's rows are one block
         double *dst = out + static_cast<size_t>(q0) * doutp;
         for (int t = tid * 2; t < total; t += nthr * 2)
           *reinterpret_cast<double2 *>(dst + t) = *reinterpret_cast<const double2 *>(tout + t);
-      } else {  // RowTab output (A): main lines and tail rows are each contiguous for the unit
-        const int mw = pa.out_mw, tw = doutp - mw;
-        double *dmain = out + static_cast<size_t>(q0) * mw;
-        double *dtail = out + pa.out_tail_off + static_cast<size_t>(q0) * tw;
+      } else {  // RowTab output (A): row by row, main part and tail part
         for (int t = tid * 2; t < total; t += nthr * 2) {
           const int pr = t / doutp, j = t - pr * doutp;
-          double *dst = j < mw ? dmain + pr * mw + j : dtail + pr * tw + (j - mw);
-          *reinterpret_cast<double2 *>(dst) = *reinterpret_cast<const double2 *>(tout + t);
+          *reinterpret_cast<double2 *>(pair_out_ptr(pa, out, out_tail, static_cast<size_t>(q0 + pr), j)) =
+              *reinterpret_cast<const double2 *>(tout + t);
         }
       }
     }
@@ -1006,6 +1109,15 @@ __global__ __launch_bounds__(kBlock) void log_table_kernel(const double *__restr
   if (e < n) out[e] = log(in[e]);  // log(0) = -inf belongs to elements that are clamped, never used
 }
 
+// the same for a RowTab (theta): `out` has the one-slot layout whatever `in` has
+__global__ __launch_bounds__(kBlock) void log_rows_kernel(RowTab in, RowTab out, size_t rows, int dp) {
+  const size_t e = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (e >= rows * dp) return;
+  const size_t row = e / dp;
+  const int off = static_cast<int>(e - row * dp);
+  *rowtab_ptr(out, row, off) = log(*rowtab_ptr(in, row, off));
+}
+
 template <int LW, int G, bool TLDS>
 __global__ __launch_bounds__(kLikThreads) void likelihood_fast_kernel(
     const mmsbm::Chunk *__restrict__ units, const int32_t *__restrict__ pair_off,
@@ -1393,6 +1505,7 @@ struct mmsbm_hip_ctx {
   bool tl_t = false, tl_a = false;  // rating tile staged in LDS (T+S launch / A launch)
   bool quad_a = false;  // the A launch runs pair_quad_a_kernel (long rows)
   bool wide = false;    // K, L beyond the LDS stage: wide_matvec / wide_slab kernels (any size)
+  bool slot_waves = true;  // several slots: one super-group of lanes walks a segment for all of them
   int ranges_pairs = 1, ranges_users = 1;  // XCD-local work lists: ranges the gathered table is cut into
   int n_cus = 256;
   size_t lds_qa = 0;
@@ -1490,6 +1603,7 @@ __global__ __launch_bounds__(kPairBlockMax) void pair_quad_a_kernel(PairBlockArg
   const double *__restrict__ in_tab = pa.in_tab + slot * pa.bs_in;
   const int32_t *__restrict__ pair_item = pa.pair_item;
   double *__restrict__ out = pa.out + slot * pa.bs_out;
+  double *__restrict__ out_tail = pa.out_tail + slot * pa.bs_out_t;
   const int dinp = pa.dinp, doutp = pa.doutp;
   extern __shared__ double lds[];
   constexpr int CS = kUnitPairs + 1;
@@ -1595,13 +1709,13 @@ __global__ __launch_bounds__(kPairBlockMax) void pair_quad_a_kernel(PairBlockArg
             a[u][3] = fma(x[i][u], m1[i].y, a[u][3]);
           }
       }
-      const int j0 = c * 4, mw = pa.out_mw;
+      const int j0 = c * 4;
 #pragma unroll
       for (int u = 0; u < kQuadUnits; ++u) {
         const int pr = u * kUnitPairs + lane;
         if (pr < np_all) {
           const size_t q = static_cast<size_t>(ch.q_begin + pr);
-          double *dst = j0 < mw ? out + q * mw + j0 : out + pa.out_tail_off + q * (doutp - mw) + (j0 - mw);
+          double *dst = pair_out_ptr(pa, out, out_tail, q, j0);
           double2 w0, w1;
           w0.x = a[u][0]; w0.y = a[u][1]; w1.x = a[u][2]; w1.y = a[u][3];
           *reinterpret_cast<double2 *>(dst) = w0;
@@ -1644,6 +1758,7 @@ __global__ __launch_bounds__(kBlock) void wide_matvec_kernel(PairBlockArgs pa, i
   const double *__restrict__ in_tab = pa.in_tab + slot * pa.bs_in;
   const double *__restrict__ tile = pa.tiles + slot * pa.bs_tiles + static_cast<size_t>(ch.rating) * dinp * doutp;
   double *__restrict__ out = pa.out + slot * pa.bs_out;
+  double *__restrict__ out_tail = pa.out_tail + slot * pa.bs_out_t;
   for (int t = tid; t < kWidePairs * dinp; t += kBlock) {
     const int pr = t / dinp, d = t - pr * dinp;
     double v = 0.0;
@@ -1654,7 +1769,6 @@ __global__ __launch_bounds__(kBlock) void wide_matvec_kernel(PairBlockArgs pa, i
     lds[t] = v;
   }
   __syncthreads();
-  const int mw = pa.out_mw, tw = doutp - mw;
   for (int j = tid; j < doutp; j += kBlock) {
     double acc[kWidePairs];
 #pragma unroll
@@ -1668,7 +1782,7 @@ __global__ __launch_bounds__(kBlock) void wide_matvec_kernel(PairBlockArgs pa, i
     for (int pr = 0; pr < kWidePairs; ++pr) {
       if (pr < np) {
         const size_t q = static_cast<size_t>(q0 + pr);
-        *(j < mw ? out + q * mw + j : out + pa.out_tail_off + q * tw + (j - mw)) = acc[pr];
+        *pair_out_ptr(pa, out, out_tail, q, j) = acc[pr];
       }
     }
   }
@@ -1718,18 +1832,25 @@ void allow_big_lds(K kernel, size_t bytes) {
 // commit: parameters advance (theta, eta, p normalised, A refreshed); otherwise the
 // un-normalised numerators are left in the "next" buffers / npr.
 // split (main/tail) tables -- see RowTab: theta and A are the gathered ones, eta/C/T stream
-RowTab plain_tab(double *base, int width) { return RowTab{base, 0, width, 0}; }
-RowTab gather_tab(const mmsbm_hip_ctx *c, double *base, size_t rows) {
+RowTab plain_tab(double *base, int width, size_t slot_stride = 0) {
+  return RowTab{base, base, width, 0, width, 0, slot_stride, 0};
+}
+// A gathered table (theta, A) as seen from restart slot `slot`: the n_slots copies of every row are
+// interleaved (RowTab), main parts of all rows first, then the tail parts.
+RowTab gather_tab(const mmsbm_hip_ctx *c, double *base, size_t rows, int slot) {
   int mw = c->split_rows ? (c->kp / 16) * 16 : c->kp;  // (split_rows is always on today)
   if (mw == 0) mw = c->kp;
-  return RowTab{base, rows * static_cast<size_t>(mw), mw, c->kp - mw};
+  const int tw = c->kp - mw, ns = c->n_slots;
+  return RowTab{base + static_cast<size_t>(slot) * mw,
+                base + rows * static_cast<size_t>(ns) * mw + static_cast<size_t>(slot) * tw,
+                mw, tw, ns * mw, ns * tw, static_cast<size_t>(mw), static_cast<size_t>(tw)};
 }
 // (`b` = which of the two ping-pong buffers; the restart slot is c->base_slot)
 RowTab theta_tab(const mmsbm_hip_ctx *c, int b) {
-  return gather_tab(c, c->theta[b].at(c->base_slot), static_cast<size_t>(c->n_users));
+  return gather_tab(c, c->theta[b].ptr, static_cast<size_t>(c->n_users), c->base_slot);
 }
 RowTab a_tab(const mmsbm_hip_ctx *c, int b) {
-  return gather_tab(c, c->atab[b].at(c->base_slot), static_cast<size_t>(c->n_pairs));
+  return gather_tab(c, c->atab[b].ptr, static_cast<size_t>(c->n_pairs), c->base_slot);
 }
 dim3 slot_grid(const mmsbm_hip_ctx *c, int blocks) {
   return dim3(static_cast<unsigned>(blocks), static_cast<unsigned>(c->launch_slots), 1);
@@ -1748,10 +1869,9 @@ struct OneSlot {
 SegArgs seg_pairs_args(const mmsbm_hip_ctx *c) {  // C = sum over a pair's triples
   const bool it = !c->lay.pair_work.items.empty();
   return SegArgs{a_tab(c, c->cur), theta_tab(c, c->cur), c->pair_off.ptr, c->pair_user.ptr,
-                 plain_tab(c->ctab.at(c->base_slot), c->kp),
+                 plain_tab(c->ctab.at(c->base_slot), c->kp, c->ctab.stride),
                  it ? static_cast<int32_t>(c->lay.pair_work.items.size()) : c->n_pairs, 0,
-                 it ? c->pair_items.ptr : nullptr, c->pair_parts.at(c->base_slot),
-                 c->atab[0].stride, c->theta[0].stride, c->ctab.stride, c->pair_parts.stride};
+                 it ? c->pair_items.ptr : nullptr, c->pair_parts.at(c->base_slot), c->pair_parts.stride};
 }
 SegArgs seg_users_args(const mmsbm_hip_ctx *c, bool commit, int seg_end) {  // theta_new
   const bool it = !c->lay.user_work.items.empty();
@@ -1759,26 +1879,32 @@ SegArgs seg_users_args(const mmsbm_hip_ctx *c, bool commit, int seg_end) {  // t
                  theta_tab(c, c->cur ^ 1),
                  it ? static_cast<int32_t>(c->lay.user_work.items.size()) : seg_end,
                  commit ? 1 : 2,
-                 it ? c->user_items.ptr : nullptr, c->user_parts.at(c->base_slot),
-                 c->theta[0].stride, c->atab[0].stride, c->theta[0].stride, c->user_parts.stride};
+                 it ? c->user_items.ptr : nullptr, c->user_parts.at(c->base_slot), c->user_parts.stride};
 }
 PairBlockArgs pair_block_t_args(const mmsbm_hip_ctx *c) {
   const int s = c->base_slot;
-  return PairBlockArgs{c->p[c->cur].at(s), c->ctab.at(s),      c->eta[c->cur].at(s), c->pair_item.ptr,
-                       c->mv_chunks.ptr,   c->ttab.at(s),      c->partial.at(s),     c->k,
-                       c->kp,              c->lp,              c->pb_spb,            c->pb_nsub,
-                       c->ablate,          c->lp,              0,
-                       c->p[0].stride,     c->ctab.stride,     c->eta[0].stride,     c->ttab.stride,
-                       c->partial.stride};
+  PairBlockArgs pa{};
+  pa.tiles = c->p[c->cur].at(s); pa.in_tab = c->ctab.at(s); pa.e_tab = c->eta[c->cur].at(s);
+  pa.pair_item = c->pair_item.ptr; pa.chunks = c->mv_chunks.ptr;
+  pa.out = c->ttab.at(s); pa.partial = c->partial.at(s);
+  pa.din = c->k; pa.dinp = c->kp; pa.doutp = c->lp; pa.spb = c->pb_spb; pa.nsub = c->pb_nsub; pa.abl = c->ablate;
+  pa.out_mw = c->lp; pa.out_rs_m = c->lp; pa.out_rs_t = 0; pa.out_tail = c->ttab.at(s);
+  pa.bs_tiles = c->p[0].stride; pa.bs_in = c->ctab.stride; pa.bs_e = c->eta[0].stride;
+  pa.bs_out = c->ttab.stride; pa.bs_out_t = 0; pa.bs_partial = c->partial.stride;
+  return pa;
 }
 PairBlockArgs pair_block_a_args(const mmsbm_hip_ctx *c, int param_slot, int a_slot) {
   const int s = c->base_slot;  // (param_slot / a_slot: ping-pong buffer indices)
-  return PairBlockArgs{c->pt[param_slot].at(s), c->eta[param_slot].at(s), nullptr, c->pair_item.ptr,
-                       c->mv_chunks.ptr,        c->atab[a_slot].at(s),    nullptr, c->l,
-                       c->lp,                   c->kp,                    kBlock,  1,
-                       c->ablate,               a_tab(c, a_slot).mw,      a_tab(c, a_slot).tail_off,
-                       c->pt[0].stride,         c->eta[0].stride,         0,       c->atab[0].stride,
-                       0};
+  const RowTab at = a_tab(c, a_slot);
+  PairBlockArgs pa{};
+  pa.tiles = c->pt[param_slot].at(s); pa.in_tab = c->eta[param_slot].at(s); pa.e_tab = nullptr;
+  pa.pair_item = c->pair_item.ptr; pa.chunks = c->mv_chunks.ptr;
+  pa.out = at.main; pa.partial = nullptr;
+  pa.din = c->l; pa.dinp = c->lp; pa.doutp = c->kp; pa.spb = kBlock; pa.nsub = 1; pa.abl = c->ablate;
+  pa.out_mw = at.mw; pa.out_rs_m = at.rs_m; pa.out_rs_t = at.rs_t; pa.out_tail = at.tail;
+  pa.bs_tiles = c->pt[0].stride; pa.bs_in = c->eta[0].stride; pa.bs_e = 0;
+  pa.bs_out = at.so_m; pa.bs_out_t = at.so_t; pa.bs_partial = 0;
+  return pa;
 }
 EtaPArgs eta_p_args(const mmsbm_hip_ctx *c, bool commit, int cols_per_block) {
   const int cur = c->cur, nxt = cur ^ 1;
@@ -1806,9 +1932,39 @@ void stage_seg(mmsbm_hip_ctx *c, bool commit, bool with_pairs, bool with_users, 
   LaunchScope ls(c, K_SEG);
   const SegArgs sp = seg_pairs_args(c), su = seg_users_args(c, commit, c->n_users);
   const int per = kBlock / group_lanes(c->code_k);
-  const int bp = with_pairs ? (sp.nseg + per - 1) / per : 0;
-  const int bu = with_users ? (su.nseg + per - 1) / per : 0;
-  if (bp + bu > 0) {
+  // several restart slots: a super-group of SW x G lanes per segment (seg_pass_slots_kernel)
+  int sw = 1;
+  if (c->launch_slots > 1 && c->slot_waves) {
+    const int room = 64 / group_lanes(c->code_k);
+    while (sw * 2 <= room && sw < c->launch_slots) sw *= 2;
+  }
+  if (sw > 1) {
+    const int per_s = kBlock / (group_lanes(c->code_k) * sw);
+    const int bps = with_pairs ? (sp.nseg + per_s - 1) / per_s : 0;
+    const int bus = with_users ? (su.nseg + per_s - 1) / per_s : 0;
+    const dim3 grid(static_cast<unsigned>(bps + bus), static_cast<unsigned>((c->launch_slots + sw - 1) / sw), 1);
+    if (bps + bus > 0) {
+#define CALL_S(G, V, S) \
+  seg_pass_slots_kernel<G, V, 4, S><<<grid, kBlock, 0, st>>>(sp, su, bps, c->kp, c->launch_slots)
+      switch (c->code_k * 100 + sw) {
+        case 2: CALL_S(4, 4, 2); break;
+        case 4: CALL_S(4, 4, 4); break;
+        case 8: CALL_S(4, 4, 8); break;
+        case 16: CALL_S(4, 4, 16); break;
+        case 102: CALL_S(8, 4, 2); break;
+        case 104: CALL_S(8, 4, 4); break;
+        case 108: CALL_S(8, 4, 8); break;
+        case 202: CALL_S(16, 4, 2); break;
+        case 204: CALL_S(16, 4, 4); break;
+        case 302: CALL_S(32, 4, 2); break;
+        default: throw ApiError(MMSBM_E_INTERNAL, "seg_pass_slots: no instantiation");
+      }
+#undef CALL_S
+    }
+  }
+  const int bp = (with_pairs && sw == 1) ? (sp.nseg + per - 1) / per : 0;
+  const int bu = (with_users && sw == 1) ? (su.nseg + per - 1) / per : 0;
+  if (bp + bu > 0) {  // one slot per workgroup (blockIdx.y = slot)
 #define CALL(G, V) \
   seg_pass_kernel<G, V, 4><<<slot_grid(c, bp + bu), kBlock, 0, st>>>(sp, su, bp, c->kp)
     DISPATCH_GV(c->code_k, CALL);
@@ -1823,9 +1979,9 @@ void stage_seg(mmsbm_hip_ctx *c, bool commit, bool with_pairs, bool with_users, 
   const int nsu_b = with_users ? static_cast<int>(wu.splits.size()) - wu.n_small : 0;
   if (nsp_s + nsu_s > 0) {
     const CombineArgs cp{c->pair_splits.ptr, sp.parts, c->pair_off.ptr, sp.fixed, sp.out, nsp_s,
-                         sp.mode, sp.bs_parts, sp.bs_fixed, sp.bs_out};
+                         sp.mode, sp.bs_parts};
     const CombineArgs cu{c->user_splits.ptr, su.parts, c->user_off.ptr, su.fixed, su.out, nsu_s,
-                         su.mode, su.bs_parts, su.bs_fixed, su.bs_out};
+                         su.mode, su.bs_parts};
     const int ba = (nsp_s + per - 1) / per, bb = (nsu_s + per - 1) / per;
 #define CALL(G, V) \
   seg_combine_small_kernel<G, V><<<slot_grid(c, ba + bb), kBlock, 0, st>>>(cp, cu, ba, c->kp)
@@ -1834,9 +1990,9 @@ void stage_seg(mmsbm_hip_ctx *c, bool commit, bool with_pairs, bool with_users, 
   }
   if (nsp_b + nsu_b > 0) {
     const CombineArgs cp{c->pair_splits.ptr + wp.n_small, sp.parts, c->pair_off.ptr, sp.fixed, sp.out, nsp_b,
-                         sp.mode, sp.bs_parts, sp.bs_fixed, sp.bs_out};
+                         sp.mode, sp.bs_parts};
     const CombineArgs cu{c->user_splits.ptr + wu.n_small, su.parts, c->user_off.ptr, su.fixed, su.out, nsu_b,
-                         su.mode, su.bs_parts, su.bs_fixed, su.bs_out};
+                         su.mode, su.bs_parts};
     const size_t lds = static_cast<size_t>(per) * c->kp * sizeof(double);
 #define CALL(G, V) \
   seg_combine_kernel<G, V><<<slot_grid(c, nsp_b + nsu_b), kBlock, lds, st>>>(cp, cu, nsp_b, c->kp)
@@ -2040,8 +2196,43 @@ void alloc_state(mmsbm_hip_ctx *c, int slots) {
   c->have.assign(static_cast<size_t>(slots), 0);
 }
 
-// host (rows, d) row-major  <->  device RowTab (rows, dp) zero-padded, main + tail parts (the two
-// parts are adjacent on the device: tail_off == rows * mw), staged through pinned memory
+// host (rows, d) row-major  <->  device RowTab (rows, dp) zero-padded, main + tail parts, staged
+// through pinned memory in the one-slot layout (main rows, then tail rows): one contiguous copy when
+// the context has one slot, a strided (2-D) copy per part when the slots' rows are interleaved
+bool tab_is_packed(const RowTab &t, int rows) {
+  return t.rs_m == t.mw && t.rs_t == t.tw && (t.tw == 0 || t.tail == t.main + static_cast<size_t>(rows) * t.mw);
+}
+void copy_rows(mmsbm_hip_ctx *c, const RowTab &t, double *stage, int rows, bool to_device) {
+  const size_t e = sizeof(double);
+  if (rows == 0) return;
+  if (tab_is_packed(t, rows)) {
+    if (to_device)
+      HIP_CHECK(hipMemcpyAsync(t.main, stage, e * rows * (t.mw + t.tw), hipMemcpyHostToDevice, c->stream));
+    else
+      HIP_CHECK(hipMemcpyAsync(stage, t.main, e * rows * (t.mw + t.tw), hipMemcpyDeviceToHost, c->stream));
+    return;
+  }
+  double *stage_t = stage + static_cast<size_t>(rows) * t.mw;
+  if (to_device) {
+    HIP_CHECK(hipMemcpy2DAsync(t.main, e * t.rs_m, stage, e * t.mw, e * t.mw, rows, hipMemcpyHostToDevice, c->stream));
+    if (t.tw > 0)
+      HIP_CHECK(hipMemcpy2DAsync(t.tail, e * t.rs_t, stage_t, e * t.tw, e * t.tw, rows, hipMemcpyHostToDevice, c->stream));
+  } else {
+    HIP_CHECK(hipMemcpy2DAsync(stage, e * t.mw, t.main, e * t.rs_m, e * t.mw, rows, hipMemcpyDeviceToHost, c->stream));
+    if (t.tw > 0)
+      HIP_CHECK(hipMemcpy2DAsync(stage_t, e * t.tw, t.tail, e * t.rs_t, e * t.tw, rows, hipMemcpyDeviceToHost, c->stream));
+  }
+}
+void zero_rows(mmsbm_hip_ctx *c, const RowTab &t, int rows) {
+  const size_t e = sizeof(double);
+  if (rows == 0) return;
+  if (tab_is_packed(t, rows)) {
+    HIP_CHECK(hipMemsetAsync(t.main, 0, e * rows * (t.mw + t.tw), c->stream));
+    return;
+  }
+  HIP_CHECK(hipMemset2DAsync(t.main, e * t.rs_m, 0, e * t.mw, rows, c->stream));
+  if (t.tw > 0) HIP_CHECK(hipMemset2DAsync(t.tail, e * t.rs_t, 0, e * t.tw, rows, c->stream));
+}
 void upload_rows(mmsbm_hip_ctx *c, const RowTab &t, const double *host, int rows, int d) {
   const int dp = t.mw + t.tw, mw = t.mw, tw = t.tw;
   double *stage = c->pin.take(static_cast<size_t>(rows) * dp);
@@ -2060,13 +2251,13 @@ void upload_rows(mmsbm_hip_ctx *c, const RowTab &t, const double *host, int rows
       }
     }
   });
-  HIP_CHECK(hipMemcpyAsync(t.base, stage, sizeof(double) * rows * dp, hipMemcpyHostToDevice, c->stream));
+  copy_rows(c, t, stage, rows, true);
 }
 // enqueue the device -> pinned copy; unpack_rows after the stream has been synchronised
 double *download_rows(mmsbm_hip_ctx *c, const RowTab &t, int rows) {
   const int dp = t.mw + t.tw;
   double *stage = c->pin.take(static_cast<size_t>(rows) * dp);
-  HIP_CHECK(hipMemcpyAsync(stage, t.base, sizeof(double) * rows * dp, hipMemcpyDeviceToHost, c->stream));
+  copy_rows(c, t, stage, rows, false);
   return stage;
 }
 void unpack_rows(double *host, const double *stage, const RowTab &t, int rows, int d) {
@@ -2457,8 +2648,8 @@ int mmsbm_hip_init_params(mmsbm_hip_ctx *ctx, const uint64_t pcg64_state[4], con
     const uint64_t off_users = ctx->swapped ? n_theta_ext : 0;  // internal users' table
     const uint64_t off_items = ctx->swapped ? 0 : n_theta_ext;
     const RowTab tt = theta_tab(ctx, cur), et = plain_tab(ctx->eta[cur].at(sl), ctx->lp);
-    HIP_CHECK(hipMemsetAsync(tt.base, 0, sizeof(double) * ctx->n_users * ctx->kp, ctx->stream));  // padding
-    HIP_CHECK(hipMemsetAsync(et.base, 0, sizeof(double) * ctx->n_items * ctx->lp, ctx->stream));
+    zero_rows(ctx, tt, ctx->n_users);  // padding columns
+    zero_rows(ctx, et, ctx->n_items);
     auto blocks = [](uint64_t total) {
       return static_cast<unsigned>((total + uint64_t(kBlock) * kDrawsPerThread - 1) / (uint64_t(kBlock) * kDrawsPerThread));
     };
@@ -2612,11 +2803,13 @@ int likelihood_fast(mmsbm_hip_ctx *c) {
     log_table_kernel<<<static_cast<unsigned>((n + kBlock - 1) / kBlock), kBlock, 0, c->stream>>>(in, out, n);
   };
   const RowTab th = theta_tab(c, cur);
-  logs(th.base, c->lg_theta.ptr, nt);  // same (main + tail) layout as theta
+  const RowTab lth{c->lg_theta.ptr, c->lg_theta.ptr + static_cast<size_t>(c->n_users) * th.mw, th.mw, th.tw,
+                   th.mw, th.tw, 0, 0};  // main + tail like theta, one slot
+  if (nt > 0)
+    log_rows_kernel<<<static_cast<unsigned>((nt + kBlock - 1) / kBlock), kBlock, 0, c->stream>>>(
+        th, lth, static_cast<size_t>(c->n_users), c->kp);
   logs(c->eta[cur].at(sl), c->lg_eta.ptr, ne);
   logs(c->p[cur].at(sl), c->lg_p.ptr, np);
-  RowTab lth = th;
-  lth.base = c->lg_theta.ptr;
   const int nb = c->n_lik_units;
   if (c->lik_part.count < static_cast<size_t>(nb)) c->lik_part.alloc(nb);
   // lanes per triple and columns per lane: at most ~20 columns (40 + 40 registers) per lane
@@ -2970,6 +3163,8 @@ int mmsbm_hip_set_option(mmsbm_hip_ctx *ctx, const char *name, double value) {
     if (key == "graph") {
       ctx->graph_mode = value != 0.0;
 
+    } else if (key == "slot_waves") {  // 0: restart slots as separate workgroups (blockIdx.y) in the triple passes
+      ctx->slot_waves = value != 0.0;
     } else if (key == "lik_fast") {
       ctx->lik_fast = value != 0.0;
     } else if (key == "lik_g") {
@@ -2996,6 +3191,7 @@ int mmsbm_hip_get_option(const mmsbm_hip_ctx *ctx, const char *name, double *val
     else if (key == "direct") *value = ctx->direct_out;
     else if (key == "quad") *value = ctx->quad_a;
     else if (key == "wide") *value = ctx->wide;
+    else if (key == "slot_waves") *value = ctx->slot_waves;
     else if (key == "lik_fast") *value = ctx->lik_fast;
     else if (key == "lik_g") *value = ctx->lik_g;
     else if (key == "ranges_pairs") *value = ctx->ranges_pairs;   // read-only: XCD-local work lists,
