@@ -781,7 +781,7 @@ __attribute__((amdgpu_num_sgpr(96))) void pair_block_kernel(PairBlockArgs pa,
 // p_new as [R][Kp][Lp] and transposed [R][Lp][Kp]; optionally the raw numerators.
 // ======================================================================================
 constexpr int kRedCols = 16, kRedRows = 64, kRedGroup = 6;  // ratings per LDS pass
-constexpr int kRedThreads = kRedCols * kRedRows, kRedBatch = 4;
+constexpr int kRedThreads = kRedCols * kRedRows, kRedBatch = 5;  // 64 x 5 = 320 slabs per rating in one round (C3: 313)
 
 template <int ROWS>
 __device__ __forceinline__ void p_update_block(
@@ -797,8 +797,11 @@ __device__ __forceinline__ void p_update_block(
   for (int r0 = 0; r0 < n_ratings; r0 += kRedGroup) {
     const int nr = min(kRedGroup, n_ratings - r0);
     int c0[kRedGroup], c1[kRedGroup];
-    double s[kRedGroup];
+    double s[kRedGroup], pold[kRedGroup];
     int longest = 0;
+#pragma unroll
+    for (int j = 0; j < kRedGroup; ++j)  // (needed at the very end: fetched up front, off the tail of the chain)
+      pold[j] = (ty == 0 && ok && j < nr) ? p_old[static_cast<size_t>(r0 + j) * kl + col] : 0.0;
 #pragma unroll
     for (int j = 0; j < kRedGroup; ++j) {
       const int r = min(r0 + j, n_ratings - 1);
@@ -849,7 +852,7 @@ __device__ __forceinline__ void p_update_block(
 #pragma unroll
           for (int i = 1; i < 8; ++i) tot += red[j][i][tx];
           const size_t e = static_cast<size_t>(r0 + j) * kl + col;
-          const double raw = p_old[e] * tot;
+          const double raw = pold[j] * tot;
           npr[e] = raw;
           tot_all += raw;
           s[j] = raw;  // stays in registers for the single-group case below
