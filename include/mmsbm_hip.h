@@ -98,8 +98,9 @@ int mmsbm_hip_pcg64_doubles(const uint64_t pcg64_state[4], uint64_t offset, int6
 /* The reference runs its `sampling` restarts as independent processes over the same triples
  * (src/mmsbm.py:182-185; batching them is the TODO of README.md:188).  A context can hold
  * n_slots independent parameter sets ("slots") that share the sorted triples on the device:
- * mmsbm_hip_em_iterate advances ALL slots with one set of kernel launches (the slot is a grid
- * dimension), every other entry point (set/get_params, update_coefficients, likelihood,
+ * mmsbm_hip_em_iterate advances ALL slots with one set of kernel launches (in the two triple
+ * passes one group of lanes walks a segment for all slots: one index stream, one contiguous row
+ * gather for every restart), every other entry point (set/get_params, update_coefficients, likelihood,
  * compute_omegas, prod_dist) acts on the SELECTED slot.  Slots never interact: slot s holds
  * exactly what a one-slot context given the same parameters would hold, bit for bit.
  * set_slots drops all parameters (set_params must follow for every slot) and selects slot 0;
@@ -179,11 +180,13 @@ int mmsbm_hip_time_stage(mmsbm_hip_ctx *ctx, int stage, int reps, float *mean_us
 /* Named tuning knobs (defaults are right for normal use): "graph" 0/1 (the same switch as
  * mmsbm_hip_set_graph_mode), "direct" 0/1 (pair stage: output rows stored from registers),
  * "quad" 0/1 (long rows: the A launch as a persistent four-unit pipeline), "lik_fast" 0/1
- * (likelihood through logarithm tables), "lik_g" 0/1/2/4/8 (its lanes per triple, 0 = automatic). */
+ * (likelihood through logarithm tables), "lik_g" 0/1/2/4/8 (its lanes per triple, 0 = automatic),
+ * "slot_waves" 0/1 (several restart slots: one super-group of lanes walks a segment for all slots
+ * -- the default -- or every slot in workgroups of its own). */
 int mmsbm_hip_set_option(mmsbm_hip_ctx *ctx, const char *name, double value);
 /* Reads a knob back; also the read-only "ranges_pairs" / "ranges_users" (ranges the XCD-local work
- * list of that pass uses, 1 = off) and "items_pairs" / "items_users" (work items, 0 = segments as
- * they are). */
+ * list of that pass uses, 1 = off), "items_pairs" / "items_users" (work items, 0 = segments as
+ * they are) and "wide" (1: K, L beyond the 64-pair LDS stage, the plain wide-row kernels run). */
 int mmsbm_hip_get_option(const mmsbm_hip_ctx *ctx, const char *name, double *value);
 /* How em_iterate launches: 0 (default) = eager launches on the context's stream; 1 = replay
  * a captured hipGraph of two iterations. */
