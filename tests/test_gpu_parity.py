@@ -1045,3 +1045,59 @@ def test_xcd_local_work_lists_chosen_by_the_data(hip):
         for got, w, nm in zip(em.get_params(), (t, e, p), ("theta", "eta", "pr")):
             assert rel_err(got, w) < 1e-11, nm
         assert em.likelihood() == pytest.approx(float(orc.compute_likelihood(data, t, e, p)), rel=1e-11)
+
+
+def test_level1_cache_never_serves_another_training_set(hip):
+    """two training sets that differ only in rows the old fingerprint never sampled (two rows
+    swapped: equal shapes, equal column sums) must not share a cached device context."""
+    from mmsbm_amd import kernels_hip
+    kernels_hip.clear_cache()
+    rng = np.random.default_rng(4)
+    n, n_u, n_i, n_r, k, l = 6000, 300, 120, 4, 6, 5
+    a = np.stack([rng.integers(0, n_u, n), rng.integers(0, n_i, n), rng.integers(0, n_r, n)], axis=1).astype(np.int64)
+    b = a.copy()
+    b[[1, 2]] = b[[2, 1]]                                  # (rows 1 and 2 differ; stride of the old sample: 2)
+    assert not np.array_equal(a[1], a[2])
+    d_u, d_i = orc.degrees(a, n_u, n_i)
+    theta, eta, pr = orc.init_params(1, n_u, n_i, n_r, k, l, d_u, d_i)
+    om_a = kernels_hip.compute_omegas(a, theta, eta, pr)
+    om_b = kernels_hip.compute_omegas(b, theta, eta, pr)   # omegas come back in the ROW ORDER of `data`
+    assert np.array_equal(om_a, orc.compute_omegas(a, theta, eta, pr))
+    assert np.array_equal(om_b, orc.compute_omegas(b, theta, eta, pr))
+    assert np.array_equal(om_b[1], om_a[2]) and not np.array_equal(om_b[1], om_a[1])
+    assert len(kernels_hip._cache) == 2                    # two contexts: a miss, not a stale hit
+    kernels_hip.update_coefficients(a, theta, eta, pr)
+    assert len(kernels_hip._cache) == 2                    # ... and the same data again is a hit
+    kernels_hip.clear_cache()
+
+
+def test_compute_likelihood_on_held_out_data(hip):
+    """src/mmsbm.py:541-553 evaluates the `data` it is given: the training set through the resident
+    context, any other set through a context of its own."""
+    g = load_golden("g4_2k_k10")
+    train = g["train"]
+    mm = hip.MMSBM(10, 10, iterations=5, seed=3)
+    mm.fit_encoded(train)
+    res = mm.results[0]
+    held = train[300:900]
+    for data in (train, train.copy(), held):
+        want = float(orc.compute_likelihood(data, res["theta"], res["eta"], res["pr"]))
+        assert mm.compute_likelihood(data, res["theta"], res["eta"], res["pr"]) == pytest.approx(want, rel=1e-11)
+    mm._release()
+
+
+def test_device_memory_query_and_slot_sizing(hip):
+    import ctypes as C
+    from mmsbm_amd import _lib
+    free, total = C.c_int64(0), C.c_int64(0)
+    _lib.call("mmsbm_hip_device_mem", 0, C.byref(free), C.byref(total))
+    assert 0 < free.value <= total.value and total.value > 100 * 2**30     # an MI355X: 288 GB
+    data = orc.synthetic_triples(20_000, 2_000, 500, 5, seed=1)
+    with hip.HipEM(data, 10, 10) as em:
+        one = em.max_slots(0.5)
+        assert one >= 8 and em.max_slots(0.5, sharers=4) <= one // 2 + 1
+        assert em.max_slots(1e-12) == 1                                     # never below one slot
+        em.set_slots(3)
+        assert em.slots == 3 and em.max_slots(0.5) >= one - 3
+    with pytest.raises(_lib.HipLibraryError):
+        _lib.call("mmsbm_hip_device_mem", 99, C.byref(free), C.byref(total))
