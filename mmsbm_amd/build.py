@@ -7,7 +7,8 @@ import subprocess
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(PKG_DIR, "csrc", "mmsbm_hip.hip")
-DEPS = [SRC, os.path.join(PKG_DIR, "csrc", "layout.hpp"),
+DEPS = [SRC, os.path.join(PKG_DIR, "csrc", "layout.hpp"), os.path.join(PKG_DIR, "csrc", "layout_gpu.hpp"),
+        os.path.join(PKG_DIR, "csrc", "pcg64.hpp"),
         os.path.join(os.path.dirname(PKG_DIR), "include", "mmsbm_hip.h")]
 LIB = os.path.join(PKG_DIR, "libmmsbm_hip.so")
 ARCH = "gfx950"

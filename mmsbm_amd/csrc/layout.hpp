@@ -172,8 +172,12 @@ inline double hot_fraction(const std::vector<int32_t> &off, int64_t rows_fit) {
 
 // off: segment offsets; idx: gathered row of every triple (ascending inside a segment);
 // per_block: work items (groups of lanes) per workgroup of the pass.
+// `cuts` (optional, instead of idx): for every segment s the n_ranges + 1 positions
+// cuts[s * (n_ranges + 1) + r] = first triple of s whose row lies in range >= r (so piece r of the
+// segment is [cuts[r], cuts[r + 1])) -- what layout_gpu.hpp computes on the device, where idx lives.
 inline void build_worklist_ranges(const std::vector<int32_t> &off, const int32_t *idx, int32_t table_rows,
-                                  int32_t n_ranges, int32_t item_len, int32_t per_block, WorkList &w) {
+                                  int32_t n_ranges, int32_t item_len, int32_t per_block, WorkList &w,
+                                  const int32_t *cuts = nullptr) {
   w = WorkList();
   w.item_len = item_len;
   const int32_t nseg = int32_t(off.size()) - 1;
@@ -190,20 +194,34 @@ inline void build_worklist_ranges(const std::vector<int32_t> &off, const int32_t
       bucket[0].push_back(WorkItem{s, b, e, -1});
       continue;
     }
+    const int32_t *cs = cuts ? cuts + size_t(s) * size_t(n_ranges + 1) : nullptr;
     if (e - b < 2 * n_ranges && e - b <= item_len) {  // a handful of triples: pieces of one or two would cost
-      bucket[size_t(range_of(idx[b + (e - b) / 2]))].push_back(WorkItem{s, b, e, -1});  // more than they save
+      int32_t rm;                                     // more than they save: the middle triple's range takes it
+      if (cs) {
+        const int32_t mid = b + (e - b) / 2;
+        rm = 0;
+        while (rm + 1 < n_ranges && cs[rm + 1] <= mid) ++rm;
+      } else {
+        rm = range_of(idx[b + (e - b) / 2]);
+      }
+      bucket[size_t(rm)].push_back(WorkItem{s, b, e, -1});
       continue;  // (only these: a whole segment gathers from every range and pollutes its XCD's L2 --
     }            //  leaving all segments under 12 triples per range whole turned -33 % into +6 %)
-    int32_t t = b;
-    while (t < e) {  // next border: first triple whose row leaves range r (binary search: rows ascend)
-      const int32_t r = range_of(idx[t]);
-      int32_t lo = t, hi = e;
-      while (hi - lo > 1) {
-        const int32_t mid = lo + (hi - lo) / 2;
-        if (range_of(idx[mid]) == r) lo = mid; else hi = mid;
+    if (cs) {
+      for (int32_t r = 0; r < n_ranges; ++r)
+        for (int32_t c = cs[r]; c < cs[r + 1]; c += item_len) pieces.emplace_back(c, r);  // long pieces are cut again
+    } else {
+      int32_t t = b;
+      while (t < e) {  // next border: first triple whose row leaves range r (binary search: rows ascend)
+        const int32_t r = range_of(idx[t]);
+        int32_t lo = t, hi = e;
+        while (hi - lo > 1) {
+          const int32_t mid = lo + (hi - lo) / 2;
+          if (range_of(idx[mid]) == r) lo = mid; else hi = mid;
+        }
+        for (int32_t c = t; c < hi; c += item_len) pieces.emplace_back(c, r);  // long pieces are cut again
+        t = hi;
       }
-      for (int32_t c = t; c < hi; c += item_len) pieces.emplace_back(c, r);  // long pieces are cut again
-      t = hi;
     }
     const int32_t np = int32_t(pieces.size());
     if (np == 1) {
@@ -345,9 +363,9 @@ inline void counting_sort(int64_t n, size_t nkeys, int threads, KeyFn &&key, Emi
   });
 }
 
-inline void build_layout(int64_t n_obs, int32_t n_users, int32_t n_items, int32_t n_ratings,
-                         const int32_t *user, const int32_t *item, const int32_t *rating,
-                         int32_t target_chunks, Layout &out) {
+// Argument and id-range checks shared by the host and the device layout builders.
+inline void validate_triples(int64_t n_obs, int32_t n_users, int32_t n_items, int32_t n_ratings,
+                             const int32_t *user, const int32_t *item, const int32_t *rating) {
   if (n_obs < 0 || n_obs >= (int64_t(1) << 31) - 64)
     throw std::invalid_argument("n_obs must be in [0, 2^31)");
   if (n_users <= 0 || n_items <= 0 || n_ratings <= 0)
@@ -355,19 +373,45 @@ inline void build_layout(int64_t n_obs, int32_t n_users, int32_t n_items, int32_
   if (n_obs > 0 && (!user || !item || !rating))
     throw std::invalid_argument("null triple array");
   const int threads = layout_threads(n_obs);
-  {
-    std::vector<int64_t> bad(size_t(threads), -1);  // first offending triple of each slice
-    parallel_slices(n_obs, threads, [&](int t, int64_t a, int64_t b) {
-      for (int64_t n = a; n < b; ++n)
-        if (user[n] < 0 || user[n] >= n_users || item[n] < 0 || item[n] >= n_items ||
-            rating[n] < 0 || rating[n] >= n_ratings) {
-          bad[size_t(t)] = n;
-          return;
-        }
-    });
-    for (int64_t n : bad)
-      if (n >= 0) throw std::invalid_argument("triple " + std::to_string(n) + " has an id out of range");
+  std::vector<int64_t> bad(size_t(threads), -1);  // first offending triple of each slice
+  parallel_slices(n_obs, threads, [&](int t, int64_t a, int64_t b) {
+    for (int64_t n = a; n < b; ++n)
+      if (user[n] < 0 || user[n] >= n_users || item[n] < 0 || item[n] >= n_items ||
+          rating[n] < 0 || rating[n] >= n_ratings) {
+        bad[size_t(t)] = n;
+        return;
+      }
+  });
+  for (int64_t n : bad)
+    if (n >= 0) throw std::invalid_argument("triple " + std::to_string(n) + " has an id out of range");
+}
+
+// What follows the sorts (needs pair_off, rating_off, user_off only): the rating-homogeneous chunks
+// and the work lists.  Shared by the host builder below and the device builder (layout_gpu.hpp).
+inline void finish_layout(Layout &L, int32_t target_chunks) {
+  const int32_t n_ratings = L.n_ratings;
+  if (target_chunks < 1) target_chunks = 1;
+  int32_t cp = int32_t((int64_t(L.n_pairs) + target_chunks - 1) / target_chunks);
+  cp = std::max<int32_t>(cp, 64);
+  cp = (cp + 15) / 16 * 16;
+  L.chunk_pairs = cp;
+  L.chunks.clear();
+  L.chunk_off.assign(size_t(n_ratings) + 1, 0);
+  for (int r = 0; r < n_ratings; ++r) {
+    for (int32_t q = L.rating_off[r]; q < L.rating_off[r + 1]; q += cp)
+      L.chunks.push_back(Chunk{r, q, std::min<int32_t>(q + cp, L.rating_off[r + 1]), 0});
+    L.chunk_off[r + 1] = int32_t(L.chunks.size());
   }
+  build_mv_chunks(L, kMvChunkPairs);
+  build_worklist(L.pair_off, L.pair_work, item_length(L.n_obs, L.n_pairs), lengths_vary(L.pair_off));
+  build_worklist(L.user_off, L.user_work, item_length(L.n_obs, L.n_users), lengths_vary(L.user_off));
+}
+
+inline void build_layout(int64_t n_obs, int32_t n_users, int32_t n_items, int32_t n_ratings,
+                         const int32_t *user, const int32_t *item, const int32_t *rating,
+                         int32_t target_chunks, Layout &out) {
+  validate_triples(n_obs, n_users, n_items, n_ratings, user, item, rating);
+  const int threads = layout_threads(n_obs);
   Layout &L = out;
   L = Layout();
   L.n_obs = n_obs; L.n_users = n_users; L.n_items = n_items; L.n_ratings = n_ratings;
@@ -438,21 +482,7 @@ inline void build_layout(int64_t n_obs, int32_t n_users, int32_t n_items, int32_
     for (int q = 0; q < L.n_pairs; ++q) L.item_pairs[cur[L.pair_item[q]]++] = q;
   }
 
-  // ---- rating-homogeneous chunks --------------------------------------------------------
-  if (target_chunks < 1) target_chunks = 1;
-  int32_t cp = int32_t((int64_t(L.n_pairs) + target_chunks - 1) / target_chunks);
-  cp = std::max<int32_t>(cp, 64);
-  cp = (cp + 15) / 16 * 16;
-  L.chunk_pairs = cp;
-  L.chunk_off.assign(size_t(n_ratings) + 1, 0);
-  for (int r = 0; r < n_ratings; ++r) {
-    for (int32_t q = L.rating_off[r]; q < L.rating_off[r + 1]; q += cp)
-      L.chunks.push_back(Chunk{r, q, std::min<int32_t>(q + cp, L.rating_off[r + 1]), 0});
-    L.chunk_off[r + 1] = int32_t(L.chunks.size());
-  }
-  build_mv_chunks(L, kMvChunkPairs);
-  build_worklist(L.pair_off, L.pair_work, item_length(n_obs, L.n_pairs), lengths_vary(L.pair_off));
-  build_worklist(L.user_off, L.user_work, item_length(n_obs, n_users), lengths_vary(L.user_off));
+  finish_layout(L, target_chunks);
 }
 
 }  // namespace mmsbm

@@ -43,6 +43,7 @@
 
 #include "../../include/mmsbm_hip.h"
 #include "layout.hpp"
+#include "layout_gpu.hpp"
 #include "pcg64.hpp"
 
 namespace {
@@ -85,6 +86,7 @@ int guarded(F &&f) {
 }
 
 constexpr double kEps = 2.220446049250313e-16;  // np.finfo(float).eps, src/kernels_numpy.py:51
+constexpr int64_t kGpuLayoutMin = 100'000;       // triples from which the layout's sorts run on the device
 constexpr int kBlock = 256;
 
 // ======================================================================================
@@ -2401,8 +2403,46 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
       throw ApiError(MMSBM_E_UNSUPPORTED, "more than 65535 distinct ratings are not supported");
 
     lap("checks");
-    mmsbm::build_layout(n_obs, c->n_users, c->n_items, n_ratings, iu, ii, rating, 512, c->lay);
-    lap("host layout (sorts)");
+    // The sorts: on the host for small inputs (14 ms at 1M ratings), on the device beyond
+    // kGpuLayoutMin triples (layout_gpu.hpp; MMSBM_HIP_GPU_LAYOUT=0/1 forces either).  The id columns
+    // are uploaded first in both cases (the element-wise kernels keep them in the original order).
+    HIP_CHECK(hipSetDevice(device));
+    HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    bool gpu_layout = n_obs >= kGpuLayoutMin;
+    if (const char *g = std::getenv("MMSBM_HIP_GPU_LAYOUT")) gpu_layout = std::atoi(g) != 0;
+    mmsbm::gpu_layout::DeviceArrays dev_idx;
+    if (gpu_layout) {
+      mmsbm::validate_triples(n_obs, c->n_users, c->n_items, n_ratings, iu, ii, rating);
+      lap("id checks");
+    }
+    {
+      const size_t bytes = sizeof(int32_t) * static_cast<size_t>(n_obs);
+      c->orig_u.alloc(n_obs); c->orig_i.alloc(n_obs); c->orig_r.alloc(n_obs);
+      if (n_obs > 0 && gpu_layout) {  // (host layout: uploaded after its own id checks, below)
+        HIP_CHECK(hipMemcpyAsync(c->orig_u.ptr, iu, bytes, hipMemcpyHostToDevice, c->stream));
+        HIP_CHECK(hipMemcpyAsync(c->orig_i.ptr, ii, bytes, hipMemcpyHostToDevice, c->stream));
+        HIP_CHECK(hipMemcpyAsync(c->orig_r.ptr, rating, bytes, hipMemcpyHostToDevice, c->stream));
+        HIP_CHECK(hipStreamSynchronize(c->stream));  // the caller's buffers are free again
+        lap("id upload");
+      }
+    }
+    if (gpu_layout) {
+      try {
+        mmsbm::gpu_layout::sort_stage(c->stream, n_obs, c->n_users, c->n_items, n_ratings, c->orig_u.ptr,
+                                      c->orig_i.ptr, c->orig_r.ptr, false, c->lay, dev_idx);
+      } catch (const std::invalid_argument &) {
+        throw;
+      } catch (const std::exception &e) {
+        throw ApiError(MMSBM_E_HIP, std::string("device layout: ") + e.what());
+      }
+      c->pair_user.ptr = dev_idx.pair_user; c->pair_user.count = static_cast<size_t>(n_obs);
+      c->user_pair.ptr = dev_idx.user_pair; c->user_pair.count = static_cast<size_t>(n_obs);
+      mmsbm::finish_layout(c->lay, 512);
+      lap("device layout (sorts)");
+    } else {
+      mmsbm::build_layout(n_obs, c->n_users, c->n_items, n_ratings, iu, ii, rating, 512, c->lay);
+      lap("host layout (sorts)");
+    }
     // big K x L tiles: four 64-pair units per pair_block workgroup (4x fewer slabs to write + add)
     const std::vector<mmsbm::Chunk> units64 = c->lay.mv_chunks;  // likelihood_units_kernel: <= 64 pairs
     c->n_lik_units = static_cast<int>(units64.size());
@@ -2440,31 +2480,37 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
         int a = 0, b = 0;
         if (std::sscanf(f, "%d,%d", &a, &b) == 2 && a >= 1 && b >= 1 && a <= 512 && b <= 512) { rp = a; ru = b; }
       }
+      // (device layout: the index arrays live on the device, so the borders are found there and only the
+      // cut positions -- segments x (ranges + 1) integers -- come back)
+      std::vector<int32_t> cuts_p, cuts_u;
+      if (gpu_layout && rp > 1) cuts_p = mmsbm::gpu_layout::range_cuts(c->stream, c->lay.pair_off, c->pair_user.ptr, c->n_users, rp);
+      if (gpu_layout && ru > 1) cuts_u = mmsbm::gpu_layout::range_cuts(c->stream, c->lay.user_off, c->user_pair.ptr, c->n_pairs, ru);
       if (rp > 1)
         mmsbm::build_worklist_ranges(c->lay.pair_off, c->lay.pair_user.data(), c->n_users, rp,
-                                     mmsbm::item_length(n_obs, c->n_pairs), per, c->lay.pair_work);
+                                     mmsbm::item_length(n_obs, c->n_pairs), per, c->lay.pair_work,
+                                     gpu_layout ? cuts_p.data() : nullptr);
       if (ru > 1)
         mmsbm::build_worklist_ranges(c->lay.user_off, c->lay.user_pair.data(), c->n_pairs, ru,
-                                     mmsbm::item_length(n_obs, c->n_users), per, c->lay.user_work);
+                                     mmsbm::item_length(n_obs, c->n_users), per, c->lay.user_work,
+                                     gpu_layout ? cuts_u.data() : nullptr);
       c->ranges_pairs = rp;
       c->ranges_users = ru;
     }
     lap("xcd-local work lists");
 
-    HIP_CHECK(hipSetDevice(device));
     {
       int cus = 0;
       if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
         c->n_cus = cus;
     }
-    HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     hipStream_t s = c->stream;
-    lap("device + stream");
     c->pair_off.upload(c->lay.pair_off, s);
-    c->pair_user.upload(c->lay.pair_user, s);
     c->pair_item.upload(c->lay.pair_item, s);
     c->user_off.upload(c->lay.user_off, s);
-    c->user_pair.upload(c->lay.user_pair, s);
+    if (!gpu_layout) {  // (the device layout left these two where they were built)
+      c->pair_user.upload(c->lay.pair_user, s);
+      c->user_pair.upload(c->lay.user_pair, s);
+    }
     c->item_off.upload(c->lay.item_off, s);
     c->item_pairs.upload(c->lay.item_pairs, s);
     c->item_deg.upload(c->lay.item_deg, s);
@@ -2485,15 +2531,13 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
     c->user_items.upload(c->lay.user_work.items, s);
     c->pair_splits.upload(c->lay.pair_work.splits, s);
     c->user_splits.upload(c->lay.user_work.splits, s);
-    {
-      std::vector<int32_t> tmp;
-      tmp.assign(iu, iu + n_obs); c->orig_u.upload(tmp, s);
-      HIP_CHECK(hipStreamSynchronize(s));
-      tmp.assign(ii, ii + n_obs); c->orig_i.upload(tmp, s);
-      HIP_CHECK(hipStreamSynchronize(s));
-      tmp.assign(rating, rating + n_obs); c->orig_r.upload(tmp, s);
-      HIP_CHECK(hipStreamSynchronize(s));
+    if (!gpu_layout && n_obs > 0) {
+      const size_t bytes = sizeof(int32_t) * static_cast<size_t>(n_obs);
+      HIP_CHECK(hipMemcpyAsync(c->orig_u.ptr, iu, bytes, hipMemcpyHostToDevice, s));
+      HIP_CHECK(hipMemcpyAsync(c->orig_i.ptr, ii, bytes, hipMemcpyHostToDevice, s));
+      HIP_CHECK(hipMemcpyAsync(c->orig_r.ptr, rating, bytes, hipMemcpyHostToDevice, s));
     }
+    HIP_CHECK(hipStreamSynchronize(s));  // nothing of the caller's (or this function's) host memory is still being read
     lap("index uploads");
     alloc_state(c.get(), 1);
     c->lik_part.alloc(4096);

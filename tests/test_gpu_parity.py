@@ -1101,3 +1101,84 @@ def test_device_memory_query_and_slot_sizing(hip):
         assert em.slots == 3 and em.max_slots(0.5) >= one - 3
     with pytest.raises(_lib.HipLibraryError):
         _lib.call("mmsbm_hip_device_mem", 99, C.byref(free), C.byref(total))
+
+
+@pytest.mark.parametrize("shape", ["uniform", "skewed", "dense", "gaps"])
+def test_device_built_layout_equals_the_host_layout(hip, shape, monkeypatch):
+    """mmsbm_hip_create sorts large inputs on the GPU (layout_gpu.hpp: radix sorts, scan, lower bounds)
+    instead of the host's counting sorts.  Both must give the same context: degrees, pair count and --
+    since every sum runs in the order the layout fixes -- bit-identical numerators and parameters."""
+    rng = np.random.default_rng(11)
+    if shape == "uniform":
+        n, n_u, n_i, n_r, k, l = 60_000, 7_000, 1_500, 5, 20, 20
+        data = np.stack([rng.integers(0, n_u, n), rng.integers(0, n_i, n), rng.integers(0, n_r, n)], axis=1)
+    elif shape == "skewed":      # heavy users / items: split segments, ordered work lists
+        n, n_u, n_i, n_r, k, l = 80_000, 3_000, 900, 4, 7, 13
+        data = np.stack([np.minimum((rng.pareto(1.1, n) * 3).astype(np.int64), n_u - 1),
+                         np.minimum((rng.pareto(1.3, n) * 2).astype(np.int64), n_i - 1), rng.integers(0, n_r, n)], axis=1)
+    elif shape == "dense":       # few users and items, many duplicates of the same (u, i, r)
+        n, n_u, n_i, n_r, k, l = 50_000, 60, 40, 3, 10, 10
+        data = np.stack([rng.integers(0, n_u, n), rng.integers(0, n_i, n), rng.integers(0, n_r, n)], axis=1)
+    else:                        # ids and a whole rating that never occur; one triple only for some pairs
+        n, n_u, n_i, n_r, k, l = 5_000, 9_000, 4_000, 6, 5, 4
+        data = np.stack([rng.integers(0, n_u, n) // 3 * 3, rng.integers(0, n_i, n) // 2 * 2,
+                         rng.choice([0, 1, 3, 5], n)], axis=1)
+    data = data.astype(np.int64)
+    d_u, d_i = orc.degrees(data, n_u, n_i)
+    theta, eta, pr = orc.init_params(2, n_u, n_i, n_r, k, l, d_u, d_i)
+    outs = []
+    for gpu in ("0", "1"):
+        monkeypatch.setenv("MMSBM_HIP_GPU_LAYOUT", gpu)
+        for swap in (0, 1):
+            with hip.HipEM(data, k, l, n_u, n_i, n_r, swap_sides=swap) as em:
+                em.set_params(theta, eta, pr)
+                num = em.update_coefficients()
+                em.iterate(3)
+                outs.append((gpu, swap, em.n_pairs, em.degrees(), num, em.get_params(), em.likelihood()))
+    monkeypatch.delenv("MMSBM_HIP_GPU_LAYOUT")
+    for swap in (0, 1):
+        host, dev = (o for o in outs if o[1] == swap)
+        assert host[0] == "0" and dev[0] == "1" and host[2] == dev[2]
+        assert all(np.array_equal(a, b) for a, b in zip(host[3], dev[3]))
+        assert all(np.array_equal(a, b) for a, b in zip(host[4], dev[4]))
+        assert all(np.array_equal(a, b) for a, b in zip(host[5], dev[5]))
+        assert host[6] == dev[6]
+    want = orc.update_coefficients(data, theta, eta, pr)
+    for got, w in zip(outs[2][4], want):
+        assert rel_err(got, w) < TOL_STEP
+    # bad ids are refused before anything is uploaded, whichever builder would run
+    bad = data.copy()
+    bad[7, 1] = n_i
+    for gpu in ("0", "1"):
+        monkeypatch.setenv("MMSBM_HIP_GPU_LAYOUT", gpu)
+        with pytest.raises(Exception, match="out of range"):
+            hip.HipEM(bad, k, l, n_u, n_i, n_r)
+    monkeypatch.delenv("MMSBM_HIP_GPU_LAYOUT")
+
+
+def test_device_built_range_cuts_equal_the_host_ones(hip, monkeypatch):
+    """XCD-local work lists (segments cut at borders of the gathered index) built from cut positions
+    found on the device give the very same lists as the host builder: bit-identical results."""
+    rng = np.random.default_rng(12)
+    n, n_u, n_i, n_r, k, l = 120_000, 700, 260, 5, 10, 10
+    users = np.minimum((rng.lognormal(0.0, 1.0, n) * 60).astype(np.int64), n_u - 1)
+    data = np.stack([users, rng.integers(0, n_i, n), rng.integers(0, n_r, n)], axis=1).astype(np.int64)
+    d_u, d_i = orc.degrees(data, n_u, n_i)
+    theta, eta, pr = orc.init_params(3, n_u, n_i, n_r, k, l, d_u, d_i)
+    monkeypatch.setenv("MMSBM_HIP_RANGES", "8,16")
+    outs = []
+    for gpu in ("0", "1"):
+        monkeypatch.setenv("MMSBM_HIP_GPU_LAYOUT", gpu)
+        with hip.HipEM(data, k, l, n_u, n_i, n_r, swap_sides=0) as em:
+            assert em.get_option("ranges_pairs") == 8 and em.get_option("ranges_users") == 16
+            items = (em.get_option("items_pairs"), em.get_option("items_users"))
+            em.set_params(theta, eta, pr)
+            em.iterate(3)
+            outs.append((items, em.get_params()))
+    assert outs[0][0] == outs[1][0] and outs[0][0][0] > 0
+    assert all(np.array_equal(a, b) for a, b in zip(outs[0][1], outs[1][1]))
+    t, e, p = theta, eta, pr
+    for _ in range(3):
+        t, e, p = orc.em_step(data, t, e, p, d_u, d_i)
+    for got, w in zip(outs[1][1], (t, e, p)):
+        assert rel_err(got, w) < 1e-11
