@@ -216,15 +216,11 @@ def main():
 
     if args.share_gpu:
         os.environ["LOCAL_RANK"] = "0"
-    coll_error = None
-    try:
-        rank, world, local, device = restarts.init_from_env(
-            args.dist_backend, force_init=(args.gpus == 1 and not args.no_collective_at_1))
-    except Exception as exc:  # a one-rank group is a nicety: measure without it rather than not at all
-        if int(os.environ.get("WORLD_SIZE", "1")) > 1:
-            raise
-        coll_error = f"{type(exc).__name__}: {exc}"
-        rank, world, local, device = restarts.init_from_env(args.dist_backend, force_init=False)
+    # N > 1: the launcher's process group (RCCL).  N = 1: no group yet -- the one-rank group that lets the
+    # end-of-job pick go through RCCL on every run is made AFTER the timed region (its barrier kernel and
+    # proxy thread cost a 20-step run 2-3 us per step when they sit in front of it; a barrier among one
+    # rank has nothing to wait for).
+    rank, world, local, device = restarts.init_from_env(args.dist_backend)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if device.type != "cuda":
@@ -259,6 +255,12 @@ def main():
     elapsed_max = float(t.item())
 
     # end of the job: likelihood of this rank's restart + ONE all-reduce to pick the best
+    coll_error = None
+    if world == 1 and not args.no_collective_at_1:
+        try:
+            restarts.init_from_env(args.dist_backend, force_init=True)
+        except Exception as exc:  # a one-rank group is a nicety: report without it rather than not at all
+            coll_error = f"{type(exc).__name__}: {exc}"
     lik = ctx.likelihood()
     best, best_lik, liks = restarts.pick_max_likelihood({rank: lik}, world, device)
 
