@@ -1675,7 +1675,7 @@ __global__ __launch_bounds__(kPairBlockMax) void pair_quad_a_kernel(PairBlockArg
 //   wide_matvec : a workgroup takes 8 pairs, parks their input rows in LDS and walks the outputs
 //                 j = tid, tid + 256, ...: out[q, j] = sum_d in[q, d] tile[d, j] (tile rows read
 //                 coalesced from global memory / L2, each value feeding 8 pairs);
-//   wide_slab   : thread = one (k, l) column of one chunk: S[k, l] = sum_q C[q, k] eta[i_q, l].
+//   wide_slab   : thread = one l for 8 consecutive k of one chunk: S[k, l] = sum_q C[q, k] eta[i_q, l].
 // Per output the association order is the LDS stage's (d ascending, one accumulator).
 // ======================================================================================
 constexpr int kWidePairs = 8, kWideChunkPairs = 1024;
@@ -1722,20 +1722,46 @@ __global__ __launch_bounds__(kBlock) void wide_matvec_kernel(PairBlockArgs pa, i
   }
 }
 
-__global__ __launch_bounds__(kBlock) void wide_slab_kernel(PairBlockArgs pa, int col_blocks) {
+// thread = one l of a block of 256, for kWideKG consecutive k: every eta value read feeds kWideKG sums
+constexpr int kWideKG = 8;  // (16: the C values no longer fit the scalar registers, 921 vs 477 us)
+__global__ __launch_bounds__(kBlock) void wide_slab_kernel(PairBlockArgs pa, int k_groups, int l_blocks) {
   const size_t slot = blockIdx.y;
-  const int chunk = blockIdx.x / col_blocks;
-  const int col = static_cast<int>(blockIdx.x % col_blocks) * kBlock + threadIdx.x;
+  const int per_chunk = k_groups * l_blocks;
+  const int chunk = blockIdx.x / per_chunk, rem = blockIdx.x - chunk * per_chunk;
+  const int k0 = (rem / l_blocks) * kWideKG, l = (rem % l_blocks) * kBlock + static_cast<int>(threadIdx.x);
   const int kp = pa.dinp, lp = pa.doutp, kl = kp * lp;
-  if (col >= kl) return;
+  if (l >= lp) return;
   const mmsbm::Chunk ch = pa.chunks[chunk];
   const double *__restrict__ ctab = pa.in_tab + slot * pa.bs_in;
   const double *__restrict__ eta = pa.e_tab + slot * pa.bs_e;
-  const int k = col / lp, l = col - k * lp;
-  double acc = 0.0;
-  for (int q = ch.q_begin; q < ch.q_end; ++q)
-    acc = fma(ctab[static_cast<size_t>(q) * kp + k], eta[static_cast<size_t>(pa.pair_item[q]) * lp + l], acc);
-  pa.partial[slot * pa.bs_partial + static_cast<size_t>(chunk) * kl + col] = acc;
+  double acc[kWideKG];
+#pragma unroll
+  for (int j = 0; j < kWideKG; ++j) acc[j] = 0.0;
+  constexpr int UB = 4;  // pairs per round: their ids, eta values and C values are in flight together
+  for (int q0 = ch.q_begin; q0 < ch.q_end; q0 += UB) {
+    int id[UB];
+    double ev[UB], cv[UB][kWideKG];
+#pragma unroll
+    for (int b = 0; b < UB; ++b) id[b] = pa.pair_item[min(q0 + b, ch.q_end - 1)];
+#pragma unroll
+    for (int b = 0; b < UB; ++b) {
+      ev[b] = eta[static_cast<size_t>(id[b]) * lp + l];
+      const double *crow = ctab + static_cast<size_t>(min(q0 + b, ch.q_end - 1)) * kp + k0;  // (kp is a multiple of 4)
+#pragma unroll
+      for (int j = 0; j < kWideKG; ++j) cv[b][j] = (k0 + j < kp) ? crow[j] : 0.0;
+    }
+#pragma unroll
+    for (int b = 0; b < UB; ++b) {
+      if (q0 + b < ch.q_end) {  // (per (k, l): pairs in ascending order, one accumulator)
+#pragma unroll
+        for (int j = 0; j < kWideKG; ++j) acc[j] = fma(cv[b][j], ev[b], acc[j]);
+      }
+    }
+  }
+  double *dst = pa.partial + slot * pa.bs_partial + static_cast<size_t>(chunk) * kl;
+#pragma unroll
+  for (int j = 0; j < kWideKG; ++j)
+    if (k0 + j < kp) dst[static_cast<size_t>(k0 + j) * lp + l] = acc[j];
 }
 
 constexpr size_t kLdsBudget = 64 * 1024;  // dynamic LDS a launch may use without hipFuncSetAttribute
@@ -1942,10 +1968,12 @@ void stage_dense(mmsbm_hip_ctx *c) {  // T = P^T C  and the K x L slabs for p
     LaunchScope ls(c, K_DENSE);
     const int nb = static_cast<int>(c->lay.mv_chunks.size());
     const PairBlockArgs pa = pair_block_t_args(c);
-    const int subs = kWideChunkPairs / kWidePairs, colb = (c->kp * c->lp + kBlock - 1) / kBlock;
+    const int subs = kWideChunkPairs / kWidePairs;
+    const int kgs = (c->kp + kWideKG - 1) / kWideKG, lbs = (c->lp + kBlock - 1) / kBlock;
     const size_t lds = static_cast<size_t>(kWidePairs) * c->kp * sizeof(double);
+    allow_big_lds(wide_matvec_kernel<false>, lds);
     wide_matvec_kernel<false><<<slot_grid(c, nb * subs), kBlock, lds, c->stream>>>(pa, subs);
-    wide_slab_kernel<<<slot_grid(c, nb * colb), kBlock, 0, c->stream>>>(pa, colb);
+    wide_slab_kernel<<<slot_grid(c, nb * kgs * lbs), kBlock, 0, c->stream>>>(pa, kgs, lbs);
     ls.done();
     return;
   }
@@ -2007,6 +2035,7 @@ void stage_matvec_a(mmsbm_hip_ctx *c, int slot, int a_slot) {
     const PairBlockArgs pa = pair_block_a_args(c, slot, a_slot);
     const int subs = kWideChunkPairs / kWidePairs;
     const size_t lds = static_cast<size_t>(kWidePairs) * c->lp * sizeof(double);
+    allow_big_lds(wide_matvec_kernel<true>, lds);
     wide_matvec_kernel<true><<<slot_grid(c, nb * subs), kBlock, lds, c->stream>>>(pa, subs);
   } else if (c->quad_a) {
     const int nb = static_cast<int>(c->lay.mv_chunks.size());
