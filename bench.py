@@ -310,12 +310,12 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cfg, rows, args.cpu_iters)
             out["gpu_over_cpu"] = its / out["cpu_baseline"]["value"]
     fence()
-    if dist.is_initialized():
-        dist.destroy_process_group()
-    if rank == 0:
+    if rank == 0:  # the line first: nothing that happens while the process group is torn down can lose it
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     os.close(json_fd)
+    if dist.is_initialized():
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
