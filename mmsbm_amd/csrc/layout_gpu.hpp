@@ -12,13 +12,13 @@
 //   (item, pair id) stable radix sort by item over the pairs -> pairs of each item
 //   offsets = lower bounds of 0..n in the sorted keys
 //
-// The radix sorts and the scan are hipCUB / rocPRIM device primitives (library calls for a library
-// job: this is set-up work outside the EM loop, not one of the hot kernels); the kernels around
-// them are below.  The result is IDENTICAL to layout.hpp's (same orders, same tie rules: both
+// The radix sorts and the scan are rocPRIM device primitives (rocprim::radix_sort_keys / _pairs,
+// rocprim::inclusive_scan: library calls for a library job -- this is set-up work outside the EM loop,
+// not one of the hot kernels); the kernels around them are below.  The result is IDENTICAL to layout.hpp's (same orders, same tie rules: both
 // sorts are stable), checked by tests on the GPU box.
 #pragma once
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
+#include <rocprim/rocprim.hpp>
 
 #include <cstdint>
 #include <stdexcept>
@@ -180,15 +180,15 @@ inline void sort_stage(hipStream_t s, int64_t n_obs, int32_t n_users, int32_t n_
     Buf<int32_t> head(n), scan(n);
     make_keys<<<blocks_for(n), kThreads, 0, s>>>(d_user, d_item, d_rating, static_cast<uint64_t>(n_items), n, key_in.p);
     size_t tmp_bytes = 0;
-    check(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, key_in.p, key_out.p, n, 0, 32 + pk_bits, s), "radix sort (size)");
+    check(rocprim::radix_sort_keys(nullptr, tmp_bytes, key_in.p, key_out.p, static_cast<size_t>(n), 0u, static_cast<unsigned>(32 + pk_bits), s), "radix sort (size)");
     size_t scan_bytes = 0;
-    check(hipcub::DeviceScan::InclusiveSum(nullptr, scan_bytes, head.p, scan.p, n, s), "scan (size)");
+    check(rocprim::inclusive_scan(nullptr, scan_bytes, head.p, scan.p, static_cast<size_t>(n), rocprim::plus<int32_t>(), s), "scan (size)");
     Buf<char> tmp(std::max(tmp_bytes, scan_bytes));
     size_t tb = std::max(tmp_bytes, scan_bytes);
-    check(hipcub::DeviceRadixSort::SortKeys(tmp.p, tb, key_in.p, key_out.p, n, 0, 32 + pk_bits, s), "radix sort");
+    check(rocprim::radix_sort_keys(tmp.p, tb, key_in.p, key_out.p, static_cast<size_t>(n), 0u, static_cast<unsigned>(32 + pk_bits), s), "radix sort");
     split_keys<<<blocks_for(n), kThreads, 0, s>>>(key_out.p, n, pair_user.p, head.p);
     tb = std::max(tmp_bytes, scan_bytes);
-    check(hipcub::DeviceScan::InclusiveSum(tmp.p, tb, head.p, scan.p, n, s), "scan");
+    check(rocprim::inclusive_scan(tmp.p, tb, head.p, scan.p, static_cast<size_t>(n), rocprim::plus<int32_t>(), s), "scan");
     if (n > 0) {
       check(hipMemcpyAsync(&n_pairs, scan.p + (n - 1), sizeof(int32_t), hipMemcpyDeviceToHost, s), "n_pairs");
       check(hipStreamSynchronize(s), "sync");
@@ -207,12 +207,12 @@ inline void sort_stage(hipStream_t s, int64_t n_obs, int32_t n_users, int32_t n_
     Buf<int32_t> item_off(static_cast<size_t>(n_items) + 1), item_deg(n_items);
     iota<<<blocks_for(n_pairs), kThreads, 0, s>>>(q_iota.p, n_pairs);
     size_t ip_bytes = 0;
-    check(hipcub::DeviceRadixSort::SortPairs(nullptr, ip_bytes, pair_item.p, item_sorted.p, q_iota.p, item_pairs.p,
-                                             n_pairs, 0, item_bits, s), "item sort (size)");
+    check(rocprim::radix_sort_pairs(nullptr, ip_bytes, pair_item.p, item_sorted.p, q_iota.p, item_pairs.p,
+                                    static_cast<size_t>(n_pairs), 0u, static_cast<unsigned>(item_bits), s), "item sort (size)");
     {
       Buf<char> tmp2(ip_bytes);
-      check(hipcub::DeviceRadixSort::SortPairs(tmp2.p, ip_bytes, pair_item.p, item_sorted.p, q_iota.p, item_pairs.p,
-                                               n_pairs, 0, item_bits, s), "item sort");
+      check(rocprim::radix_sort_pairs(tmp2.p, ip_bytes, pair_item.p, item_sorted.p, q_iota.p, item_pairs.p,
+                                      static_cast<size_t>(n_pairs), 0u, static_cast<unsigned>(item_bits), s), "item sort");
       lower_bounds<<<blocks_for(n_items + 1), kThreads, 0, s>>>(item_sorted.p, n_pairs, n_items, item_off.p);
       item_degrees<<<blocks_for(n_items), kThreads, 0, s>>>(item_off.p, item_pairs.p, pair_off.p, n_items, item_deg.p);
       to_host(L.pair_off, pair_off.p, static_cast<size_t>(n_pairs) + 1, s);
@@ -228,11 +228,11 @@ inline void sort_stage(hipStream_t s, int64_t n_obs, int32_t n_users, int32_t n_
     // ---- user order: stable sort of the pair-ordered triples by user ----------------------------
     Buf<int32_t> user_sorted(n), user_off(static_cast<size_t>(n_users) + 1);
     size_t up_bytes = 0;
-    check(hipcub::DeviceRadixSort::SortPairs(nullptr, up_bytes, pair_user.p, user_sorted.p, triple_pair.p, user_pair.p,
-                                             n, 0, user_bits, s), "user sort (size)");
+    check(rocprim::radix_sort_pairs(nullptr, up_bytes, pair_user.p, user_sorted.p, triple_pair.p, user_pair.p,
+                                    static_cast<size_t>(n), 0u, static_cast<unsigned>(user_bits), s), "user sort (size)");
     Buf<char> tmp3(up_bytes);
-    check(hipcub::DeviceRadixSort::SortPairs(tmp3.p, up_bytes, pair_user.p, user_sorted.p, triple_pair.p, user_pair.p,
-                                             n, 0, user_bits, s), "user sort");
+    check(rocprim::radix_sort_pairs(tmp3.p, up_bytes, pair_user.p, user_sorted.p, triple_pair.p, user_pair.p,
+                                    static_cast<size_t>(n), 0u, static_cast<unsigned>(user_bits), s), "user sort");
     lower_bounds<<<blocks_for(n_users + 1), kThreads, 0, s>>>(user_sorted.p, n, n_users, user_off.p);
     to_host(L.user_off, user_off.p, static_cast<size_t>(n_users) + 1, s);
     if (want_host_idx) {
