@@ -154,11 +154,11 @@ struct DeviceArrays {  // the two N-sized arrays stay on the device (ownership p
 
 // d_user / d_item / d_rating: the validated id columns on the device (n_obs each).  Fills every
 // host-side member of `L` that layout.hpp's sort stage fills EXCEPT pair_user and user_pair, which
-// are returned as device arrays (`want_host_idx`: also copy them to the host, for the XCD-local
-// work lists of dense data).  finish_layout() must follow.
+// stay on the device (range_cuts() below serves the one host-side consumer they have).
+// finish_layout() must follow.
 inline void sort_stage(hipStream_t s, int64_t n_obs, int32_t n_users, int32_t n_items, int32_t n_ratings,
                        const int32_t *d_user, const int32_t *d_item, const int32_t *d_rating,
-                       bool want_host_idx, Layout &L, DeviceArrays &dev) {
+                       Layout &L, DeviceArrays &dev) {
   L = Layout();
   L.n_obs = n_obs; L.n_users = n_users; L.n_items = n_items; L.n_ratings = n_ratings;
   const int64_t n = n_obs;
@@ -235,10 +235,6 @@ inline void sort_stage(hipStream_t s, int64_t n_obs, int32_t n_users, int32_t n_
                                     static_cast<size_t>(n), 0u, static_cast<unsigned>(user_bits), s), "user sort");
     lower_bounds<<<blocks_for(n_users + 1), kThreads, 0, s>>>(user_sorted.p, n, n_users, user_off.p);
     to_host(L.user_off, user_off.p, static_cast<size_t>(n_users) + 1, s);
-    if (want_host_idx) {
-      to_host(L.pair_user, pair_user.p, n, s);
-      to_host(L.user_pair, user_pair.p, n, s);
-    }
     check(hipStreamSynchronize(s), "sync");
   }
   check(hipGetLastError(), "layout kernels");

@@ -2439,6 +2439,8 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
     HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     bool gpu_layout = n_obs >= kGpuLayoutMin;
     if (const char *g = std::getenv("MMSBM_HIP_GPU_LAYOUT")) gpu_layout = std::atoi(g) != 0;
+    // (the device sort packs (rating, item) into 31 bits; sparser key spaces stay on the host)
+    if (static_cast<uint64_t>(n_ratings) * static_cast<uint64_t>(c->n_items) >= (uint64_t(1) << 31)) gpu_layout = false;
     mmsbm::gpu_layout::DeviceArrays dev_idx;
     if (gpu_layout) {
       mmsbm::validate_triples(n_obs, c->n_users, c->n_items, n_ratings, iu, ii, rating);
@@ -2458,7 +2460,7 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
     if (gpu_layout) {
       try {
         mmsbm::gpu_layout::sort_stage(c->stream, n_obs, c->n_users, c->n_items, n_ratings, c->orig_u.ptr,
-                                      c->orig_i.ptr, c->orig_r.ptr, false, c->lay, dev_idx);
+                                      c->orig_i.ptr, c->orig_r.ptr, c->lay, dev_idx);
       } catch (const std::invalid_argument &) {
         throw;
       } catch (const std::exception &e) {
