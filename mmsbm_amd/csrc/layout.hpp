@@ -297,11 +297,19 @@ constexpr int32_t kMvChunkPairs = 64;  // default: one 64-pair unit per workgrou
 // (Re)build the pair_block work list with `pairs` pairs per workgroup (a multiple of 64).  More
 // pairs per workgroup = fewer K x L slabs, which matters once a slab is large (big K*L).
 inline void build_mv_chunks(Layout &L, int32_t pairs) {
+  // Every rating's chunk count is padded to a multiple of 8 with EMPTY chunks (q_begin == q_end): chunk
+  // j of every rating then lands on the same XCD (workgroups are dealt to the 8 XCDs round-robin), and
+  // the rows of an item, which its R (item, rating) pairs all gather, are served to R - 1 of them by
+  // that XCD's L2.  (Speed only: an empty chunk's workgroup writes a zero slab and nothing else.)
+  const bool align = std::getenv("MMSBM_HIP_NO_CHUNK_ALIGN") == nullptr;
   L.mv_chunks.clear();
   L.mv_chunk_off.assign(size_t(L.n_ratings) + 1, 0);
   for (int r = 0; r < L.n_ratings; ++r) {
-    for (int32_t q = L.rating_off[r]; q < L.rating_off[r + 1]; q += pairs)
-      L.mv_chunks.push_back(Chunk{r, q, std::min<int32_t>(q + pairs, L.rating_off[r + 1]), 0});
+    const int32_t end = L.rating_off[r + 1];
+    for (int32_t q = L.rating_off[r]; q < end; q += pairs)
+      L.mv_chunks.push_back(Chunk{r, q, std::min<int32_t>(q + pairs, end), 0});
+    if (align && L.n_ratings > 1 && end > L.rating_off[r])
+      while ((L.mv_chunks.size() - size_t(L.mv_chunk_off[r])) % size_t(kXcds)) L.mv_chunks.push_back(Chunk{r, end, end, 0});
     L.mv_chunk_off[r + 1] = int32_t(L.mv_chunks.size());
   }
 }
