@@ -1,0 +1,85 @@
+"""bench.py's host logic without a GPU: the roofline object (SURVEY 8(d) basis, staleness of the
+committed counter summary), the self-launch command and the argument defaults the driver relies on."""
+import json
+import os
+import sys
+import types
+
+import pytest
+
+from conftest import ROOT
+
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (light: torch and the library are imported inside main())
+
+
+class FakeCtx:
+    bytes_per_slot = 107_000_000
+    n_pairs, n_users, n_items = 99_993, 99_997, 20_000
+
+
+PROF = {"seg_pass_kernel": (64.0, 1, 360_798_360, 32_000_000), "pair_block_kernel(T+S)": (18.0, 1, 37_400_000, 21_000_000),
+        "eta_p_kernel": (9.0, 1, 27_600_000, 3_300_000), "pair_block_kernel(A)": (12.0, 1, 21_400_000, 16_000_000)}
+
+
+def _args(config="c3"):
+    return types.SimpleNamespace(config=config)
+
+
+def test_roofline_object_follows_survey_8d_and_reads_the_committed_profile():
+    n, k, l = 1_000_000, 20, 20
+    rf = bench.roofline_object(_args(), FakeCtx(), PROF, n, k, l)
+    assert rf["bound"] == "hbm" and rf["kernel"] == "seg_pass_kernel" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert rf["algorithmic_bytes_per_launch"] == n * (12 + 8 * k + 8 * l) == 332_000_000
+    assert rf["achieved"] == pytest.approx(332_000_000 / 64e-6 / 1e9)
+    assert rf["frac"] == pytest.approx(rf["achieved"] / 8000.0)
+    assert rf["algorithmic_bytes_model"] == 360_798_360 and rf["achieved_model"] > rf["achieved"]
+    assert "Infinity Cache" in rf["served_from"] and rf["resident_set_bytes"] < 256 << 20
+    # the committed summary belongs to the committed kernel sources: traffic and the rocprof duration are there
+    with open(os.path.join(ROOT, "profiles", "pmc_summary.json")) as fh:
+        pmc = json.load(fh)
+    assert pmc["_meta"]["c3"]["kernel_source_sha16"] == bench.kernel_source_sha16(), \
+        "profiles/pmc_summary.json is stale: rerun scripts/profile_round.sh + summarize_profile.py"
+    assert rf["traffic"] == pmc["c3"]["seg_pass_kernel"]["hbm_bytes_per_launch"] > rf["algorithmic_bytes_per_launch"]
+    assert rf["rocprof_avg_us"] == pmc["c3"]["seg_pass_kernel"]["avg_us"] and rf["rocprof_source"].endswith("_kernel_stats.csv")
+    for cfg in ("c2", "c5"):   # every bench config has its summary, with the LDS-pipe counters
+        ent = pmc[cfg]["pair_block_kernel(T+S)"]
+        assert ent["avg_us"] > 0 and "SQ_WAIT_INST_LDS" in ent and "SQ_LDS_BANK_CONFLICT" in ent
+
+
+def test_roofline_traffic_is_null_when_the_kernel_sources_changed(monkeypatch):
+    monkeypatch.setattr(bench, "kernel_source_sha16", lambda: "0" * 16)
+    rf = bench.roofline_object(_args(), FakeCtx(), PROF, 1_000_000, 20, 20)
+    assert rf["traffic"] is None and "stale" in rf["traffic_source"]
+    assert rf["rocprof_avg_us"] is not None and "older kernel sources" in rf["rocprof_source"]
+
+
+def test_roofline_says_hbm_when_the_resident_set_exceeds_the_infinity_cache():
+    class Big(FakeCtx):
+        bytes_per_slot = 2_700_000_000
+    rf = bench.roofline_object(_args("c5"), Big(), PROF, 10_000_000, 50, 50)
+    assert rf["served_from"].startswith("HBM")
+
+
+def test_self_launch_starts_torch_distributed_run_as_a_child(monkeypatch):
+    seen = {}
+
+    def fake_run(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return types.SimpleNamespace(returncode=7)
+
+    monkeypatch.setattr(bench.subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "20", "--warmup", "5"])
+    rc = bench.self_launch(types.SimpleNamespace(gpus=4))
+    assert rc == 7
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "20", "--warmup", "5"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_argument_defaults(monkeypatch):
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    a = bench.parse_args()
+    assert (a.gpus, a.config, a.no_cpu_baseline, a.batched_restarts) == (1, "c3", False, 0) and a.steps >= 100
