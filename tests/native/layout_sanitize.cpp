@@ -30,11 +30,25 @@ static void check(const std::vector<int32_t> &u, const std::vector<int32_t> &i, 
   }
   std::vector<int> cover(L.n_pairs, 0);
   for (const auto &c : L.mv_chunks) {
-    CHECK(c.q_begin < c.q_end && c.q_end - c.q_begin <= mmsbm::kMvChunkPairs);
+    CHECK(c.q_begin <= c.q_end && c.q_end - c.q_begin <= mmsbm::kMvChunkPairs);
     CHECK(L.rating_off[c.rating] <= c.q_begin && c.q_end <= L.rating_off[c.rating + 1]);
     for (int q = c.q_begin; q < c.q_end; ++q) cover[q]++;
   }
   for (int q = 0; q < L.n_pairs; ++q) CHECK(cover[q] == 1);
+  // empty chunks are padding only: at the tail of a rating's list, which they bring to a multiple of the XCD count
+  for (int rr = 0; rr < R && L.n_ratings > 1; ++rr) {
+    const int a = L.mv_chunk_off[rr], b = L.mv_chunk_off[rr + 1];
+    CHECK((b - a) % mmsbm::kXcds == 0);
+    CHECK((b == a) == (L.rating_off[rr] == L.rating_off[rr + 1]));
+    int pads = 0;
+    for (int k = a; k < b; ++k) {
+      const auto &c = L.mv_chunks[size_t(k)];
+      CHECK(c.rating == rr);
+      if (c.q_begin == c.q_end) { ++pads; CHECK(c.q_begin == L.rating_off[rr + 1]); }
+      else CHECK(pads == 0);
+    }
+    CHECK(pads < mmsbm::kXcds);
+  }
   for (const mmsbm::WorkList *w : {&L.pair_work, &L.user_work}) {
     const auto &off = (w == &L.pair_work) ? L.pair_off : L.user_off;
     std::vector<int> seen(static_cast<size_t>(n), 0);
