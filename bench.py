@@ -199,6 +199,8 @@ def roofline_object(args, ctx, prof, n, k, l):
 
 def main():
     args = parse_args()
+    from mmsbm_amd.build import ensure_library   # (no HIP, no torch: safe before the ranks are started)
+    ensure_library()                             # a fresh clone has no libmmsbm_hip.so yet
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
     # stdout carries exactly ONE line (rank 0's JSON): whatever libraries print while the job runs

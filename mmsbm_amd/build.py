@@ -34,13 +34,33 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     """hipcc --offload-arch=gfx950 -shared -> mmsbm_amd/libmmsbm_hip.so; returns its path."""
     if not force and not is_stale():
         return LIB
+    tmp = f"{LIB}.{os.getpid()}.tmp"   # renamed into place when complete: nobody ever loads half a library
     cmd = [hipcc_path(), "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-shared",
-           "-Wall", "-Wno-unused-function", *EXTRA_FLAGS, "-Wl,-rpath,/opt/rocm/lib", "-o", LIB, SRC]
+           "-Wall", "-Wno-unused-function", *EXTRA_FLAGS, "-Wl,-rpath,/opt/rocm/lib", "-o", tmp, SRC]
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
+        if os.path.exists(tmp):
+            os.remove(tmp)
         raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+    os.replace(tmp, LIB)
+    return LIB
+
+
+def ensure_library() -> str:
+    """Build the library if it is not there (a fresh clone: the .so is not tracked).  Safe to call from
+    several ranks at once: one builds under a file lock, the others wait and find it built."""
+    if os.path.exists(LIB):
+        return LIB
+    import fcntl
+    with open(LIB + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not os.path.exists(LIB):
+                build_library(force=True)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB
 
 

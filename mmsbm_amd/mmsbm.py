@@ -260,8 +260,7 @@ class MMSBM:
         matrix, raw = ctx.predict_finish()
         self.run_stats = [ctx.final_stats(st) for st in per_run]
         likelihoods = np.array([a["likelihood"] for a in self.results])
-        accuracies = [st["accuracy"] for st in self.run_stats]
-        best = accuracies.index(max(accuracies))  # src/mmsbm.py:474-478
+        best = int(np.argmax([st["accuracy"] for st in self.run_stats]))  # first best restart, src/mmsbm.py:474-478
         enc = self.data_handler
         res = self.results[best]
         self.theta = pd.DataFrame(res["theta"], index=enc.user_labels())
@@ -273,8 +272,8 @@ class MMSBM:
         return self.prediction_matrix
 
     def choose_best_run(self, rats):
-        accuracies = [self._compute_stats(a)["accuracy"] for a in rats]
-        return accuracies.index(max(accuracies))
+        """Index of the first prediction matrix with the highest accuracy (src/mmsbm.py:474-478)."""
+        return int(np.argmax([self._compute_stats(a)["accuracy"] for a in rats]))
 
     # ------------------------------------------------------------------ scoring (src/mmsbm.py:319-369,488-539)
     def score(self, silent=False):
@@ -291,29 +290,19 @@ class MMSBM:
         return {"stats": stats, "objects": {"theta": self.theta, "eta": self.eta, "pr": self.pr}}
 
     def _compute_stats(self, rat):
-        return self._compute_final_stats(self._compute_indicators(rat))
-
-    def _compute_indicators(self, rat):
-        pred = np.argmax(rat, axis=1)
-        real = self.test[:, 2]
-        mask = rat.sum(axis=1) != 0
-        if not np.all(mask):
-            pred, real, rat = pred[mask], real[mask], rat[mask]
-        pred_pond = rat @ self.ratings
-        return {"true": (pred == real).astype(int),
-                "almost": (np.abs(pred - real) <= 1).astype(int),
-                "s2": np.abs(pred - real),
-                "true_pond": (real == np.round(pred_pond)).astype(int),
-                "s2pond": np.abs(pred_pond - real)}
-
-    @staticmethod
-    def _compute_final_stats(rat):
-        n = len(rat["true"])
-        return {"accuracy": rat["true"].sum() / n,
-                "one_off_accuracy": rat["almost"].sum() / n,
-                "mae": 1 - rat["true_pond"].sum() / n,
-                "s2": rat["s2"].sum(),
-                "s2pond": rat["s2pond"].sum()}
+        """Scores of a prediction matrix the CALLER supplies (the model's own predictions are scored on
+        the device, predict_score_kernel): the same six sums the device returns -- rows with any mass,
+        exact hits, hits within one class, |error|, hits and |error| of the weighted prediction
+        (src/mmsbm.py:488-528) -- turned into the five scores by HipEM.final_stats."""
+        rat = np.asarray(rat, dtype=np.float64)
+        truth = np.asarray(self.test[:, 2])
+        keep = rat.sum(axis=1) != 0                       # rows without a prediction do not count
+        err = np.abs(np.argmax(rat, axis=1) - truth)[keep]
+        weighted = (rat @ self.ratings)[keep]
+        real = truth[keep]
+        raw = (int(keep.sum()), int((err == 0).sum()), int((err <= 1).sum()), int(err.sum()),
+               int((np.round(weighted) == real).sum()), float(np.abs(weighted - real).sum()))
+        return HipEM.final_stats(raw)
 
     def compute_likelihood(self, data, theta, eta, pr):
         """src/mmsbm.py:541-553: the likelihood of ``data`` (encoded triples -- the training set
@@ -391,11 +380,8 @@ class MMSBM:
             by_f = dict(x for part in parts for x in part)
             all_results = [by_f[f] for f in range(folds)]
         accuracies = [a["stats"]["accuracy"] for a in all_results]
-        best = accuracies.index(max(accuracies))
-        self.theta = all_results[best]["objects"]["theta"]
-        self.eta = all_results[best]["objects"]["eta"]
-        self.pr = all_results[best]["objects"]["pr"]
-        self.prediction_matrix = all_results[best]["objects"]["rat"]
+        kept = all_results[int(np.argmax(accuracies))]["objects"]   # the first best fold (src/mmsbm.py:460-465)
+        self.theta, self.eta, self.pr, self.prediction_matrix = (kept[k] for k in ("theta", "eta", "pr", "rat"))
         self.cv_results = all_results
         self.logger.info(f"Ran {folds} folds with accuracies {accuracies}.")
         return accuracies
