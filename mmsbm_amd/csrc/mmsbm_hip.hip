@@ -1438,6 +1438,9 @@ struct mmsbm_hip_ctx {
   size_t lds_t = 0, lds_a = 0;
   bool tl_t = false, tl_a = false;  // rating tile staged in LDS (T+S launch / A launch)
   bool quad_a = false;  // the A launch runs pair_quad_a_kernel (long rows)
+  bool mfma = false;    // both pair-stage launches run pair_mfma_kernel (tiles beyond the scalar cache, K, L <= 64)
+  size_t lds_mt = 0, lds_ma = 0;
+  int mfma_threads = kPairBlockMax;  // T+S launch: 512 (eight waves) or 256
   bool wide = false;    // K, L beyond the LDS stage: wide_matvec / wide_slab kernels (any size)
   bool slot_waves = true;  // several slots: one super-group of lanes walks a segment for all of them
   int ranges_pairs = 1, ranges_users = 1;  // XCD-local work lists: ranges the gathered table is cut into
@@ -1665,6 +1668,205 @@ __global__ __launch_bounds__(kPairBlockMax) void pair_quad_a_kernel(PairBlockArg
   }
 #undef PRJ
 #undef DJ
+}
+
+// ======================================================================================
+// pair_mfma -- the pair stage on the matrix cores, for rating tiles that no longer fit the scalar cache
+// (K x L > 1024 with K, L <= 64: BASELINE's K = L = 50).  There the lane-per-pair form is bound by the
+// LDS pipe (one broadcast ds_read_b128 of the tile per two FMAs; profiles/r2_c5: SQ_WAIT_INST_LDS),
+// while both products of a 64-pair unit are small dense GEMMs:
+//   T[64 x Dout]   = X[64 x Din] . tile[Din x Dout]     (X = C rows; the gathered eta rows in the A launch)
+//   S[Din x Dout] += X^T[Din x 64] . E[64 x Dout]       (E = gathered eta rows; T+S launch only)
+// v_mfma_f64_16x16x4_f64 takes ONE double per lane and operand (A[i = lane & 15][k = lane >> 4],
+// B[k = lane >> 4][j = lane & 15]; D[row = (lane >> 4) + 4 reg][col = lane & 15]): 2,048 flops per KB
+// read from LDS, 16 x less LDS traffic per flop than the lane-per-pair form.  (The f64 matrix rate
+// equals the f64 vector rate on this chip: the gain is operand delivery, not a higher peak.)
+// Staging as in pair_block (cst = X transposed with an odd stride, which serves both products without
+// bank conflicts; es = eta rows; the tile once per workgroup).  Four waves:
+//   T: wave w owns rows 16w .. 16w+15 of the unit and all (<= 4) column tiles; the results go to
+//      memory from the accumulators (16 lanes = 128 contiguous bytes of a row);
+//   S: the (<= 16) 16 x 16 tiles of the slab are dealt to the waves, <= 4 each, and stay in the
+//      accumulators across the workgroup's units; one slab per workgroup at the end, as before.
+// Rows / columns beyond Din / Dout inside a 16-tile are computed on clamped (duplicate) operands and
+// never stored.  Association order per output: k (resp. pair) ascending, fused in groups of four.
+// ======================================================================================
+typedef double mfma_d4 __attribute__((ext_vector_type(4)));
+#ifndef MMSBM_MFMA_WPE
+#define MMSBM_MFMA_WPE 4  // waves per SIMD the eight-wave form is compiled for (4: two workgroups per CU)
+#endif
+constexpr int kMfmaMaxDim = 64;       // <= 4 tiles of 16 per side
+constexpr int kMfmaChunkPairs = 256;  // pairs per workgroup at most (their item ids are parked in LDS)
+static_assert(kMfmaChunkPairs >= 4 * mmsbm::kMvChunkPairs, "pair_mfma_kernel parks a whole chunk's item ids in LDS");
+
+// NT threads: 256 (four waves as described) or 512 -- eight waves, each with half of the column tiles of its
+// T rows and <= 2 slab tiles, so that the accumulators and the prefetched rows of the T+S launch fit
+// 128 registers and two workgroups (16 waves) share a CU.
+template <bool GATHER, bool DO_S, int NT>
+__global__ __launch_bounds__(NT, NT == 512 ? MMSBM_MFMA_WPE : 2) void pair_mfma_kernel(PairBlockArgs pa,
+                                                           const double *__restrict__ tiles0) {
+  constexpr int NW = NT / 64;                              // waves
+  constexpr int NLD = kUnitPairs * kMfmaMaxDim / 2 / NT;   // double2 per thread, unit and table
+  constexpr int TC = 16 / NW;                              // column tiles per wave in T (4 or 2)
+  constexpr int SA = 16 / NW;                              // slab tiles per wave at most (4 or 2)
+  const size_t slot = blockIdx.y;
+  const double *__restrict__ tiles = tiles0 + slot * pa.bs_tiles;
+  const double *__restrict__ in_tab = pa.in_tab + slot * pa.bs_in;
+  const double *__restrict__ e_tab = pa.e_tab + slot * pa.bs_e;
+  const int32_t *__restrict__ pair_item = pa.pair_item;
+  double *__restrict__ out = pa.out + slot * pa.bs_out;
+  double *__restrict__ out_tail = pa.out_tail + slot * pa.bs_out_t;
+  double *__restrict__ partial = pa.partial + slot * pa.bs_partial;
+  const int dinp = pa.dinp, doutp = pa.doutp;
+  extern __shared__ double lds[];
+  constexpr int CS = kUnitPairs + 1;
+  double *cst = lds;                                            // [dinp][CS]   X transposed
+  double *tile_l = cst + static_cast<size_t>(dinp) * CS;        // [dinp][doutp]
+  double *es = tile_l + static_cast<size_t>(dinp) * doutp;      // [64][doutp]  (DO_S)
+  int *ids_l = reinterpret_cast<int *>(es + (DO_S ? static_cast<size_t>(kUnitPairs) * doutp : 0));  // [256]
+  const mmsbm::Chunk ch = pa.chunks[blockIdx.x];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lk = lane >> 4;
+  const int nto = (doutp + 15) >> 4, mti = (dinp + 15) >> 4;
+  {
+    const double *src = tiles + static_cast<size_t>(ch.rating) * dinp * doutp;
+    for (int t = tid * 2; t < dinp * doutp; t += NT * 2)
+      *reinterpret_cast<double2 *>(tile_l + t) = *reinterpret_cast<const double2 *>(src + t);
+    if (GATHER || DO_S)
+      for (int t = tid; t < ch.q_end - ch.q_begin; t += NT) ids_l[t] = pair_item[ch.q_begin + t];
+  }
+  // this thread's share of a unit: elements t = 2 tid + j * 2 NT of the flat (pair, entry) space of X and of E.
+  // (pair = t / dinp through a multiply-high with ceil(2^32 / dinp), exact for t < 2^32 / dinp: recomputed at
+  // every use, a table of them per thread cost the registers that decide whether two workgroups share a CU)
+  const unsigned mx = 0xFFFFFFFFu / static_cast<unsigned>(dinp) + 1u, me = 0xFFFFFFFFu / static_cast<unsigned>(doutp) + 1u;
+#define MFMA_PX(j) static_cast<int>(__umulhi(static_cast<unsigned>(tid * 2 + (j) * NT * 2), mx))
+#define MFMA_PE(j) static_cast<int>(__umulhi(static_cast<unsigned>(tid * 2 + (j) * NT * 2), me))
+  const int trow0 = 16 * (wave & 3), tn0 = TC * (wave >> 2);  // T: this wave's rows and first column tile
+  int bcol[TC];  // this lane's column of each of its output tiles
+#pragma unroll
+  for (int n = 0; n < TC; ++n) bcol[n] = min(16 * (tn0 + n) + li, doutp - 1);
+  // S: tile t = wave + NW a of the mti x nto grid
+  mfma_d4 acc_s[SA];
+  int s_a[SA], s_b[SA];
+  bool s_on[SA];
+#pragma unroll
+  for (int a = 0; a < SA; ++a) {
+    const int t = wave + NW * a;
+    s_on[a] = DO_S && t < mti * nto;
+    const int m = s_on[a] ? t / nto : 0, n = s_on[a] ? t - m * nto : 0;
+    s_a[a] = min(16 * m + li, dinp - 1) * CS + lk;         // + 4 s           : X[pair 4s + lk][k]
+    s_b[a] = lk * doutp + min(16 * n + li, doutp - 1);     // + 4 s * doutp   : E[pair 4s + lk][l]
+    acc_s[a] = mfma_d4{0.0, 0.0, 0.0, 0.0};
+  }
+  __syncthreads();  // ids (and the tile) are in LDS
+
+  // rows of the unit at q0 into registers: every load of the unit is in flight at once
+  double2 vx[NLD];
+  double vex[NLD], vey[NLD];  // (as scalars: a double2 array stored with ds_write_b128 stayed in scratch memory)
+  // (a macro, not a lambda: arrays captured by reference ended up in scratch memory, and every scratch
+  // access waits for ALL outstanding loads)
+#define MFMA_FETCH(Q0)                                                                                  \
+  do {                                                                                                  \
+    const int fq = (Q0), fnp = min(kUnitPairs, ch.q_end - fq), fbase = fq - ch.q_begin;                  \
+    _Pragma("unroll") for (int j = 0; j < NLD; ++j) {                                                   \
+      /* unconditional: shares beyond the unit's pairs re-read its last row and are dropped */          \
+      const int fp0 = MFMA_PX(j), fpr = min(fp0, fnp - 1);                                              \
+      const size_t frow = GATHER ? static_cast<size_t>(ids_l[fbase + fpr]) : static_cast<size_t>(fq + fpr); \
+      vx[j] = *reinterpret_cast<const double2 *>(in_tab + frow * dinp + (tid * 2 + j * NT * 2 - fp0 * dinp)); \
+      if (DO_S) {                                                                                       \
+        const int fe0 = MFMA_PE(j);                                                                     \
+        const size_t ferow = static_cast<size_t>(ids_l[fbase + min(fe0, fnp - 1)]);                     \
+        const double2 fe = *reinterpret_cast<const double2 *>(e_tab + ferow * doutp + (tid * 2 + j * NT * 2 - fe0 * doutp)); \
+        vex[j] = fe.x;                                                                                  \
+        vey[j] = fe.y;                                                                                  \
+      }                                                                                                 \
+    }                                                                                                   \
+  } while (0)
+  MFMA_FETCH(ch.q_begin);
+
+  for (int q0 = ch.q_begin; q0 < ch.q_end; q0 += kUnitPairs) {
+    const int np = min(kUnitPairs, ch.q_end - q0);
+    if (q0 != ch.q_begin) __syncthreads();  // previous unit fully consumed
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+      const int pr = MFMA_PX(j);
+      if (pr < np) {
+        double *dst = cst + (tid * 2 + j * NT * 2 - pr * dinp) * CS + pr;
+        dst[0] = vx[j].x;
+        dst[CS] = vx[j].y;
+      }
+      if (DO_S && MFMA_PE(j) < np) {
+        double2 e2;
+        e2.x = vex[j]; e2.y = vey[j];
+        *reinterpret_cast<double2 *>(es + (tid * 2 + j * NT * 2)) = e2;
+      }
+    }
+    if (np < kUnitPairs) {  // ragged tail of a rating: the missing pairs are zero columns of X, zero rows of E
+      for (int t = tid; t < (kUnitPairs - np) * dinp; t += NT)
+        cst[(t / (kUnitPairs - np)) * CS + np + t % (kUnitPairs - np)] = 0.0;
+      if (DO_S)
+        for (int t = np * doutp + tid; t < kUnitPairs * doutp; t += NT) es[t] = 0.0;
+    }
+    __syncthreads();
+    if (q0 + kUnitPairs < ch.q_end) MFMA_FETCH(q0 + kUnitPairs);  // the next unit's rows travel during the products
+    if (DO_S) {  // S += X^T E : the 64 pairs are the summed index, four per instruction
+#pragma unroll 4
+      for (int s = 0; s < kUnitPairs / 4; ++s) {
+#pragma unroll
+        for (int a = 0; a < SA; ++a)  // (unconditional: a tile beyond the grid repeats tile 0 and is never stored)
+          acc_s[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(cst[s_a[a] + 4 * s], es[s_b[a] + 4 * s * doutp],
+                                                          acc_s[a], 0, 0, 0);
+      }
+    }
+    // T = X tile : this wave's 16 rows, its column tiles
+    mfma_d4 acc_t[TC];
+#pragma unroll
+    for (int n = 0; n < TC; ++n) acc_t[n] = mfma_d4{0.0, 0.0, 0.0, 0.0};
+    if (tn0 < nto) {
+#pragma unroll 2
+      for (int s = 0; s < dinp / 4; ++s) {
+        const double x = cst[(4 * s + lk) * CS + trow0 + li];
+        const double *trow = tile_l + (4 * s + lk) * doutp;
+#pragma unroll
+        for (int n = 0; n < TC; ++n)  // (a column tile beyond Dout repeats the last column and is never stored)
+          acc_t[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(x, trow[bcol[n]], acc_t[n], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int n = 0; n < TC; ++n) {
+      const int col = 16 * (tn0 + n) + li;
+      if (tn0 + n < nto && col < doutp) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int r = trow0 + lk + 4 * g;
+          if (r < np) *pair_out_ptr(pa, out, out_tail, static_cast<size_t>(q0 + r), col) = acc_t[n][g];
+        }
+      }
+    }
+  }
+  if (DO_S) {
+    double *dst = partial + static_cast<size_t>(blockIdx.x) * dinp * doutp;
+#pragma unroll
+    for (int a = 0; a < SA; ++a) {
+      if (!s_on[a]) continue;
+      const int t = wave + NW * a, m = t / nto, n = t - m * nto;
+      const int col = 16 * n + li;
+      if (col < doutp) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int k = 16 * m + lk + 4 * g;
+          if (k < dinp) dst[static_cast<size_t>(k) * doutp + col] = acc_s[a][g];
+        }
+      }
+    }
+  }
+}
+#undef MFMA_FETCH
+#undef MFMA_PX
+#undef MFMA_PE
+size_t pair_mfma_lds(int dinp, int doutp, bool with_s) {
+  return (static_cast<size_t>(dinp) * (kUnitPairs + 1) + static_cast<size_t>(dinp) * doutp +
+          (with_s ? static_cast<size_t>(kUnitPairs) * doutp : 0)) * sizeof(double) + kMfmaChunkPairs * sizeof(int);
 }
 
 // ======================================================================================
@@ -1962,6 +2164,10 @@ void stage_seg(mmsbm_hip_ctx *c, bool commit, bool with_pairs, bool with_users, 
   ls.done();
 }
 
+bool mfma_possible(const mmsbm_hip_ctx *c) {
+  return !c->wide && c->kp <= kMfmaMaxDim && c->lp <= kMfmaMaxDim && c->lds_mt <= kLdsMax && c->lds_ma <= kLdsMax;
+}
+
 void stage_dense(mmsbm_hip_ctx *c) {  // T = P^T C  and the K x L slabs for p
   if (c->n_chunks == 0) return;
   if (c->wide) {
@@ -1974,6 +2180,20 @@ void stage_dense(mmsbm_hip_ctx *c) {  // T = P^T C  and the K x L slabs for p
     allow_big_lds(wide_matvec_kernel<false>, lds);
     wide_matvec_kernel<false><<<slot_grid(c, nb * subs), kBlock, lds, c->stream>>>(pa, subs);
     wide_slab_kernel<<<slot_grid(c, nb * kgs * lbs), kBlock, 0, c->stream>>>(pa, kgs, lbs);
+    ls.done();
+    return;
+  }
+  if (c->mfma) {
+    LaunchScope ls(c, K_DENSE);
+    const int nb = static_cast<int>(c->lay.mv_chunks.size());
+    const PairBlockArgs pa = pair_block_t_args(c);
+    if (c->mfma_threads == kBlock) {
+      allow_big_lds(pair_mfma_kernel<false, true, kBlock>, c->lds_mt);
+      pair_mfma_kernel<false, true, kBlock><<<slot_grid(c, nb), kBlock, c->lds_mt, c->stream>>>(pa, pa.tiles);
+    } else {
+      allow_big_lds(pair_mfma_kernel<false, true, kPairBlockMax>, c->lds_mt);
+      pair_mfma_kernel<false, true, kPairBlockMax><<<slot_grid(c, nb), kPairBlockMax, c->lds_mt, c->stream>>>(pa, pa.tiles);
+    }
     ls.done();
     return;
   }
@@ -2037,6 +2257,11 @@ void stage_matvec_a(mmsbm_hip_ctx *c, int slot, int a_slot) {
     const size_t lds = static_cast<size_t>(kWidePairs) * c->lp * sizeof(double);
     allow_big_lds(wide_matvec_kernel<true>, lds);
     wide_matvec_kernel<true><<<slot_grid(c, nb * subs), kBlock, lds, c->stream>>>(pa, subs);
+  } else if (c->mfma) {
+    const int nb = static_cast<int>(c->lay.mv_chunks.size());
+    const PairBlockArgs pa = pair_block_a_args(c, slot, a_slot);
+    allow_big_lds(pair_mfma_kernel<true, false, kBlock>, c->lds_ma);
+    pair_mfma_kernel<true, false, kBlock><<<slot_grid(c, nb), kBlock, c->lds_ma, c->stream>>>(pa, pa.tiles);
   } else if (c->quad_a) {
     const int nb = static_cast<int>(c->lay.mv_chunks.size());
     const PairBlockArgs pa = pair_block_a_args(c, slot, a_slot);
@@ -2489,6 +2714,10 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
                 sizeof(double);
     c->quad_a = !c->wide && c->kp * c->lp > 1024 && c->tl_a && c->pb_threads_a == kPairBlockMax &&
                 c->lds_qa <= kLdsMax - 2048 && c->lp <= 64;
+    // ... and both launches on the matrix cores where the tile has left the scalar cache (pair_mfma_kernel)
+    c->lds_mt = pair_mfma_lds(c->kp, c->lp, true);
+    c->lds_ma = pair_mfma_lds(c->lp, c->kp, false);
+    c->mfma = mfma_possible(c.get()) && c->kp * c->lp > 1024 && std::getenv("MMSBM_HIP_NO_MFMA") == nullptr;
     c->n_pairs = c->lay.n_pairs;
     c->n_chunks = static_cast<int>(c->lay.mv_chunks.size());
     // dense data: XCD-local work lists (layout.hpp) -- every segment cut at fixed borders of the
@@ -3183,6 +3412,11 @@ int mmsbm_hip_set_option(mmsbm_hip_ctx *ctx, const char *name, double value) {
     } else if (key == "quad") {  // 0: the A launch through pair_block like every other shape
       ctx->quad_a = value != 0.0 && !ctx->wide && ctx->kp * ctx->lp > 1024 && ctx->tl_a &&
                     ctx->pb_threads_a == kPairBlockMax && ctx->lds_qa <= kLdsMax - 2048 && ctx->lp <= 64;
+    } else if (key == "mfma_threads") {
+      if (value != kBlock && value != kPairBlockMax) throw std::invalid_argument("mfma_threads: 256 or 512");
+      ctx->mfma_threads = static_cast<int>(value);
+    } else if (key == "mfma") {  // the pair stage on the matrix cores (any K, L <= 64; chosen by create() for big tiles)
+      ctx->mfma = value != 0.0 && mfma_possible(ctx);
     } else {
       throw std::invalid_argument("unknown option: " + key);
     }
@@ -3197,6 +3431,8 @@ int mmsbm_hip_get_option(const mmsbm_hip_ctx *ctx, const char *name, double *val
     if (key == "graph") *value = ctx->graph_mode;
     else if (key == "direct") *value = ctx->direct_out;
     else if (key == "quad") *value = ctx->quad_a;
+    else if (key == "mfma") *value = ctx->mfma;
+    else if (key == "mfma_threads") *value = ctx->mfma_threads;
     else if (key == "wide") *value = ctx->wide;
     else if (key == "slot_waves") *value = ctx->slot_waves;
     else if (key == "lik_fast") *value = ctx->lik_fast;

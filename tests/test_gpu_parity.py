@@ -926,6 +926,50 @@ def test_wide_row_kernels_agree_with_the_lds_stage(hip, monkeypatch):
         assert rel_err(got, w) < 1e-11
 
 
+@pytest.mark.parametrize("k,l,forced", [(50, 50, False), (40, 60, False), (33, 64, False), (64, 17, False), (36, 36, False),
+                                        (20, 20, True), (7, 64, True), (3, 5, True), (16, 16, True), (48, 20, True)])
+def test_pair_stage_on_the_matrix_cores(hip, k, l, forced):
+    """pair_mfma_kernel (v_mfma_f64_16x16x4_f64): chosen by the library for K x L > 1024 with K, L <= 64
+    (BASELINE's K = L = 50), forced here on smaller tiles too.  Ragged rating chunks (units of 1..64
+    pairs, chunks of several units), restart slots, either side paired with the rating; numerators
+    after one step and parameters / likelihood after three iterations against the oracle, and against
+    the lane-per-pair kernels (same sums, associated differently)."""
+    rng = np.random.default_rng(100 * k + l)
+    n_u, n_i, n_r = 300, 170, 4
+    n = 5000
+    r_col = np.minimum(rng.geometric(0.45, n) - 1, n_r - 1)          # unequal rating counts: ragged chunk tails
+    data = np.stack([rng.integers(0, n_u, n), rng.integers(0, n_i, n), r_col], axis=1).astype(np.int64)
+    d_u, d_i = orc.degrees(data, n_u, n_i)
+    theta, eta, pr = orc.init_params(11, n_u, n_i, n_r, k, l, d_u, d_i)
+    theta2, eta2, pr2 = orc.init_params(12, n_u, n_i, n_r, k, l, d_u, d_i)
+    want = orc.update_coefficients(data, theta, eta, pr)
+    t, e, p = theta, eta, pr
+    for _ in range(3):
+        t, e, p = orc.em_step(data, t, e, p, d_u, d_i)
+    for swap in (0, 1):
+        outs = {}
+        for on in (1, 0):
+            with hip.HipEM(data, k, l, n_u, n_i, n_r, slots=2, swap_sides=swap) as em:
+                if not forced:
+                    assert em.get_option("mfma") == 1.0               # the library's own choice
+                em.set_option("mfma", on)
+                assert em.get_option("mfma") == float(on)
+                em.select(1).set_params(theta2, eta2, pr2)
+                em.select(0).set_params(theta, eta, pr)
+                if on:
+                    for got, w, nm in zip(em.update_coefficients(), want, ("n_theta", "n_eta", "n_pr")):
+                        assert rel_err(got, w) < TOL_STEP, (swap, nm)
+                em.iterate(3)
+                outs[on] = [em.select(s).get_params() for s in range(2)]
+                if on:
+                    assert em.select(0).likelihood() == pytest.approx(float(orc.compute_likelihood(data, t, e, p)), rel=1e-11)
+        for got, w, nm in zip(outs[1][0], (t, e, p), ("theta", "eta", "pr")):
+            assert rel_err(got, w) < 1e-11, (swap, nm)
+        for s_ in range(2):
+            for a, b, nm in zip(outs[1][s_], outs[0][s_], ("theta", "eta", "pr")):
+                assert rel_err(a, b) < 1e-12, (swap, s_, nm)
+
+
 @pytest.mark.parametrize("n_r,k,l", [(1, 3, 4), (33, 5, 6), (100, 4, 3), (7, 20, 20)])
 def test_many_or_single_rating_values(hip, n_r, k, l):
     """R = 1 (p stays 1 everywhere) up to R = 100 (many tiny rating-homogeneous units, several
