@@ -1695,7 +1695,7 @@ typedef double mfma_d4 __attribute__((ext_vector_type(4)));
 #define MMSBM_MFMA_WPE 4  // waves per SIMD the eight-wave form is compiled for (4: two workgroups per CU)
 #endif
 constexpr int kMfmaMaxDim = 64;       // <= 4 tiles of 16 per side
-constexpr int kMfmaChunkPairs = 256;  // pairs per workgroup at most (their item ids are parked in LDS)
+constexpr int kMfmaChunkPairs = 1024;  // pairs per workgroup at most (their item ids are parked in LDS)
 static_assert(kMfmaChunkPairs >= 4 * mmsbm::kMvChunkPairs, "pair_mfma_kernel parks a whole chunk's item ids in LDS");
 
 // NT threads: 256 (four waves as described) or 512 -- eight waves, each with half of the column tiles of its
@@ -1723,6 +1723,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? MMSBM_MFMA_WPE : 2) void pair_mfma_
   double *tile_l = cst + static_cast<size_t>(dinp) * CS;        // [dinp][doutp]
   double *es = tile_l + static_cast<size_t>(dinp) * doutp;      // [64][doutp]  (DO_S)
   int *ids_l = reinterpret_cast<int *>(es + (DO_S ? static_cast<size_t>(kUnitPairs) * doutp : 0));  // [256]
+  STAMP(0);
   const mmsbm::Chunk ch = pa.chunks[blockIdx.x];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1786,6 +1787,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? MMSBM_MFMA_WPE : 2) void pair_mfma_
 
   for (int q0 = ch.q_begin; q0 < ch.q_end; q0 += kUnitPairs) {
     const int np = min(kUnitPairs, ch.q_end - q0);
+    STAMP(1);
     if (q0 != ch.q_begin) __syncthreads();  // previous unit fully consumed
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
@@ -1807,8 +1809,11 @@ __global__ __launch_bounds__(NT, NT == 512 ? MMSBM_MFMA_WPE : 2) void pair_mfma_
       if (DO_S)
         for (int t = np * doutp + tid; t < kUnitPairs * doutp; t += NT) es[t] = 0.0;
     }
+    STAMP(2);
     __syncthreads();
+    STAMP(3);
     if (q0 + kUnitPairs < ch.q_end) MFMA_FETCH(q0 + kUnitPairs);  // the next unit's rows travel during the products
+    STAMP(4);
     if (DO_S) {  // S += X^T E : the 64 pairs are the summed index, four per instruction
 #pragma unroll 4
       for (int s = 0; s < kUnitPairs / 4; ++s) {
@@ -1818,6 +1823,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? MMSBM_MFMA_WPE : 2) void pair_mfma_
                                                           acc_s[a], 0, 0, 0);
       }
     }
+    STAMP(5);
     // T = X tile : this wave's 16 rows, its column tiles
     mfma_d4 acc_t[TC];
 #pragma unroll
@@ -1832,6 +1838,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? MMSBM_MFMA_WPE : 2) void pair_mfma_
           acc_t[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(x, trow[bcol[n]], acc_t[n], 0, 0, 0);
       }
     }
+    STAMP(6);
 #pragma unroll
     for (int n = 0; n < TC; ++n) {
       const int col = 16 * (tn0 + n) + li;
@@ -1844,6 +1851,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? MMSBM_MFMA_WPE : 2) void pair_mfma_
       }
     }
   }
+  STAMP(7);
   if (DO_S) {
     double *dst = partial + static_cast<size_t>(blockIdx.x) * dinp * doutp;
 #pragma unroll
@@ -1860,6 +1868,11 @@ __global__ __launch_bounds__(NT, NT == 512 ? MMSBM_MFMA_WPE : 2) void pair_mfma_
       }
     }
   }
+#ifdef MMSBM_STAMPS
+  __syncthreads();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  STAMP(8);
+#endif
 }
 #undef MFMA_FETCH
 #undef MFMA_PX
@@ -2702,8 +2715,17 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
     // big K x L tiles: four 64-pair units per pair_block workgroup (4x fewer slabs to write + add)
     const std::vector<mmsbm::Chunk> units64 = c->lay.mv_chunks;  // likelihood_units_kernel: <= 64 pairs
     c->n_lik_units = static_cast<int>(units64.size());
+    // ... and both launches on the matrix cores where the tile has left the scalar cache (pair_mfma_kernel),
+    // with eight units per workgroup while that still leaves every CU a few rounds of workgroups (C5: T+S
+    // 358 -> 342 us, half the slabs for eta_p: 123 -> 111 us; 768 or 1,024 pairs per workgroup are slower)
+    c->lds_mt = pair_mfma_lds(c->kp, c->lp, true);
+    c->lds_ma = pair_mfma_lds(c->lp, c->kp, false);
+    c->mfma = mfma_possible(c.get()) && c->kp * c->lp > 1024 && std::getenv("MMSBM_HIP_NO_MFMA") == nullptr;
+    int big_chunk = 4 * mmsbm::kMvChunkPairs;
+    if (c->mfma && c->lay.n_pairs >= 2 * big_chunk * 4 * c->n_cus) big_chunk *= 2;
+    if (const char *e = std::getenv("MMSBM_HIP_MFMA_CHUNK")) big_chunk = std::min(std::max(std::atoi(e) / 64 * 64, 64), kMfmaChunkPairs);  // (tuning)
     if (c->wide) mmsbm::build_mv_chunks(c->lay, kWideChunkPairs);
-    else if (c->kp * c->lp > 1024) mmsbm::build_mv_chunks(c->lay, 4 * mmsbm::kMvChunkPairs);
+    else if (c->kp * c->lp > 1024) mmsbm::build_mv_chunks(c->lay, big_chunk);
     // long rows: the mat-vec's outputs go to memory straight from registers (C5: -6 % on both
     // pair_block launches); short rows are cheaper transposed through LDS and copied out flat
     // (C3: direct stores cost +1.1 / +1.7 us)
@@ -2713,11 +2735,7 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
     c->lds_qa = (static_cast<size_t>(kQuadUnits) * c->lp * (kUnitPairs + 1) + static_cast<size_t>(c->lp) * c->kp) *
                 sizeof(double);
     c->quad_a = !c->wide && c->kp * c->lp > 1024 && c->tl_a && c->pb_threads_a == kPairBlockMax &&
-                c->lds_qa <= kLdsMax - 2048 && c->lp <= 64;
-    // ... and both launches on the matrix cores where the tile has left the scalar cache (pair_mfma_kernel)
-    c->lds_mt = pair_mfma_lds(c->kp, c->lp, true);
-    c->lds_ma = pair_mfma_lds(c->lp, c->kp, false);
-    c->mfma = mfma_possible(c.get()) && c->kp * c->lp > 1024 && std::getenv("MMSBM_HIP_NO_MFMA") == nullptr;
+                c->lds_qa <= kLdsMax - 2048 && c->lp <= 64 && big_chunk == 4 * mmsbm::kMvChunkPairs;
     c->n_pairs = c->lay.n_pairs;
     c->n_chunks = static_cast<int>(c->lay.mv_chunks.size());
     // dense data: XCD-local work lists (layout.hpp) -- every segment cut at fixed borders of the
