@@ -17,6 +17,8 @@ os.makedirs(dst, exist_ok=True)
 def short(name):
     for key, nm in (("seg_pass_kernel", "seg_pass_kernel"), ("pair_block_kernel<false", "pair_block_kernel(T+S)"),
                     ("pair_block_kernel<true", "pair_block_kernel(A)"), ("pair_quad_a_kernel", "pair_block_kernel(A)"),
+                    # (K x L > 1024: the same two launches run pair_mfma_kernel; full_name keeps the kernel's own name)
+                    ("pair_mfma_kernel<false", "pair_block_kernel(T+S)"), ("pair_mfma_kernel<true", "pair_block_kernel(A)"),
                     ("eta_p_kernel", "eta_p_kernel"), ("seg_combine_small_kernel", "seg_combine_small_kernel"),
                     ("seg_combine_kernel", "seg_combine_kernel"), ("likelihood_fast_kernel", "likelihood_fast_kernel"), ("log_table_kernel", "log_table_kernel"),
                     ("init_rows_kernel", "init_rows_kernel"), ("likelihood_units_kernel", "likelihood_units_kernel"),
@@ -40,7 +42,7 @@ if stats:
         w = csv.DictWriter(fh, fieldnames=list(rows[0].keys())); w.writeheader(); w.writerows(rows)
 
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
-for part in ("fetch", "write", "l2", "sq", "lds_a", "lds_b"):
+for part in ("fetch", "write", "l2", "sq", "lds_a", "lds_b", "mfma"):
     for f in newest(os.path.join(src, f"prof_{tag}_{part}", "*", "*_counter_collection.csv")):
         for r in csv.DictReader(open(f)):
             nm = short(r["Kernel_Name"])
@@ -79,7 +81,7 @@ for nm, cs in agg.items():
         ent["avg_us"] = avg_us.get(nm)
         for key in ("SQ_INSTS_LDS", "SQ_ACTIVE_INST_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_WAIT_INST_LDS",
                     "SQ_LDS_IDX_ACTIVE", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU",
-                    "SQ_ACTIVE_INST_ANY"):
+                    "SQ_ACTIVE_INST_ANY", "SQ_INSTS_MFMA", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_F64"):
             if key in cs:
                 ent[key] = sum(cs[key]) / len(cs[key])
         summary[config][nm] = ent
