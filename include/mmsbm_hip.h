@@ -182,7 +182,10 @@ int mmsbm_hip_time_stage(mmsbm_hip_ctx *ctx, int stage, int reps, float *mean_us
  * "quad" 0/1 (long rows: the A launch as a persistent four-unit pipeline), "lik_fast" 0/1
  * (likelihood through logarithm tables), "lik_g" 0/1/2/4/8 (its lanes per triple, 0 = automatic),
  * "slot_waves" 0/1 (several restart slots: one super-group of lanes walks a segment for all slots
- * -- the default -- or every slot in workgroups of its own). */
+ * -- the default -- or every slot in workgroups of its own), "mfma" 0/1 (the pair stage on the
+ * matrix cores, v_mfma_f64_16x16x4_f64; create() turns it on for K x L > 1024 with K, L <= 64 and it can
+ * be forced on any K, L <= 64; environment MMSBM_HIP_NO_MFMA=1 keeps it off), "mfma_threads" 256/512
+ * (workgroup size of its T+S launch). */
 int mmsbm_hip_set_option(mmsbm_hip_ctx *ctx, const char *name, double value);
 /* Reads a knob back; also the read-only "ranges_pairs" / "ranges_users" (ranges the XCD-local work
  * list of that pass uses, 1 = off), "items_pairs" / "items_users" (work items, 0 = segments as
