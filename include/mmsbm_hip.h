@@ -185,7 +185,9 @@ int mmsbm_hip_time_stage(mmsbm_hip_ctx *ctx, int stage, int reps, float *mean_us
  * -- the default -- or every slot in workgroups of its own), "mfma" 0/1 (the pair stage on the
  * matrix cores, v_mfma_f64_16x16x4_f64; create() turns it on for K x L > 1024 with K, L <= 64 and it can
  * be forced on any K, L <= 64; environment MMSBM_HIP_NO_MFMA=1 keeps it off), "mfma_threads" 256/512
- * (workgroup size of its T+S launch). */
+ * (workgroup size of its T+S launch), "predict_fast" 0/1 (prod_dist / predict through the table of
+ * p_r eta_i over every (item, rating) combination -- the default where the rows are not far fewer than
+ * the items -- or always through the one-thread-per-row kernels). */
 int mmsbm_hip_set_option(mmsbm_hip_ctx *ctx, const char *name, double value);
 /* Reads a knob back; also the read-only "ranges_pairs" / "ranges_users" (ranges the XCD-local work
  * list of that pass uses, 1 = off), "items_pairs" / "items_users" (work items, 0 = segments as

@@ -1273,6 +1273,96 @@ __global__ __launch_bounds__(kBlock) void predict_score_kernel(
   if (threadIdx.x < kScoreStats) block_out[blockIdx.x * kScoreStats + threadIdx.x] = red[threadIdx.x][0];
 }
 
+// ======================================================================================
+// prod_dist / predict through the factorisation (round 2).  P[m, r] = theta_u . (p_r eta_i): the inner
+// vector B[(i, r), :] = p_r eta_i is the A launch's mat-vec over EVERY (item, rating) combination (a
+// rating-major pair list q = r I + i built once per context), after which a test row costs R dot
+// products of length K instead of R K L multiply-adds behind dependent loads: 1M rows at K = L = 50,
+// R = 10 took 357 ms per restart in predict_score_kernel, now the B launch (0.2 ms) plus this kernel.
+// A group of G lanes per test row (lane gl owns VEC entries, as in seg_pass); MODE 0 writes the
+// distribution (prod_dist), MODE 1 adds it to the session's running sum and reduces the restart's six
+// indicator sums exactly as predict_score_kernel does (fixed-order tree over the workgroup's rows).
+// ======================================================================================
+template <int G, int VEC, int MODE>
+__global__ __launch_bounds__(kBlock) void predict_rows_kernel(
+    const int32_t *__restrict__ pu, const int32_t *__restrict__ pi, const int32_t *__restrict__ preal,
+    RowTab theta, const double *__restrict__ btab, size_t rating_stride, const double *__restrict__ weights,
+    double *__restrict__ dist, double *__restrict__ block_out, int64_t n_rows, int n_ratings, int dp,
+    int first) {
+  constexpr int PER = kBlock / G;
+  __shared__ double red[kScoreStats][PER];
+  const int gl = threadIdx.x % G, grp = threadIdx.x / G;
+  const int64_t m = static_cast<int64_t>(blockIdx.x) * PER + grp;
+  double st[kScoreStats];
+#pragma unroll
+  for (int j = 0; j < kScoreStats; ++j) st[j] = 0.0;
+  if (m < n_rows) {  // (whole groups)
+    const bool act = gl * VEC < dp;
+    const int lane_off = act ? gl * VEC : 0;
+    double f[VEC];
+    load_vec<VEC>(rowtab_ptr(theta, static_cast<size_t>(pu[m]), lane_off), f);
+    if (!act) {
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) f[v] = 0.0;
+    }
+    const double *brow = btab + static_cast<size_t>(pi[m]) * dp + lane_off;
+    double *srow = dist + m * n_ratings;
+    int best = 0;
+    double bestv = 0.0, tot = 0.0, pond = 0.0;
+    constexpr int RB = 4;  // ratings whose rows are in flight together
+    for (int r0 = 0; r0 < n_ratings; r0 += RB) {
+      double g[RB][VEC];
+#pragma unroll
+      for (int b = 0; b < RB; ++b) load_vec<VEC>(brow + static_cast<size_t>(min(r0 + b, n_ratings - 1)) * rating_stride, g[b]);
+#pragma unroll
+      for (int b = 0; b < RB; ++b) {
+        const int r = r0 + b;
+        if (r < n_ratings) {
+          double pt = 0.0;
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) pt = fma(g[b][v], f[v], pt);
+          const double v = group_sum<G>(pt);
+          if (MODE == 0) {
+            if (gl == 0) srow[r] = v;
+          } else {
+            if (gl == 0) srow[r] = first ? v : srow[r] + v;
+            if (r == 0 || v > bestv) {  // np.argmax: the first maximum
+              bestv = v;
+              best = r;
+            }
+            tot += v;
+            pond += v * weights[r];
+          }
+        }
+      }
+    }
+    if (MODE == 1 && gl == 0 && tot != 0.0) {  // src/mmsbm.py:505-510: all-zero rows are dropped
+      const int real = preal[m];
+      const int dd = abs(best - real);
+      st[0] = 1.0;
+      st[1] = dd == 0 ? 1.0 : 0.0;
+      st[2] = dd <= 1 ? 1.0 : 0.0;
+      st[3] = static_cast<double>(dd);
+      st[4] = (static_cast<double>(real) == rint(pond)) ? 1.0 : 0.0;  // np.round: half to even
+      st[5] = fabs(pond - static_cast<double>(real));
+    }
+  }
+  if (MODE == 0) return;
+  if (gl == 0) {
+#pragma unroll
+    for (int j = 0; j < kScoreStats; ++j) red[j][grp] = st[j];
+  }
+  __syncthreads();
+  for (int h = PER / 2; h > 0; h >>= 1) {
+    if (gl == 0 && grp < h) {
+#pragma unroll
+      for (int j = 0; j < kScoreStats; ++j) red[j][grp] += red[j][grp + h];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < kScoreStats) block_out[blockIdx.x * kScoreStats + threadIdx.x] = red[threadIdx.x][0];
+}
+
 // src/kernels_numpy.py:21-36.  One thread per element; sk/sl = output strides of the
 // internal (k, l) indices (they differ from (L, 1) when the sides are swapped).
 __global__ __launch_bounds__(kBlock) void omegas_kernel(
@@ -1438,6 +1528,12 @@ struct mmsbm_hip_ctx {
   size_t lds_t = 0, lds_a = 0;
   bool tl_t = false, tl_a = false;  // rating tile staged in LDS (T+S launch / A launch)
   bool quad_a = false;  // the A launch runs pair_quad_a_kernel (long rows)
+  // prod_dist / predict through B[(item, rating), :] = p_r eta_i (predict_rows_kernel)
+  DevBuf<int32_t> grid_item;          // item of pair q = r * I + i, every (item, rating) combination
+  DevBuf<mmsbm::Chunk> grid_chunks;   // its rating-homogeneous chunks
+  int grid_n_chunks = 0, mv_chunk_pairs = mmsbm::kMvChunkPairs;
+  DevBuf<double> btab;                // [I * R][kp], of the slot being scored
+  bool predict_fast = true;
   bool mfma = false;    // both pair-stage launches run pair_mfma_kernel (tiles beyond the scalar cache, K, L <= 64)
   size_t lds_mt = 0, lds_ma = 0;
   int mfma_threads = kPairBlockMax;  // T+S launch: 512 (eight waves) or 256
@@ -2259,25 +2355,27 @@ void stage_eta_p(mmsbm_hip_ctx *c, bool commit) {  // eta_new ; p_new, pT_new, r
   ls.done();
 }
 
-// A[q,:] from (eta, pT) of parameter slot `slot` into atab[a_slot]
-void stage_matvec_a(mmsbm_hip_ctx *c, int slot, int a_slot) {
-  if (c->n_chunks == 0) return;
+// A[q,:] from (eta, pT) of parameter slot `slot` into atab[a_slot] -- or, with `grid` set, the same
+// mat-vec over every (item, rating) combination into the plain table btab (prod_dist / predict)
+void stage_matvec_a(mmsbm_hip_ctx *c, int slot, int a_slot, bool grid = false) {
+  const int nb = grid ? c->grid_n_chunks : static_cast<int>(c->lay.mv_chunks.size());
+  if (nb == 0) return;
   LaunchScope ls(c, K_MATVEC_A);
+  PairBlockArgs pa = pair_block_a_args(c, slot, a_slot);
+  if (grid) {
+    pa.pair_item = c->grid_item.ptr; pa.chunks = c->grid_chunks.ptr;
+    pa.out = c->btab.ptr; pa.out_tail = nullptr;
+    pa.out_mw = pa.doutp; pa.out_rs_m = pa.doutp; pa.out_rs_t = 0; pa.bs_out = 0; pa.bs_out_t = 0;
+  }
   if (c->wide) {
-    const int nb = static_cast<int>(c->lay.mv_chunks.size());
-    const PairBlockArgs pa = pair_block_a_args(c, slot, a_slot);
     const int subs = kWideChunkPairs / kWidePairs;
     const size_t lds = static_cast<size_t>(kWidePairs) * c->lp * sizeof(double);
     allow_big_lds(wide_matvec_kernel<true>, lds);
     wide_matvec_kernel<true><<<slot_grid(c, nb * subs), kBlock, lds, c->stream>>>(pa, subs);
   } else if (c->mfma) {
-    const int nb = static_cast<int>(c->lay.mv_chunks.size());
-    const PairBlockArgs pa = pair_block_a_args(c, slot, a_slot);
     allow_big_lds(pair_mfma_kernel<true, false, kBlock>, c->lds_ma);
     pair_mfma_kernel<true, false, kBlock><<<slot_grid(c, nb), kBlock, c->lds_ma, c->stream>>>(pa, pa.tiles);
   } else if (c->quad_a) {
-    const int nb = static_cast<int>(c->lay.mv_chunks.size());
-    const PairBlockArgs pa = pair_block_a_args(c, slot, a_slot);
     const dim3 grid = slot_grid(c, std::min(nb, c->n_cus));
 #define QA(NL)                                                                                    \
   do {                                                                                            \
@@ -2289,8 +2387,6 @@ void stage_matvec_a(mmsbm_hip_ctx *c, int slot, int a_slot) {
     else if (nl <= 13) QA(13); else if (nl <= 14) QA(14); else QA(16);
 #undef QA
   } else {
-    const int nb = static_cast<int>(c->lay.mv_chunks.size());
-    const PairBlockArgs pa = pair_block_a_args(c, slot, a_slot);
 #define PA_D(TL, NT, D)                                                                     \
   do {                                                                                      \
     allow_big_lds(pair_block_kernel<true, false, 1, TL, NT, 4, D>, c->lds_a);               \
@@ -2726,6 +2822,7 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
     if (const char *e = std::getenv("MMSBM_HIP_MFMA_CHUNK")) big_chunk = std::min(std::max(std::atoi(e) / 64 * 64, 64), kMfmaChunkPairs);  // (tuning)
     if (c->wide) mmsbm::build_mv_chunks(c->lay, kWideChunkPairs);
     else if (c->kp * c->lp > 1024) mmsbm::build_mv_chunks(c->lay, big_chunk);
+    c->mv_chunk_pairs = c->wide ? kWideChunkPairs : (c->kp * c->lp > 1024 ? big_chunk : mmsbm::kMvChunkPairs);
     // long rows: the mat-vec's outputs go to memory straight from registers (C5: -6 % on both
     // pair_block launches); short rows are cheaper transposed through LDS and copied out flat
     // (C3: direct stores cost +1.1 / +1.7 us)
@@ -3176,6 +3273,62 @@ int mmsbm_hip_compute_omegas(mmsbm_hip_ctx *ctx, double *out, int64_t capacity_e
   });
 }
 
+namespace {
+// ---- prod_dist / predict through B = p_r eta_i over every (item, rating) combination ---------------
+// Worth it when the rows to score are not far fewer than the items (B costs I R K L multiply-adds, a row
+// then R K instead of R K L) and B fits comfortably: otherwise the per-row kernels run.
+bool rows_fast_ok(const mmsbm_hip_ctx *c, int64_t n_rows) {
+  if (!c->predict_fast || n_rows <= 0) return false;
+  const uint64_t combos = static_cast<uint64_t>(c->n_items) * static_cast<uint64_t>(c->n_ratings);
+  if (combos >= (uint64_t(1) << 31) - 2048 || n_rows * 4 < c->n_items) return false;
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return false;
+  return combos * static_cast<uint64_t>(c->kp) * sizeof(double) <= (free_b + c->btab.count * sizeof(double)) / 2;
+}
+void ensure_pair_grid(mmsbm_hip_ctx *c) {  // q = r * I + i, chunks of the pair stage's size per rating
+  const size_t combos = static_cast<size_t>(c->n_items) * c->n_ratings;
+  if (c->grid_item.count != combos || c->grid_n_chunks == 0) {
+    std::vector<int32_t> item(combos);
+    std::vector<mmsbm::Chunk> chunks;
+    for (int r = 0; r < c->n_ratings; ++r) {
+      const int32_t base = static_cast<int32_t>(static_cast<size_t>(r) * c->n_items);
+      for (int i = 0; i < c->n_items; ++i) item[static_cast<size_t>(base) + i] = i;
+      for (int i = 0; i < c->n_items; i += c->mv_chunk_pairs)
+        chunks.push_back(mmsbm::Chunk{r, base + i, base + std::min(i + c->mv_chunk_pairs, c->n_items), 0});
+    }
+    c->grid_item.upload(item, c->stream);
+    c->grid_chunks.upload(chunks, c->stream);
+    HIP_CHECK(hipStreamSynchronize(c->stream));  // (host vectors are locals)
+    c->grid_n_chunks = static_cast<int>(chunks.size());
+  }
+  if (c->btab.count < combos * c->kp) c->btab.alloc(combos * c->kp);
+}
+// B for the selected slot (the caller holds a OneSlot), then one group of lanes per row.
+// mode 0: dist[m][r] = P[m, r];  mode 1: dist += P, block_out = the restart's six sums per workgroup
+int rows_launch(mmsbm_hip_ctx *c, int mode, const int32_t *pu, const int32_t *pi, const int32_t *preal,
+                const double *weights, double *dist, double *block_out, int64_t n_rows, int first) {
+  ensure_pair_grid(c);
+  stage_matvec_a(c, c->cur, c->cur, true);
+  const int per = kBlock / group_lanes(c->code_k);
+  const int nb = static_cast<int>((n_rows + per - 1) / per);
+  const size_t rstride = static_cast<size_t>(c->n_items) * c->kp;
+#define CALL(G, V)                                                                                           \
+  do {                                                                                                       \
+    if (mode == 0)                                                                                           \
+      predict_rows_kernel<G, V, 0><<<nb, kBlock, 0, c->stream>>>(pu, pi, preal, theta_tab(c, c->cur), c->btab.ptr, \
+          rstride, weights, dist, block_out, n_rows, c->n_ratings, c->kp, first);                            \
+    else                                                                                                     \
+      predict_rows_kernel<G, V, 1><<<nb, kBlock, 0, c->stream>>>(pu, pi, preal, theta_tab(c, c->cur), c->btab.ptr, \
+          rstride, weights, dist, block_out, n_rows, c->n_ratings, c->kp, first);                            \
+  } while (0)
+  DISPATCH_GV(c->code_k, CALL);
+#undef CALL
+  HIP_CHECK(hipGetLastError());
+  return nb;
+}
+
+}  // namespace
+
 int mmsbm_hip_prod_dist(mmsbm_hip_ctx *ctx, int64_t n_pairs, const int32_t *user,
                         const int32_t *item, double *out) {
   return guarded([&] {
@@ -3199,23 +3352,33 @@ int mmsbm_hip_prod_dist(mmsbm_hip_ctx *ctx, int64_t n_pairs, const int32_t *user
     HIP_CHECK(hipMemcpyAsync(di.ptr, ii, sizeof(int32_t) * n_pairs, hipMemcpyHostToDevice, ctx->stream));
     OneSlot one(ctx);
     const int cur = ctx->cur, sl = ctx->sel;
-    const int64_t nb = (n_elems + kBlock - 1) / kBlock;
-    prod_dist_kernel<<<static_cast<unsigned>(nb), kBlock, 0, ctx->stream>>>(
-        du.ptr, di.ptr, theta_tab(ctx, cur), ctx->eta[cur].at(sl), ctx->p[cur].at(sl), dout.ptr,
-        n_pairs, ctx->n_ratings, ctx->k, ctx->l, ctx->kp, ctx->lp);
-    HIP_CHECK(hipGetLastError());
+    if (rows_fast_ok(ctx, n_pairs)) {
+      rows_launch(ctx, 0, du.ptr, di.ptr, nullptr, nullptr, dout.ptr, nullptr, n_pairs, 1);
+    } else {
+      const int64_t nb = (n_elems + kBlock - 1) / kBlock;
+      prod_dist_kernel<<<static_cast<unsigned>(nb), kBlock, 0, ctx->stream>>>(
+          du.ptr, di.ptr, theta_tab(ctx, cur), ctx->eta[cur].at(sl), ctx->p[cur].at(sl), dout.ptr,
+          n_pairs, ctx->n_ratings, ctx->k, ctx->l, ctx->kp, ctx->lp);
+      HIP_CHECK(hipGetLastError());
+    }
     HIP_CHECK(hipMemcpyAsync(out, dout.ptr, sizeof(double) * n_elems, hipMemcpyDeviceToHost, ctx->stream));
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ctx->btab.release();  // (the B table is scratch: restart slots are sized from the free memory)
   });
 }
 
 namespace {
 void score_launch(mmsbm_hip_ctx *ctx, bool finish, double *stats) {
-  const int64_t nb64 = (ctx->ps_rows + kBlock - 1) / kBlock;
+  const bool fast = !finish && rows_fast_ok(ctx, ctx->ps_rows);
+  const int per_block = fast ? kBlock / group_lanes(ctx->code_k) : kBlock;
+  const int64_t nb64 = (ctx->ps_rows + per_block - 1) / per_block;
   const int nb = static_cast<int>(nb64);
   if (ctx->ps_part.count < static_cast<size_t>(nb) * kScoreStats) ctx->ps_part.alloc(static_cast<size_t>(nb) * kScoreStats);
   const int cur = ctx->cur, sl = ctx->sel;
-  if (nb > 0) {
+  if (nb > 0 && fast) {
+    rows_launch(ctx, 1, ctx->ps_u.ptr, ctx->ps_i.ptr, ctx->ps_r.ptr, ctx->ps_w.ptr, ctx->ps_sum.ptr, ctx->ps_part.ptr,
+                ctx->ps_rows, ctx->ps_added == 0 ? 1 : 0);
+  } else if (nb > 0) {
     if (finish)
       predict_score_kernel<true><<<nb, kBlock, 0, ctx->stream>>>(
           ctx->ps_u.ptr, ctx->ps_i.ptr, ctx->ps_r.ptr, theta_tab(ctx, cur), ctx->eta[cur].at(sl),
@@ -3296,6 +3459,7 @@ int mmsbm_hip_predict_finish(mmsbm_hip_ctx *ctx, double *mean_dist, double stats
     const int64_t rows = ctx->ps_rows;
     score_launch(ctx, true, stats);
     ctx->ps_rows = -1;  // the session is over whatever happens next
+    ctx->btab.release();
     if (mean_dist && rows > 0) {
       HIP_CHECK(hipMemcpyAsync(mean_dist, ctx->ps_sum.ptr, sizeof(double) * rows * ctx->n_ratings,
                                hipMemcpyDeviceToHost, ctx->stream));
@@ -3430,6 +3594,8 @@ int mmsbm_hip_set_option(mmsbm_hip_ctx *ctx, const char *name, double value) {
     } else if (key == "quad") {  // 0: the A launch through pair_block like every other shape
       ctx->quad_a = value != 0.0 && !ctx->wide && ctx->kp * ctx->lp > 1024 && ctx->tl_a &&
                     ctx->pb_threads_a == kPairBlockMax && ctx->lds_qa <= kLdsMax - 2048 && ctx->lp <= 64;
+    } else if (key == "predict_fast") {  // 0: prod_dist / predict through the per-row kernels (R K L multiply-adds per row)
+      ctx->predict_fast = value != 0.0;
     } else if (key == "mfma_threads") {
       if (value != kBlock && value != kPairBlockMax) throw std::invalid_argument("mfma_threads: 256 or 512");
       ctx->mfma_threads = static_cast<int>(value);
@@ -3451,6 +3617,7 @@ int mmsbm_hip_get_option(const mmsbm_hip_ctx *ctx, const char *name, double *val
     else if (key == "quad") *value = ctx->quad_a;
     else if (key == "mfma") *value = ctx->mfma;
     else if (key == "mfma_threads") *value = ctx->mfma_threads;
+    else if (key == "predict_fast") *value = ctx->predict_fast;
     else if (key == "wide") *value = ctx->wide;
     else if (key == "slot_waves") *value = ctx->slot_waves;
     else if (key == "lik_fast") *value = ctx->lik_fast;

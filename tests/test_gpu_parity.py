@@ -689,6 +689,46 @@ def test_device_predict_score_matches_host_formulas(hip, swap):
         assert abs(got["s2pond"] - want["s2pond"]) <= 1e-12 * want["s2pond"]
 
 
+@pytest.mark.parametrize("k,l,n_i", [(3, 4, 40), (20, 20, 150), (50, 50, 90), (8, 70, 60), (200, 24, 50)])
+def test_predict_through_the_item_rating_table(hip, k, l, n_i):
+    """prod_dist / predict as P[m, r] = theta_u . (p_r eta_i): the inner vectors for every (item,
+    rating) combination come from the A launch's mat-vec (lane-per-pair, matrix-core and wide-row
+    forms), a test row then costs R dot products (predict_rows_kernel).  Same distributions as the
+    per-row kernels (option predict_fast = 0) and the oracle, same indicator sums; taken only when
+    the rows are not far fewer than the items."""
+    rng = np.random.default_rng(k * 31 + l)
+    n_u, n_r = 120, 4
+    data = np.stack([rng.integers(0, n_u, 3000), rng.integers(0, n_i, 3000), rng.integers(0, n_r, 3000)], axis=1).astype(np.int64)
+    test = np.stack([rng.integers(0, n_u, 1001), rng.integers(0, n_i, 1001), rng.integers(0, n_r, 1001)], axis=1).astype(np.int64)
+    d_u, d_i = orc.degrees(data, n_u, n_i)
+    weights = np.arange(n_r, dtype=np.float64)
+    for swap in (0, 1):
+        with hip.HipEM(data, k, l, n_u, n_i, n_r, slots=2, swap_sides=swap) as em:
+            for s_ in range(2):
+                em.select(s_).set_params(*orc.init_params(7 + s_, n_u, n_i, n_r, k, l, d_u, d_i))
+            em.iterate(2)
+            got = {}
+            for fast in (1, 0):
+                em.set_option("predict_fast", fast)
+                assert em.get_option("predict_fast") == float(fast)
+                rats = [em.select(s_).prod_dist(test) for s_ in range(2)]
+                em.predict_begin(test, weights)
+                per = [em.select(s_).predict_add() for s_ in range(2)]
+                mean, raw = em.predict_finish()
+                assert np.array_equal(mean, np.array(rats).mean(axis=0))
+                got[fast] = (rats, per, mean, raw)
+            em.set_option("predict_fast", 1)
+            few = em.select(0).prod_dist(test[:3])           # 3 rows, many items: the per-row kernel either way
+            ref = [orc.prod_dist(test, *em.select(s_).get_params()) for s_ in range(2)]
+        for s_ in range(2):
+            assert np.allclose(got[1][0][s_], ref[s_], rtol=1e-11, atol=1e-300)
+            assert np.allclose(got[1][0][s_], got[0][0][s_], rtol=1e-12, atol=1e-300)
+            assert np.array_equal(got[1][1][s_][:5], got[0][1][s_][:5])                     # counts: exact
+            assert got[1][1][s_][5] == pytest.approx(got[0][1][s_][5], rel=1e-12)
+        assert np.array_equal(got[1][3][:5], got[0][3][:5])
+        assert np.allclose(few, ref[0][:3], rtol=1e-11, atol=1e-300)
+
+
 def test_device_predict_session_errors(hip):
     from mmsbm_amd import _lib
     data, test, (n_u, n_i, n_r, k, l), d_u, d_i = _score_problem()
