@@ -1434,8 +1434,8 @@ struct DevBuf {
   }
   void alloc(size_t n) {
     release();
-    count = n;
     HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&ptr), std::max<size_t>(n, 1) * sizeof(T)));
+    count = n;  // (only once the memory is there: a failed allocation leaves an empty buffer)
   }
   void upload(const std::vector<T> &h, hipStream_t s) {
     alloc(h.size());
@@ -1537,6 +1537,7 @@ struct mmsbm_hip_ctx {
   bool mfma = false;    // both pair-stage launches run pair_mfma_kernel (tiles beyond the scalar cache, K, L <= 64)
   size_t lds_mt = 0, lds_ma = 0;
   int mfma_threads = kPairBlockMax;  // T+S launch: 512 (eight waves) or 256
+  bool mfma_big = false;  // K or L beyond 64: the blocked forms (mfma_rows_kernel + mfma_slab_kernel)
   bool wide = false;    // K, L beyond the LDS stage: wide_matvec / wide_slab kernels (any size)
   bool slot_waves = true;  // several slots: one super-group of lanes walks a segment for all of them
   int ranges_pairs = 1, ranges_users = 1;  // XCD-local work lists: ranges the gathered table is cut into
@@ -1879,7 +1880,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? MMSBM_MFMA_WPE : 2) void pair_mfma_
       }                                                                                                 \
     }                                                                                                   \
   } while (0)
-  MFMA_FETCH(ch.q_begin);
+  if (ch.q_begin < ch.q_end) MFMA_FETCH(ch.q_begin);  // (an empty chunk -- padding of the unit list -- only writes its zero slab)
 
   for (int q0 = ch.q_begin; q0 < ch.q_end; q0 += kUnitPairs) {
     const int np = min(kUnitPairs, ch.q_end - q0);
@@ -1973,6 +1974,226 @@ __global__ __launch_bounds__(NT, NT == 512 ? MMSBM_MFMA_WPE : 2) void pair_mfma_
 #undef MFMA_FETCH
 #undef MFMA_PX
 #undef MFMA_PE
+// ======================================================================================
+// The same two products for K or L beyond 64, in 64 x 64 blocks (round 2).  Before, these shapes ran the
+// lane-per-pair stage with the tile through scalar loads (K, L up to ~150) or the plain wide-row kernels
+// (beyond): at K = L = 100 the pair stage took 61 % of the iteration, at K = L = 200 75 %.  Blocked, T and
+// S no longer share a workgroup (T sums over ALL of Din for a block of outputs; S keeps a Din x Dout block
+// in the accumulators over ALL pairs of a chunk), so the T+S stage is two launches:
+//   mfma_rows_kernel<GATHER>  workgroup = (64-pair unit, block of <= 64 output columns): loops over the
+//       64-blocks of Din -- X block transposed + tile block in LDS, the next blocks in flight -- with the
+//       output tiles in the accumulators throughout (wave = 16 rows x 2 column tiles);
+//   mfma_slab_kernel          workgroup = (chunk, Din block, Dout block): loops over the chunk's units --
+//       X block transposed + E block in LDS -- with its <= 16 slab tiles dealt to the 8 waves.
+// Operand layouts, clamping of partial tiles and association order as in pair_mfma_kernel.  Each table is
+// re-read once per block of the other side (from L2 / the Infinity Cache: blocks of one unit are
+// neighbours in the grid).
+// ======================================================================================
+constexpr int kMfmaBlk = 64;
+
+// pair = t / w for t < 2^32 / w through a multiply-high (see pair_mfma_kernel)
+__device__ __forceinline__ unsigned mfma_magic(int w) { return 0xFFFFFFFFu / static_cast<unsigned>(w) + 1u; }
+
+template <bool GATHER>
+__global__ __launch_bounds__(kPairBlockMax, 4) void mfma_rows_kernel(PairBlockArgs pa, const double *__restrict__ tiles0,
+                                                                    int subs_per_chunk, int n_lb) {
+  constexpr int NT = kPairBlockMax, CS = kUnitPairs + 1, NLD = kUnitPairs * kMfmaBlk / 2 / NT;  // 4 double2 per table
+  const size_t slot = blockIdx.y;
+  const double *__restrict__ tiles = tiles0 + slot * pa.bs_tiles;
+  const double *__restrict__ in_tab = pa.in_tab + slot * pa.bs_in;
+  double *__restrict__ out = pa.out + slot * pa.bs_out;
+  double *__restrict__ out_tail = pa.out_tail + slot * pa.bs_out_t;
+  const int dinp = pa.dinp, doutp = pa.doutp;
+  const int lb = static_cast<int>(blockIdx.x % n_lb), usub = static_cast<int>(blockIdx.x / n_lb);
+  const mmsbm::Chunk ch = pa.chunks[usub / subs_per_chunk];
+  const int q0 = ch.q_begin + (usub % subs_per_chunk) * kUnitPairs;
+  if (q0 >= ch.q_end) return;
+  const int np = min(kUnitPairs, ch.q_end - q0);
+  const int lb0 = lb * kMfmaBlk, lbw = min(kMfmaBlk, doutp - lb0);
+  extern __shared__ double lds[];
+  double *cst = lds;                        // [64 k'][CS]   X block, transposed
+  double *tile_b = cst + kMfmaBlk * CS;     // [64 k'][64]   tile block
+  int *ids_l = reinterpret_cast<int *>(tile_b + kMfmaBlk * kMfmaBlk);  // [64]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lk = lane >> 4;
+  if (GATHER) {
+    if (tid < kUnitPairs) ids_l[tid] = pa.pair_item[q0 + min(tid, np - 1)];
+    __syncthreads();
+  }
+  const double *__restrict__ tile_r = tiles + static_cast<size_t>(ch.rating) * dinp * doutp + lb0;
+  const int trow0 = 16 * (wave & 3), tn0 = 2 * (wave >> 2);
+  int bcol[2];
+#pragma unroll
+  for (int n = 0; n < 2; ++n) bcol[n] = min(16 * (tn0 + n) + li, lbw - 1);
+  mfma_d4 acc[2];
+#pragma unroll
+  for (int n = 0; n < 2; ++n) acc[n] = mfma_d4{0.0, 0.0, 0.0, 0.0};
+  const unsigned ml = mfma_magic(lbw);
+  double2 vx[NLD];
+  double tx[NLD], ty[NLD];
+  // shares of a block: X element t = (pair, k') with pair = t / kbw; tile element t = (k', j) with k' = t / lbw
+#define ROWS_FETCH(KB0)                                                                                        \
+  do {                                                                                                         \
+    const int fk0 = (KB0), fkw = min(kMfmaBlk, dinp - fk0);                                                    \
+    const unsigned fmx = mfma_magic(fkw);                                                                      \
+    _Pragma("unroll") for (int j = 0; j < NLD; ++j) {                                                          \
+      const int t = tid * 2 + j * NT * 2;                                                                      \
+      const int fp0 = static_cast<int>(__umulhi(static_cast<unsigned>(t), fmx)), fpr = min(fp0, np - 1);       \
+      const int fd = min(t - fp0 * fkw, fkw - 2);                                                              \
+      const size_t frow = GATHER ? static_cast<size_t>(ids_l[fpr]) : static_cast<size_t>(q0 + fpr);            \
+      vx[j] = *reinterpret_cast<const double2 *>(in_tab + frow * dinp + fk0 + fd);                             \
+      const int fr0 = static_cast<int>(__umulhi(static_cast<unsigned>(t), ml)), frr = min(fr0, fkw - 1);       \
+      const double2 ft = *reinterpret_cast<const double2 *>(tile_r + static_cast<size_t>(fk0 + frr) * doutp +  \
+                                                            min(t - fr0 * lbw, lbw - 2));                      \
+      tx[j] = ft.x;                                                                                            \
+      ty[j] = ft.y;                                                                                            \
+    }                                                                                                          \
+  } while (0)
+  ROWS_FETCH(0);
+  for (int kb0 = 0; kb0 < dinp; kb0 += kMfmaBlk) {
+    const int kbw = min(kMfmaBlk, dinp - kb0);
+    const unsigned mx = mfma_magic(kbw);
+    if (kb0 != 0) __syncthreads();  // previous block fully consumed
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+      const int t = tid * 2 + j * NT * 2;
+      const int pr = static_cast<int>(__umulhi(static_cast<unsigned>(t), mx));
+      if (pr < kUnitPairs) {  // (pairs >= np hold a copy of the last row: their output rows are never stored)
+        double *dst = cst + (t - pr * kbw) * CS + pr;
+        dst[0] = vx[j].x;
+        dst[CS] = vx[j].y;
+      }
+      const int kr = static_cast<int>(__umulhi(static_cast<unsigned>(t), ml));
+      if (kr < kbw) {
+        double2 t2;
+        t2.x = tx[j]; t2.y = ty[j];
+        *reinterpret_cast<double2 *>(tile_b + kr * kMfmaBlk + (t - kr * lbw)) = t2;
+      }
+    }
+    __syncthreads();
+    if (kb0 + kMfmaBlk < dinp) ROWS_FETCH(kb0 + kMfmaBlk);
+#pragma unroll 2
+    for (int s = 0; s < kbw / 4; ++s) {
+      const double x = cst[(4 * s + lk) * CS + trow0 + li];
+      const double *trow = tile_b + (4 * s + lk) * kMfmaBlk;
+#pragma unroll
+      for (int n = 0; n < 2; ++n) acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(x, trow[bcol[n]], acc[n], 0, 0, 0);
+    }
+  }
+#undef ROWS_FETCH
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    const int col = 16 * (tn0 + n) + li;
+    if (col < lbw) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int r = trow0 + lk + 4 * g;
+        if (r < np) *pair_out_ptr(pa, out, out_tail, static_cast<size_t>(q0 + r), lb0 + col) = acc[n][g];
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(kPairBlockMax, 4) void mfma_slab_kernel(PairBlockArgs pa, int n_kb, int n_lb) {
+  constexpr int NT = kPairBlockMax, NW = NT / 64, CS = kUnitPairs + 1, NLD = kUnitPairs * kMfmaBlk / 2 / NT;
+  const size_t slot = blockIdx.y;
+  const double *__restrict__ in_tab = pa.in_tab + slot * pa.bs_in;
+  const double *__restrict__ e_tab = pa.e_tab + slot * pa.bs_e;
+  double *__restrict__ partial = pa.partial + slot * pa.bs_partial;
+  const int dinp = pa.dinp, doutp = pa.doutp;
+  const int blk = static_cast<int>(blockIdx.x % (n_kb * n_lb)), chunk = static_cast<int>(blockIdx.x / (n_kb * n_lb));
+  const int kb0 = (blk / n_lb) * kMfmaBlk, lb0 = (blk % n_lb) * kMfmaBlk;
+  const int kbw = min(kMfmaBlk, dinp - kb0), lbw = min(kMfmaBlk, doutp - lb0);
+  const mmsbm::Chunk ch = pa.chunks[chunk];
+  extern __shared__ double lds[];
+  double *cst = lds;                      // [64 k'][CS]  X block, transposed
+  double *es = cst + kMfmaBlk * CS;       // [64 pairs][64]  E block
+  int *ids_l = reinterpret_cast<int *>(es + kUnitPairs * kMfmaBlk);  // [kMfmaChunkPairs]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lk = lane >> 4;
+  for (int t = tid; t < ch.q_end - ch.q_begin; t += NT) ids_l[t] = pa.pair_item[ch.q_begin + t];
+  const int mt = (kbw + 15) >> 4, nt = (lbw + 15) >> 4;
+  mfma_d4 acc[2];
+  int s_a[2], s_b[2];
+  bool s_on[2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int t = wave + NW * a;
+    s_on[a] = t < mt * nt;
+    const int m = s_on[a] ? t / nt : 0, n = s_on[a] ? t - m * nt : 0;
+    s_a[a] = min(16 * m + li, kbw - 1) * CS + lk;
+    s_b[a] = lk * kMfmaBlk + min(16 * n + li, lbw - 1);
+    acc[a] = mfma_d4{0.0, 0.0, 0.0, 0.0};
+  }
+  const unsigned mx = mfma_magic(kbw), me = mfma_magic(lbw);
+  __syncthreads();  // ids
+  double2 vx[NLD];
+  double ex[NLD], ey[NLD];
+#define SLAB_FETCH(Q0)                                                                                         \
+  do {                                                                                                         \
+    const int fq = (Q0), fnp = min(kUnitPairs, ch.q_end - fq), fbase = fq - ch.q_begin;                         \
+    _Pragma("unroll") for (int j = 0; j < NLD; ++j) {                                                          \
+      const int t = tid * 2 + j * NT * 2;                                                                      \
+      const int fp0 = static_cast<int>(__umulhi(static_cast<unsigned>(t), mx)), fpr = min(fp0, fnp - 1);       \
+      vx[j] = *reinterpret_cast<const double2 *>(in_tab + static_cast<size_t>(fq + fpr) * dinp + kb0 +         \
+                                                 min(t - fp0 * kbw, kbw - 2));                                 \
+      const int fe0 = static_cast<int>(__umulhi(static_cast<unsigned>(t), me));                                \
+      const size_t ferow = static_cast<size_t>(ids_l[fbase + min(fe0, fnp - 1)]);                              \
+      const double2 fe = *reinterpret_cast<const double2 *>(e_tab + ferow * doutp + lb0 + min(t - fe0 * lbw, lbw - 2)); \
+      ex[j] = fe.x;                                                                                            \
+      ey[j] = fe.y;                                                                                            \
+    }                                                                                                          \
+  } while (0)
+  if (ch.q_begin < ch.q_end) SLAB_FETCH(ch.q_begin);  // (an empty chunk only writes its zero block)
+  for (int q0 = ch.q_begin; q0 < ch.q_end; q0 += kUnitPairs) {
+    const int np = min(kUnitPairs, ch.q_end - q0);
+    if (q0 != ch.q_begin) __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+      const int t = tid * 2 + j * NT * 2;
+      const int pr = static_cast<int>(__umulhi(static_cast<unsigned>(t), mx));
+      if (pr < kUnitPairs) {  // pairs >= np: zero columns of X (so that whatever E holds there adds nothing)
+        double *dst = cst + (t - pr * kbw) * CS + pr;
+        dst[0] = pr < np ? vx[j].x : 0.0;
+        dst[CS] = pr < np ? vx[j].y : 0.0;
+      }
+      const int pe = static_cast<int>(__umulhi(static_cast<unsigned>(t), me));
+      if (pe < kUnitPairs) {  // (pairs >= np: a copy of the last row, finite)
+        double2 e2;
+        e2.x = ex[j]; e2.y = ey[j];
+        *reinterpret_cast<double2 *>(es + pe * kMfmaBlk + (t - pe * lbw)) = e2;
+      }
+    }
+    __syncthreads();
+    if (q0 + kUnitPairs < ch.q_end) SLAB_FETCH(q0 + kUnitPairs);
+#pragma unroll 4
+    for (int s = 0; s < kUnitPairs / 4; ++s) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+        acc[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(cst[s_a[a] + 4 * s], es[s_b[a] + 4 * s * kMfmaBlk], acc[a], 0, 0, 0);
+    }
+  }
+#undef SLAB_FETCH
+  double *dst = partial + static_cast<size_t>(chunk) * dinp * doutp;
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    if (!s_on[a]) continue;
+    const int t = wave + NW * a, m = t / nt, n = t - m * nt;
+    const int col = 16 * n + li;
+    if (col < lbw) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int k = 16 * m + lk + 4 * g;
+        if (k < kbw) dst[static_cast<size_t>(kb0 + k) * doutp + lb0 + col] = acc[a][g];
+      }
+    }
+  }
+}
+constexpr size_t kMfmaRowsLds = (kMfmaBlk * (kUnitPairs + 1) + kMfmaBlk * kMfmaBlk) * sizeof(double) + kUnitPairs * sizeof(int);
+constexpr size_t kMfmaSlabLds = (kMfmaBlk * (kUnitPairs + 1) + kUnitPairs * kMfmaBlk) * sizeof(double) + kMfmaChunkPairs * sizeof(int);
+
 size_t pair_mfma_lds(int dinp, int doutp, bool with_s) {
   return (static_cast<size_t>(dinp) * (kUnitPairs + 1) + static_cast<size_t>(dinp) * doutp +
           (with_s ? static_cast<size_t>(kUnitPairs) * doutp : 0)) * sizeof(double) + kMfmaChunkPairs * sizeof(int);
@@ -2279,6 +2500,19 @@ bool mfma_possible(const mmsbm_hip_ctx *c) {
 
 void stage_dense(mmsbm_hip_ctx *c) {  // T = P^T C  and the K x L slabs for p
   if (c->n_chunks == 0) return;
+  if (c->mfma_big) {
+    LaunchScope ls(c, K_DENSE);
+    const int nb = static_cast<int>(c->lay.mv_chunks.size());
+    const PairBlockArgs pa = pair_block_t_args(c);
+    const int subs = c->mv_chunk_pairs / kUnitPairs;
+    const int n_kb = (c->kp + kMfmaBlk - 1) / kMfmaBlk, n_lb = (c->lp + kMfmaBlk - 1) / kMfmaBlk;
+    allow_big_lds(mfma_rows_kernel<false>, kMfmaRowsLds);
+    allow_big_lds(mfma_slab_kernel, kMfmaSlabLds);
+    mfma_rows_kernel<false><<<slot_grid(c, nb * subs * n_lb), kPairBlockMax, kMfmaRowsLds, c->stream>>>(pa, pa.tiles, subs, n_lb);
+    mfma_slab_kernel<<<slot_grid(c, nb * n_kb * n_lb), kPairBlockMax, kMfmaSlabLds, c->stream>>>(pa, n_kb, n_lb);
+    ls.done();
+    return;
+  }
   if (c->wide) {
     LaunchScope ls(c, K_DENSE);
     const int nb = static_cast<int>(c->lay.mv_chunks.size());
@@ -2367,7 +2601,11 @@ void stage_matvec_a(mmsbm_hip_ctx *c, int slot, int a_slot, bool grid = false) {
     pa.out = c->btab.ptr; pa.out_tail = nullptr;
     pa.out_mw = pa.doutp; pa.out_rs_m = pa.doutp; pa.out_rs_t = 0; pa.bs_out = 0; pa.bs_out_t = 0;
   }
-  if (c->wide) {
+  if (c->mfma_big) {
+    const int subs = c->mv_chunk_pairs / kUnitPairs, n_kb = (c->kp + kMfmaBlk - 1) / kMfmaBlk;  // (outputs: K columns)
+    allow_big_lds(mfma_rows_kernel<true>, kMfmaRowsLds);
+    mfma_rows_kernel<true><<<slot_grid(c, nb * subs * n_kb), kPairBlockMax, kMfmaRowsLds, c->stream>>>(pa, pa.tiles, subs, n_kb);
+  } else if (c->wide) {
     const int subs = kWideChunkPairs / kWidePairs;
     const size_t lds = static_cast<size_t>(kWidePairs) * c->lp * sizeof(double);
     allow_big_lds(wide_matvec_kernel<true>, lds);
@@ -2817,6 +3055,11 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
     c->lds_mt = pair_mfma_lds(c->kp, c->lp, true);
     c->lds_ma = pair_mfma_lds(c->lp, c->kp, false);
     c->mfma = mfma_possible(c.get()) && c->kp * c->lp > 1024 && std::getenv("MMSBM_HIP_NO_MFMA") == nullptr;
+    // K or L beyond 64: the blocked matrix-core kernels take over from the lane-per-pair stage with its tile in
+    // scalar loads and from the wide-row kernels (skinny shapes -- a side below 16 -- keep those: one
+    // 16 x 16 tile would be mostly padding)
+    c->mfma_big = !c->mfma && c->kp * c->lp > 1024 && std::min(c->kp, c->lp) >= 16 &&
+                  std::getenv("MMSBM_HIP_NO_MFMA") == nullptr;
     int big_chunk = 4 * mmsbm::kMvChunkPairs;
     if (c->mfma && c->lay.n_pairs >= 2 * big_chunk * 4 * c->n_cus) big_chunk *= 2;
     if (const char *e = std::getenv("MMSBM_HIP_MFMA_CHUNK")) big_chunk = std::min(std::max(std::atoi(e) / 64 * 64, 64), kMfmaChunkPairs);  // (tuning)
@@ -3303,11 +3546,23 @@ void ensure_pair_grid(mmsbm_hip_ctx *c) {  // q = r * I + i, chunks of the pair 
   }
   if (c->btab.count < combos * c->kp) c->btab.alloc(combos * c->kp);
 }
-// B for the selected slot (the caller holds a OneSlot), then one group of lanes per row.
+// eligibility + the table's memory; false (and no error left behind) sends the caller to the per-row kernels
+bool rows_fast_prepare(mmsbm_hip_ctx *c, int64_t n_rows) {
+  if (!rows_fast_ok(c, n_rows)) return false;
+  try {
+    ensure_pair_grid(c);
+  } catch (const ApiError &) {  // out of memory after all (another context took it): not an error of this call
+    (void)hipGetLastError();
+    c->btab.release();
+    return false;
+  }
+  return true;
+}
+// B for the selected slot (the caller holds a OneSlot and rows_fast_prepare said yes), then one group of
+// lanes per row.
 // mode 0: dist[m][r] = P[m, r];  mode 1: dist += P, block_out = the restart's six sums per workgroup
 int rows_launch(mmsbm_hip_ctx *c, int mode, const int32_t *pu, const int32_t *pi, const int32_t *preal,
                 const double *weights, double *dist, double *block_out, int64_t n_rows, int first) {
-  ensure_pair_grid(c);
   stage_matvec_a(c, c->cur, c->cur, true);
   const int per = kBlock / group_lanes(c->code_k);
   const int nb = static_cast<int>((n_rows + per - 1) / per);
@@ -3352,7 +3607,7 @@ int mmsbm_hip_prod_dist(mmsbm_hip_ctx *ctx, int64_t n_pairs, const int32_t *user
     HIP_CHECK(hipMemcpyAsync(di.ptr, ii, sizeof(int32_t) * n_pairs, hipMemcpyHostToDevice, ctx->stream));
     OneSlot one(ctx);
     const int cur = ctx->cur, sl = ctx->sel;
-    if (rows_fast_ok(ctx, n_pairs)) {
+    if (rows_fast_prepare(ctx, n_pairs)) {
       rows_launch(ctx, 0, du.ptr, di.ptr, nullptr, nullptr, dout.ptr, nullptr, n_pairs, 1);
     } else {
       const int64_t nb = (n_elems + kBlock - 1) / kBlock;
@@ -3369,7 +3624,7 @@ int mmsbm_hip_prod_dist(mmsbm_hip_ctx *ctx, int64_t n_pairs, const int32_t *user
 
 namespace {
 void score_launch(mmsbm_hip_ctx *ctx, bool finish, double *stats) {
-  const bool fast = !finish && rows_fast_ok(ctx, ctx->ps_rows);
+  const bool fast = !finish && rows_fast_prepare(ctx, ctx->ps_rows);
   const int per_block = fast ? kBlock / group_lanes(ctx->code_k) : kBlock;
   const int64_t nb64 = (ctx->ps_rows + per_block - 1) / per_block;
   const int nb = static_cast<int>(nb64);
@@ -3599,8 +3854,10 @@ int mmsbm_hip_set_option(mmsbm_hip_ctx *ctx, const char *name, double value) {
     } else if (key == "mfma_threads") {
       if (value != kBlock && value != kPairBlockMax) throw std::invalid_argument("mfma_threads: 256 or 512");
       ctx->mfma_threads = static_cast<int>(value);
-    } else if (key == "mfma") {  // the pair stage on the matrix cores (any K, L <= 64; chosen by create() for big tiles)
-      ctx->mfma = value != 0.0 && mfma_possible(ctx);
+    } else if (key == "mfma") {  // the pair stage on the matrix cores: 0 off, 1 on (one-block form if K, L <= 64,
+                                 // else the blocked form), 2 the blocked form whatever the shape
+      ctx->mfma = value == 1.0 && mfma_possible(ctx);
+      ctx->mfma_big = value != 0.0 && !ctx->mfma && ctx->mv_chunk_pairs <= kMfmaChunkPairs;
     } else {
       throw std::invalid_argument("unknown option: " + key);
     }
@@ -3615,7 +3872,7 @@ int mmsbm_hip_get_option(const mmsbm_hip_ctx *ctx, const char *name, double *val
     if (key == "graph") *value = ctx->graph_mode;
     else if (key == "direct") *value = ctx->direct_out;
     else if (key == "quad") *value = ctx->quad_a;
-    else if (key == "mfma") *value = ctx->mfma;
+    else if (key == "mfma") *value = ctx->mfma ? 1.0 : (ctx->mfma_big ? 2.0 : 0.0);
     else if (key == "mfma_threads") *value = ctx->mfma_threads;
     else if (key == "predict_fast") *value = ctx->predict_fast;
     else if (key == "wide") *value = ctx->wide;

@@ -1010,6 +1010,50 @@ def test_pair_stage_on_the_matrix_cores(hip, k, l, forced):
                 assert rel_err(a, b) < 1e-12, (swap, s_, nm)
 
 
+@pytest.mark.parametrize("k,l,mode", [(80, 80, 1), (100, 100, 1), (130, 70, 1), (65, 16, 1), (200, 200, 1), (300, 24, 1),
+                                      (20, 20, 2), (50, 50, 2), (7, 64, 2), (64, 64, 2)])
+def test_pair_stage_on_the_matrix_cores_blocked(hip, k, l, mode):
+    """K or L beyond 64: mfma_rows_kernel + mfma_slab_kernel (64 x 64 blocks), the library's own choice
+    where both sides have at least 16 groups; forced (option mfma = 2) on shapes the one-block kernel or
+    the vector kernels would take.  Ragged chunks, restart slots, either orientation; against the oracle
+    and against the vector-ALU kernels (lane-per-pair stage or wide rows) of the same context."""
+    rng = np.random.default_rng(1000 * k + l)
+    n_u, n_i, n_r = 200, 150, 3
+    n = 4000 if k * l < 20000 else 2500
+    r_col = np.minimum(rng.geometric(0.5, n) - 1, n_r - 1)
+    data = np.stack([rng.integers(0, n_u, n), rng.integers(0, n_i, n), r_col], axis=1).astype(np.int64)
+    d_u, d_i = orc.degrees(data, n_u, n_i)
+    theta, eta, pr = orc.init_params(21, n_u, n_i, n_r, k, l, d_u, d_i)
+    theta2, eta2, pr2 = orc.init_params(22, n_u, n_i, n_r, k, l, d_u, d_i)
+    want = orc.update_coefficients(data, theta, eta, pr)
+    t, e, p = theta, eta, pr
+    for _ in range(2):
+        t, e, p = orc.em_step(data, t, e, p, d_u, d_i)
+    for swap in (0, 1):
+        outs = {}
+        with hip.HipEM(data, k, l, n_u, n_i, n_r, slots=2, swap_sides=swap) as em:
+            if mode == 1:
+                assert em.get_option("mfma") == 2.0                   # the library's own choice
+            for on in (mode, 0):
+                em.set_option("mfma", on)
+                assert em.get_option("mfma") == (2.0 if on else 0.0)
+                em.select(1).set_params(theta2, eta2, pr2)
+                em.select(0).set_params(theta, eta, pr)
+                if on:
+                    for got, w, nm in zip(em.update_coefficients(), want, ("n_theta", "n_eta", "n_pr")):
+                        assert rel_err(got, w) < TOL_STEP, (swap, nm)
+                em.iterate(2)
+                outs[on] = [em.select(s_).get_params() for s_ in range(2)]
+                if on:
+                    assert em.select(0).likelihood() == pytest.approx(float(orc.compute_likelihood(data, t, e, p)), rel=1e-11)
+                    assert np.allclose(em.select(0).prod_dist(data[:400]), orc.prod_dist(data[:400], t, e, p), rtol=1e-11, atol=1e-300)
+        for got, w, nm in zip(outs[mode][0], (t, e, p), ("theta", "eta", "pr")):
+            assert rel_err(got, w) < 1e-11, (swap, nm)
+        for s_ in range(2):
+            for a, b, nm in zip(outs[mode][s_], outs[0][s_], ("theta", "eta", "pr")):
+                assert rel_err(a, b) < 1e-12, (swap, s_, nm)
+
+
 @pytest.mark.parametrize("n_r,k,l", [(1, 3, 4), (33, 5, 6), (100, 4, 3), (7, 20, 20)])
 def test_many_or_single_rating_values(hip, n_r, k, l):
     """R = 1 (p stays 1 everywhere) up to R = 100 (many tiny rating-homogeneous units, several
