@@ -182,9 +182,10 @@ int mmsbm_hip_time_stage(mmsbm_hip_ctx *ctx, int stage, int reps, float *mean_us
  * "quad" 0/1 (long rows: the A launch as a persistent four-unit pipeline), "lik_fast" 0/1
  * (likelihood through logarithm tables), "lik_g" 0/1/2/4/8 (its lanes per triple, 0 = automatic),
  * "slot_waves" 0/1 (several restart slots: one super-group of lanes walks a segment for all slots
- * -- the default -- or every slot in workgroups of its own), "mfma" 0/1 (the pair stage on the
- * matrix cores, v_mfma_f64_16x16x4_f64; create() turns it on for K x L > 1024 with K, L <= 64 and it can
- * be forced on any K, L <= 64; environment MMSBM_HIP_NO_MFMA=1 keeps it off), "mfma_threads" 256/512
+ * -- the default -- or every slot in workgroups of its own), "mfma" 0/1/2 (the pair stage on the
+ * matrix cores, v_mfma_f64_16x16x4_f64: 0 off, 1 on -- the one-block kernel for K, L <= 64, else the
+ * blocked kernels --, 2 the blocked kernels whatever the shape; create() turns it on for K x L > 1024
+ * unless a side has fewer than 16 groups; environment MMSBM_HIP_NO_MFMA=1 keeps it off), "mfma_threads" 256/512
  * (workgroup size of its T+S launch), "predict_fast" 0/1 (prod_dist / predict through the table of
  * p_r eta_i over every (item, rating) combination -- the default where the rows are not far fewer than
  * the items -- or always through the one-thread-per-row kernels). */
