@@ -286,7 +286,9 @@ def main():
                                    f"{model.m + 1} items, R={r}, K={k}, L={l}, one restart per GPU "
                                    f"(sampling={world}), uniform generator seed 0, model seed 0",
                        "launch": "hipGraph replay" if args.graph else "eager",
-                       "pairs": ctx.n_pairs},
+                       "pairs": ctx.n_pairs,
+                       "pair_stage": {0.0: "vector ALUs (pair_block_kernel)", 1.0: "matrix cores (pair_mfma_kernel)",
+                                      2.0: "matrix cores, blocked (mfma_rows_kernel + mfma_slab_kernel)"}[ctx.get_option("mfma")]},
             "collective": coll,
             "roofline": roofline_object(args, ctx, prof, n, k, l),
             "iteration": {"algorithmic_read_bytes": rd, "algorithmic_write_bytes": wr,
