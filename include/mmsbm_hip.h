@@ -192,7 +192,8 @@ int mmsbm_hip_time_stage(mmsbm_hip_ctx *ctx, int stage, int reps, float *mean_us
 int mmsbm_hip_set_option(mmsbm_hip_ctx *ctx, const char *name, double value);
 /* Reads a knob back; also the read-only "ranges_pairs" / "ranges_users" (ranges the XCD-local work
  * list of that pass uses, 1 = off), "items_pairs" / "items_users" (work items, 0 = segments as
- * they are) and "wide" (1: K, L beyond the 64-pair LDS stage, the plain wide-row kernels run). */
+ * they are) and "wide" (1: K, L beyond the 64-pair LDS stage -- the vector form of the pair stage is then the plain
+ * wide-row kernels; they run when "mfma" reads 0, the blocked matrix-core kernels when it reads 2). */
 int mmsbm_hip_get_option(const mmsbm_hip_ctx *ctx, const char *name, double *value);
 /* How em_iterate launches: 0 (default) = eager launches on the context's stream; 1 = replay
  * a captured hipGraph of two iterations. */
