@@ -40,6 +40,21 @@ for j in range(300):
         for s in range(em.slots):
             em.select(s).init_params(j + s)
         em.iterate(3)
+        if j % 3 == 0:   # the prediction paths and their scratch (item x rating table, session buffers)
+            rows = small[: 40_000 if j % 2 else 300]
+            em.select(0).prod_dist(rows)
+            em.predict_begin(rows, np.arange(5, dtype=np.float64))
+            em.predict_add()
+            em.predict_finish()
         if j % 100 == 0:
             print(f"create/destroy {j}: free {free_mb() - base:+.1f} MiB vs start", flush=True)
 print(f"after 300 contexts: free {free_mb() - base:+.1f} MiB vs start  [{time.time() - t0:.1f}s]")
+big = synthetic_triples(400_000, 40_000, 5_000, 6, 2)
+for j, (kk, ll) in enumerate([(50, 50), (100, 80), (200, 200), (300, 8)] * 5):      # every pair-stage family
+    with HipEM(big, kk, ll, slots=1 + j % 2) as em:
+        for s in range(em.slots):
+            em.select(s).init_params(j + s)
+        em.iterate(2)
+        em.select(0).prod_dist(big[:50_000])
+        assert np.isfinite(em.select(0).likelihood())
+print(f"after 20 contexts with big tiles (matrix-core one-block / blocked, wide rows): free {free_mb() - base:+.1f} MiB vs start  [{time.time() - t0:.1f}s]")
