@@ -104,6 +104,21 @@ class HipEM:
         if int(slots) != 1:
             self.set_slots(slots)
 
+    def suggested_slots(self, most=8):
+        """How many restarts to advance together as slots of one launch.  Slots share the index stream and
+        turn a gathered row into whole cache lines, which pays while the slot-interleaved gathered tables
+        (rows x K x 8 bytes x slots) stay below roughly 700 MB; beyond that the gathers get slower than the
+        sharing saves.  Measured per restart-iteration, 1 / 4 / 8 slots: 1M ratings K=20 98 / 77 / 75 us,
+        10M x 1M users K=20 1,046 / 838 / 919, 4M x 400k K=50 905 / 878 / 886, 10M x 1M K=50 (BASELINE
+        config 5) 2,213 / 2,469 / 2,394 -- there the restarts run one after the other."""
+        rows = max(self.n_items if self.swapped else self.n_users, self.n_pairs)
+        groups = self.l if self.swapped else self.k
+        table = rows * 8 * (-(-groups // 4) * 4)
+        s = max(1, int(most))
+        while s > 1 and s * table > 700 * 2 ** 20:
+            s //= 2
+        return s
+
     # -- lifetime ------------------------------------------------------------------------
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:

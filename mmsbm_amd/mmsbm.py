@@ -39,7 +39,7 @@ class MMSBM:
     rng = None
 
     def __init__(self, user_groups, item_groups, iterations=400, sampling=1, seed=None,
-                 debug=False, backend="auto", devices=None, restarts_per_launch=8,
+                 debug=False, backend="auto", devices=None, restarts_per_launch=None,
                  contexts_per_device=1, tol=None, check_every=50):
         self.start_time = datetime.now()
         self.user_groups = user_groups
@@ -51,7 +51,8 @@ class MMSBM:
         self.devices = devices
         # Restarts that share a GPU run as slots of one context, up to this many per batch
         # (C3: 1.2x the restarts/s of one at a time, C2: 3x, C1-sized problems: ~Sx).
-        self.restarts_per_launch = max(1, int(restarts_per_launch))
+        # restarts advanced together as slots of one context; None: HipEM.suggested_slots() decides from the table sizes
+        self.restarts_per_launch = None if restarts_per_launch is None else max(1, int(restarts_per_launch))
         # More than one context (= stream) per GPU is possible too; slots do the same job
         # better, so the default is one.
         self.contexts_per_device = max(1, int(contexts_per_device))
@@ -133,8 +134,9 @@ class MMSBM:
         def work(w):  # this worker's restarts, in batches of slots
             dev, slot = workers[w]
             mine, out = todo[w::len(workers)], []
-            for b in range(0, len(mine), self.restarts_per_launch):
-                batch = mine[b:b + self.restarts_per_launch]
+            per = self.restarts_per_launch or self._ctx(dev, slot).suggested_slots()
+            for b in range(0, len(mine), per):
+                batch = mine[b:b + per]
                 out.extend(zip(batch, self.run_samplings(batch, device=dev, slot=slot)))
             return out
 

@@ -47,6 +47,9 @@ class FakeHipEM:
     def max_slots(self, fraction=0.5, sharers=1):
         return getattr(FakeHipEM, "MAX_SLOTS", 1 << 20)
 
+    def suggested_slots(self, most=8):
+        return getattr(FakeHipEM, "SUGGESTED_SLOTS", most)
+
     # -- parameters
     def degrees(self):
         return orc.degrees(self.data, self.n_users, self.n_items)

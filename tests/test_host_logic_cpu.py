@@ -91,6 +91,31 @@ def test_restarts_are_batched_over_slots_without_changing_them(fake):
     assert mm.likelihood == mm.results[accs.index(max(accs))]["likelihood"]   # best run = best accuracy
 
 
+def test_default_batch_size_follows_the_table_sizes(fake, monkeypatch):
+    """restarts_per_launch=None: the context's suggestion decides (HipEM.suggested_slots: 8, halved while
+    the slot-interleaved gathered tables would exceed ~700 MB -- BASELINE config 5 runs its restarts one
+    after the other); an explicit value wins."""
+    import types
+    from mmsbm_amd.core import HipEM
+
+    def sug(n_users, n_items, n_pairs, k, l, swapped=False):
+        return HipEM.suggested_slots(types.SimpleNamespace(n_users=n_users, n_items=n_items, n_pairs=n_pairs,
+                                                           k=k, l=l, swapped=swapped))
+    assert sug(100_000, 20_000, 100_000, 20, 20) == 8               # C3 / C4
+    assert sug(1_000_000, 100_000, 1_000_000, 20, 20) == 4
+    assert sug(400_000, 50_000, 400_000, 50, 50) == 4
+    assert sug(1_000_000, 100_000, 1_000_000, 50, 50) == 1          # C5
+    assert sug(100_000, 1_000_000, 900_000, 50, 20, swapped=True) == sug(1_000_000, 100_000, 900_000, 20, 50)
+    g = load_golden("g2_c1_sampling3")
+    for suggested, per, want in ((8, None, [3]), (1, None, [1, 1, 1]), (2, None, [2, 1]), (1, 8, [3])):
+        monkeypatch.setattr(fake.FakeHipEM, "SUGGESTED_SLOTS", suggested, raising=False)
+        fake.LOG.clear()
+        mm = host.MMSBM(2, 2, iterations=10, sampling=3, seed=1, restarts_per_launch=per)
+        mm.fit_encoded(g["train"])
+        assert [e[1] for e in fake.LOG if e[0] == "set_slots"][1:] == want
+        assert np.array_equal(np.array([r["likelihood"] for r in mm.results]), g["likelihoods"])
+
+
 def test_restarts_spread_over_devices_and_contexts(fake):
     g = load_golden("g2_c1_sampling3")
     mm = host.MMSBM(2, 2, iterations=10, sampling=3, seed=1, devices=[1, 0, 1], contexts_per_device=1)
