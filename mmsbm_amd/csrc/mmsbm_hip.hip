@@ -1079,7 +1079,12 @@ __global__ __launch_bounds__(kLikThreads) void likelihood_fast_kernel(
   const const_tile_ptr gltile = (const_tile_ptr)(reinterpret_cast<uintptr_t>(logp + toff));
   constexpr int TPB = kLikThreads / G;  // triples per round
   const int grp = tid / G, g = tid % G;
-  const int col0 = g * LW;
+  // lane g of a group owns the column PAIRS 2g, 2g + 2G, 2g + 4G, ...: one (16-byte) read instruction of a
+  // group then covers 2G consecutive tile entries in LDS.  (Blocks of LW consecutive columns per lane put the
+  // lanes 8 LW bytes apart -- a two-way bank conflict on every tile read: SQ_LDS_BANK_CONFLICT was twice
+  // SQ_ACTIVE_INST_LDS at C5; single columns g, g + G, ... are conflict-free too but cannot be read as
+  // 16-byte pairs: 52 vs 39 ms.)
+#define LIK_COL(j) (2 * g + ((j) & 1) + 2 * G * ((j) >> 1))
   const double log_eps = log(kEps);
   const int t0 = poff[0], t1 = poff[npairs];
   double total = 0.0;
@@ -1097,7 +1102,7 @@ __global__ __launch_bounds__(kLikThreads) void likelihood_fast_kernel(
     double e[LW], le[LW];
 #pragma unroll
     for (int j = 0; j < LW; j += 2) {  // (columns past lp: any in-range address, masked below)
-      const int cc = min(col0 + j, lp - 2);
+      const int cc = min(LIK_COL(j), lp - 2);
       const double2 v = *reinterpret_cast<const double2 *>(eta + irow * lp + cc);
       const double2 lv = *reinterpret_cast<const double2 *>(leta + irow * lp + cc);
       e[j] = v.x; e[j + 1] = v.y;
@@ -1109,7 +1114,7 @@ __global__ __launch_bounds__(kLikThreads) void likelihood_fast_kernel(
       const double ltk = *rowtab_ptr(ltheta, urow, k);
 #pragma unroll
       for (int j = 0; j < LW; ++j) {
-        const int l = col0 + j;
+        const int l = LIK_COL(j);
         const bool real = l < l_groups;
         const int lc = min(l, lp - 1);
         double pv, lpv;
@@ -1143,6 +1148,7 @@ __global__ __launch_bounds__(kLikThreads) void likelihood_fast_kernel(
   }
   if (tid == 0) block_out[blockIdx.x] = red[0];
 }
+#undef LIK_COL
 
 // ======================================================================================
 // Initial parameters on the device (src/mmsbm.py:224-233): table[row][j] = U / degree(row) with

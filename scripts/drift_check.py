@@ -1,4 +1,4 @@
-"""Drift of the HIP path against the oracle over many EM iterations (C2, or a slice of C3):
+"""Drift of the HIP path against the oracle over many EM iterations (a config tag or N,U,I,R,K,L):
 max |diff| / max |want| for theta, eta, p at checkpoints, and argmax agreement of the
 predictions under the tie rule (compare only where the oracle's top-2 gap exceeds 1e-9)."""
 import sys, os, time
@@ -9,7 +9,7 @@ from mmsbm_amd.synthetic import CONFIGS, synthetic_triples
 from oracle import mmsbm_oracle as orc
 name = sys.argv[1] if len(sys.argv) > 1 else "c2"
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 200
-n, u, i, r, k, l = CONFIGS[name]
+n, u, i, r, k, l = CONFIGS[name] if name in CONFIGS else tuple(int(x) for x in name.split(","))  # or N,U,I,R,K,L
 train = synthetic_triples(n, u, i, r, 0)
 mm = MMSBM(k, l, iterations=iters, seed=0); mm._prepare_objects(train)
 ctx = mm._ctx(0); d_u, d_i = ctx.degrees()
