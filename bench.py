@@ -77,11 +77,13 @@ def self_launch(args):
 
 
 def kernel_source_sha16():
-    """Identity of the kernels a profile was taken with (profiles/pmc_summary.json records it)."""
+    """Identity of the kernels a profile was taken with (profiles/pmc_summary.json records it): every
+    source under mmsbm_amd/csrc, in name order."""
     h = hashlib.sha256()
-    for rel in ("mmsbm_amd/csrc/mmsbm_hip.hip", "mmsbm_amd/csrc/layout.hpp"):
-        with open(os.path.join(ROOT, rel), "rb") as fh:
-            h.update(fh.read())
+    csrc = os.path.join(ROOT, "mmsbm_amd", "csrc")
+    for name in sorted(f for f in os.listdir(csrc) if f.endswith((".hip", ".hpp"))):
+        with open(os.path.join(csrc, name), "rb") as fh:
+            h.update(name.encode() + b"\0" + fh.read())
     return h.hexdigest()[:16]
 
 

@@ -7,9 +7,9 @@ import subprocess
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(PKG_DIR, "csrc", "mmsbm_hip.hip")
-DEPS = [SRC, os.path.join(PKG_DIR, "csrc", "layout.hpp"), os.path.join(PKG_DIR, "csrc", "layout_gpu.hpp"),
-        os.path.join(PKG_DIR, "csrc", "pcg64.hpp"),
-        os.path.join(os.path.dirname(PKG_DIR), "include", "mmsbm_hip.h")]
+CSRC = os.path.join(PKG_DIR, "csrc")
+DEPS = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp"))) + [
+    os.path.join(os.path.dirname(PKG_DIR), "include", "mmsbm_hip.h")]
 LIB = os.path.join(PKG_DIR, "libmmsbm_hip.so")
 ARCH = "gfx950"
 # MMSBM_HIPCC_FLAGS: extra compiler flags for experiments (e.g. "-mllvm -amdgpu-kernarg-preload-count=16")

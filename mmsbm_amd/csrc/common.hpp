@@ -1,0 +1,96 @@
+// common.hpp -- error plumbing and the device helpers every kernel uses (DPP moves, group sums, vector loads)
+// Part of the single translation unit mmsbm_hip.hip (included there, in order; not a stand-alone header).
+#pragma once
+
+namespace {
+
+
+// ======================================================================================
+// errors
+// ======================================================================================
+thread_local std::string g_last_error;
+
+struct ApiError : std::runtime_error {
+  int code;
+  ApiError(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+
+#define HIP_CHECK(expr)                                                                 \
+  do {                                                                                  \
+    hipError_t e_ = (expr);                                                             \
+    if (e_ != hipSuccess)                                                               \
+      throw ApiError(MMSBM_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));   \
+  } while (0)
+
+template <class F>
+int guarded(F &&f) {
+  try {
+    f();
+    return MMSBM_OK;
+  } catch (const ApiError &e) {
+    g_last_error = e.what();
+    return e.code;
+  } catch (const std::invalid_argument &e) {
+    g_last_error = e.what();
+    return MMSBM_E_INVALID;
+  } catch (const std::bad_alloc &) {
+    g_last_error = "host allocation failed";
+    return MMSBM_E_INTERNAL;
+  } catch (const std::exception &e) {
+    g_last_error = e.what();
+    return MMSBM_E_INTERNAL;
+  }
+}
+
+constexpr double kEps = 2.220446049250313e-16;  // np.finfo(float).eps, src/kernels_numpy.py:51
+constexpr int64_t kGpuLayoutMin = 100'000;       // triples from which the layout's sorts run on the device
+constexpr int kBlock = 256;
+
+// ======================================================================================
+// device helpers
+// ======================================================================================
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+
+// Sum over the G consecutive lanes of a group (G a power of two, groups aligned to G).
+// Every step adds a value to its mirror image, so all lanes of a group end with the
+// bitwise-identical sum.  Up to 16 lanes stay inside one DPP row (no LDS traffic).
+template <int G>
+__device__ __forceinline__ double group_sum(double x) {
+  if (G >= 2) x += dpp_move<0xB1>(x);    // quad_perm [1,0,3,2]
+  if (G >= 4) x += dpp_move<0x4E>(x);    // quad_perm [2,3,0,1]
+  if (G >= 8) x += dpp_move<0x141>(x);   // row_half_mirror
+  if (G >= 16) x += dpp_move<0x140>(x);  // row_mirror
+  if (G >= 32) x += __shfl_xor(x, 16, 64);
+  if (G >= 64) x += __shfl_xor(x, 32, 64);
+  return x;
+}
+
+template <int VEC>
+__device__ __forceinline__ void load_vec(const double *__restrict__ p, double (&v)[VEC]) {
+#pragma unroll
+  for (int j = 0; j < VEC; j += 2) {
+    const double2 t = *reinterpret_cast<const double2 *>(p + j);
+    v[j] = t.x;
+    v[j + 1] = t.y;
+  }
+}
+
+template <int VEC>
+__device__ __forceinline__ void store_vec(double *__restrict__ p, const double (&v)[VEC]) {
+#pragma unroll
+  for (int j = 0; j < VEC; j += 2) {
+    double2 t;
+    t.x = v[j];
+    t.y = v[j + 1];
+    *reinterpret_cast<double2 *>(p + j) = t;
+  }
+}
+
+
+}  // namespace

@@ -1,0 +1,216 @@
+// eta_p.hpp -- p_update and item_sum, the two roles of eta_p_kernel
+// Part of the single translation unit mmsbm_hip.hip (included there, in order; not a stand-alone header).
+#pragma once
+
+namespace {
+
+// ======================================================================================
+// kernel 4: p_update -- n_p[r][k][l] = p[r][k][l] * sum_{chunks c of r} S_c[k][l] (fixed
+// order: 64 strided partial sums, then 8 sums of 8, then a sum of 8), followed by
+// normalize_with_self over r (src/expectation_maximization.py:152-155; zero rows stay
+// zero).  One block owns 16 (k,l) columns for ALL ratings (8 x 128 rows is 0.5 us faster launched
+// back to back but 0.5 us slower inside the iteration; 4 x 256 rows is slower either way), so no
+// inter-block hand-off is
+// needed; every thread's slab loads are independent and issued back to back.  Writes
+// p_new as [R][Kp][Lp] and transposed [R][Lp][Kp]; optionally the raw numerators.
+// ======================================================================================
+constexpr int kRedCols = 16, kRedRows = 64, kRedGroup = 6;  // ratings per LDS pass
+constexpr int kRedThreads = kRedCols * kRedRows, kRedBatch = 5;  // 64 x 5 = 320 slabs per rating in one round (C3: 313)
+
+template <int ROWS>
+__device__ __forceinline__ void p_update_block(
+    double (*red)[ROWS][kRedCols], int block, const double *__restrict__ partial,
+    const int32_t *__restrict__ chunk_off, const double *__restrict__ p_old,
+    double *__restrict__ p_new, double *__restrict__ pt_new, double *__restrict__ npr,
+    int n_ratings, int kp, int lp, int normalize) {
+  const int tx = threadIdx.x % kRedCols, ty = threadIdx.x / kRedCols;
+  const int kl = kp * lp;
+  const int col = block * kRedCols + tx;
+  const bool ok = col < kl;
+  double tot_all = 0.0;  // meaningful for ty == 0
+  for (int r0 = 0; r0 < n_ratings; r0 += kRedGroup) {
+    const int nr = min(kRedGroup, n_ratings - r0);
+    int c0[kRedGroup], c1[kRedGroup];
+    double s[kRedGroup], pold[kRedGroup];
+    int longest = 0;
+#pragma unroll
+    for (int j = 0; j < kRedGroup; ++j)  // (needed at the very end: fetched up front, off the tail of the chain)
+      pold[j] = (ty == 0 && ok && j < nr) ? p_old[static_cast<size_t>(r0 + j) * kl + col] : 0.0;
+#pragma unroll
+    for (int j = 0; j < kRedGroup; ++j) {
+      const int r = min(r0 + j, n_ratings - 1);
+      c0[j] = chunk_off[r];
+      c1[j] = (j < nr) ? chunk_off[r + 1] : c0[j];
+      longest = max(longest, c1[j] - c0[j]);
+      s[j] = 0.0;
+    }
+    if (ok) {
+      for (int off = ty; off < longest; off += ROWS * kRedBatch) {
+        double v[kRedGroup][kRedBatch];
+#pragma unroll
+        for (int j = 0; j < kRedGroup; ++j)
+#pragma unroll
+          for (int i = 0; i < kRedBatch; ++i) {  // every rating's slab loads issued together
+            const int c = c0[j] + off + i * ROWS;
+            v[j][i] = (c < c1[j]) ? partial[static_cast<size_t>(c) * kl + col] : 0.0;
+          }
+#pragma unroll
+        for (int j = 0; j < kRedGroup; ++j)
+#pragma unroll
+          for (int i = 0; i < kRedBatch; ++i) s[j] += v[j][i];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < kRedGroup; ++j) red[j][ty][tx] = s[j];
+    __syncthreads();
+    if (ty < 8) {  // ROWS rows -> 8 partial sums (fixed order)
+#pragma unroll
+      for (int j = 0; j < kRedGroup; ++j) {
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < ROWS / 8; ++i) t += red[j][ty * (ROWS / 8) + i][tx];
+        s[j] = t;
+      }
+    }
+    __syncthreads();
+    if (ty < 8) {
+#pragma unroll
+      for (int j = 0; j < kRedGroup; ++j) red[j][ty][tx] = s[j];
+    }
+    __syncthreads();
+    if (ty == 0 && ok) {
+#pragma unroll
+      for (int j = 0; j < kRedGroup; ++j) {
+        if (j < nr) {
+          double tot = red[j][0][tx];
+#pragma unroll
+          for (int i = 1; i < 8; ++i) tot += red[j][i][tx];
+          const size_t e = static_cast<size_t>(r0 + j) * kl + col;
+          const double raw = pold[j] * tot;
+          npr[e] = raw;
+          tot_all += raw;
+          s[j] = raw;  // stays in registers for the single-group case below
+        }
+      }
+    }
+    __syncthreads();
+    if (n_ratings <= kRedGroup) {  // common case: normalise straight from registers
+      if (ty == 0 && ok && normalize) {
+        const double den = (tot_all == 0.0) ? 1.0 : tot_all;
+        const int k = col / lp, l = col % lp;
+#pragma unroll
+        for (int j = 0; j < kRedGroup; ++j) {
+          if (j < nr) {
+            const double v = s[j] / den;
+            p_new[static_cast<size_t>(j) * kl + col] = v;
+            pt_new[static_cast<size_t>(j) * kl + static_cast<size_t>(l) * kp + k] = v;
+          }
+        }
+      }
+      return;
+    }
+  }
+  if (ty == 0 && ok && normalize) {
+    const double den = (tot_all == 0.0) ? 1.0 : tot_all;
+    const int k = col / lp, l = col % lp;
+    for (int r = 0; r < n_ratings; ++r) {
+      const size_t e = static_cast<size_t>(r) * kl + col;
+      const double v = npr[e] / den;  // this thread's own stores: program order suffices
+      p_new[e] = v;
+      pt_new[static_cast<size_t>(r) * kl + static_cast<size_t>(l) * kp + k] = v;
+    }
+  }
+}
+
+// ======================================================================================
+// item_sum -- eta_new[i,:] = eta[i,:] * sum_{q in item i} T[q,:] / d_i  (src/mmsbm.py:249).
+// One group of G lanes per item.
+// ======================================================================================
+template <int G, int VEC>
+__device__ __forceinline__ void item_sum_block(
+    int block, const double *__restrict__ ttab, const int32_t *__restrict__ item_off,
+    const int32_t *__restrict__ item_pairs, const int32_t *__restrict__ item_deg,
+    const double *__restrict__ eta, double *__restrict__ eta_new, int n_items, int lp,
+    int normalize, const int32_t *__restrict__ item_grid, int n_ratings) {
+  constexpr int B = 8;
+  const int it = block * (static_cast<int>(blockDim.x) / G) + threadIdx.x / G;
+  const int gl = threadIdx.x % G;
+  if (it >= n_items || gl * VEC >= lp) return;
+  const int lane_off = gl * VEC;
+  double acc[VEC], e[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) acc[v] = 0.0;
+  load_vec<VEC>(eta + static_cast<size_t>(it) * lp + lane_off, e);
+  if (item_grid) {
+    // dense data (most (item, rating) combinations occur): the item's pairs sit in a fixed-width
+    // grid row (-1: no such pair; ascending rating like the CSR list, so the sums are the same), one
+    // dependent load level less than offsets -> pair ids -> rows
+    const int32_t *row = item_grid + static_cast<size_t>(it) * n_ratings;
+    for (int j = 0; j < n_ratings; j += B) {
+      int id[B];
+      double t[B][VEC];
+#pragma unroll
+      for (int b = 0; b < B; ++b) id[b] = row[min(j + b, n_ratings - 1)];
+#pragma unroll
+      for (int b = 0; b < B; ++b) load_vec<VEC>(ttab + static_cast<size_t>(max(id[b], 0)) * lp + lane_off, t[b]);
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+        if (j + b < n_ratings && id[b] >= 0) {
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) acc[v] += t[b][v];
+        }
+      }
+    }
+  }
+  const int beg = item_grid ? 0 : item_off[it], end = item_grid ? 0 : item_off[it + 1];
+  for (int j = beg; j < end; j += B) {
+    int id[B];
+    double t[B][VEC];
+#pragma unroll
+    for (int b = 0; b < B; ++b) id[b] = item_pairs[min(j + b, end - 1)];
+#pragma unroll
+    for (int b = 0; b < B; ++b) load_vec<VEC>(ttab + static_cast<size_t>(id[b]) * lp + lane_off, t[b]);
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+      if (j + b < end) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] += t[b][v];
+      }
+    }
+  }
+  const double d = static_cast<double>(max(item_deg[it], 1));
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) e[v] = normalize ? (e[v] * acc[v]) / d : e[v] * acc[v];
+  store_vec<VEC>(eta_new + static_cast<size_t>(it) * lp + lane_off, e);
+}
+
+// eta_p -- the two independent updates that follow the T / slab stage share ONE launch:
+// blocks [0, nb_p) run p_update_block, the rest run item_sum_block.
+struct EtaPArgs {
+  const double *partial; const int32_t *chunk_off; const double *p_old;
+  double *p_new; double *pt_new; double *npr;
+  const double *ttab; const int32_t *item_off; const int32_t *item_pairs; const int32_t *item_deg;
+  const double *eta; double *eta_new;
+  int n_ratings, kp, lp, n_items, normalize, nb_p, abl;
+  size_t bs_partial, bs_p, bs_t, bs_eta;  // restart slots (blockIdx.y): table strides
+  const int32_t *item_grid;               // [n_items][n_ratings] pair id or -1 (dense data), else null
+};
+
+template <int G, int VEC>
+__global__ __launch_bounds__(kRedThreads) void eta_p_kernel(EtaPArgs a) {
+  __shared__ double red[kRedGroup][kRedRows][kRedCols];
+  const size_t slot = blockIdx.y;
+  if (a.abl & (static_cast<int>(blockIdx.x) < a.nb_p ? 64 : 128)) return;  // tuning aid: skip a role
+  if (static_cast<int>(blockIdx.x) < a.nb_p)
+    p_update_block<kRedRows>(red, blockIdx.x, a.partial + slot * a.bs_partial, a.chunk_off,
+                             a.p_old + slot * a.bs_p, a.p_new + slot * a.bs_p,
+                             a.pt_new + slot * a.bs_p, a.npr + slot * a.bs_p, a.n_ratings, a.kp,
+                             a.lp, a.normalize);
+  else
+    item_sum_block<G, VEC>(blockIdx.x - a.nb_p, a.ttab + slot * a.bs_t, a.item_off, a.item_pairs,
+                           a.item_deg, a.eta + slot * a.bs_eta, a.eta_new + slot * a.bs_eta,
+                           a.n_items, a.lp, a.normalize, a.item_grid, a.n_ratings);
+}
+
+
+}  // namespace

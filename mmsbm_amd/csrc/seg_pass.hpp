@@ -1,0 +1,266 @@
+// seg_pass.hpp -- kernel 0: the two triple passes (pair segments, user segments) and the combine kernels of split segments
+// Part of the single translation unit mmsbm_hip.hip (included there, in order; not a stand-alone header).
+#pragma once
+
+namespace {
+
+// ======================================================================================
+// kernel 0: seg_pass -- the two triple passes (user segments and pair segments), fused
+// into one launch.  One group of G lanes per segment; lane gl owns VEC consecutive
+// entries of the K-vector.
+//
+//   acc[:] = sum_{n in segment} gath[idx[n], :] / max(fixed[seg, :] . gath[idx[n], :], eps)
+//
+//   user segments: fixed = theta, gath = A, out = theta * acc / d_u   (src/mmsbm.py:248)
+//   pair segments: fixed = A,     gath = theta, out = C = acc
+// ======================================================================================
+// A table of rows that are GATHERED by index (theta, A).  A 160-byte row (K = 20) straddles two
+// 128-byte cache lines; the table is therefore kept as a "main" part of whole 128-byte lines
+// (mw = 16 * floor(Kp/16) doubles per row, line aligned) plus a compact "tail" part
+// (tw = Kp - mw doubles per row), so a gather misses on one line of the big main part and
+// hits the small, cache-resident tail part.  mw == row width and tw == 0 describes a plain table.
+struct RowTab {
+  double *main;      // row r, off < mw:  main + r * rs_m + off
+  double *tail;      // row r, off >= mw: tail + r * rs_t + (off - mw)
+  int mw, tw;        // widths of the two parts (tw == 0: a plain table)
+  int rs_m, rs_t;    // row strides in doubles
+  size_t so_m, so_t; // distance between the copies of two consecutive restart slots (see below)
+};
+// Restart slots.  The two GATHERED tables (theta, A) keep the slots' copies of a row side by side:
+// row r = [slot 0 | slot 1 | ...], so rs_m = n_slots * mw, so_m = mw (and the same for the tail part).
+// One index then serves every slot and a gather of row r for all slots is ONE contiguous piece of
+// n_slots * 160 bytes at K = 20 -- whole 128-byte lines, no separate 32-byte tail access.  Streamed
+// tables (C, T, eta) are plain per-slot copies: rs_m = width, so_m = the table's size.
+__device__ __forceinline__ double *rowtab_ptr(const RowTab &t, size_t row, int off) {
+  return off < t.mw ? t.main + row * t.rs_m + off : t.tail + row * t.rs_t + (off - t.mw);
+}
+
+struct SegArgs {
+  RowTab fixed;
+  RowTab gath;
+  const int32_t *off;
+  const int32_t *idx;
+  RowTab out;
+  int32_t nseg;  // number of work units: segments, or work items when `items` is set
+  int32_t mode;  // 0: out = acc   1: out = fixed*acc/max(len,1)   2: out = fixed*acc
+  const mmsbm::WorkItem *items;  // null: unit w is segment w.  Else unit w is a piece of a segment
+  double *parts;                 // [n_parts][dp] partial rows of the split segments
+  size_t bs_parts;               // restart slots: distance in doubles between the slots' partial rows
+};
+__device__ __forceinline__ RowTab slot_tab(RowTab t, size_t slot) {
+  t.main += slot * t.so_m;
+  t.tail += slot * t.so_t;
+  return t;
+}
+
+// One body for both forms.  SW == 1: a group of G lanes per segment, the restart slot is blockIdx.y.
+// SW > 1: a "super-group" of SW x G lanes walks one segment for SW slots (lane = slot * G + gl).  The
+// slots' copies of a gathered row are neighbours in memory (RowTab), so one index load serves all of
+// them and the gather of a row is one contiguous piece of SW * 8 * dp bytes -- whole cache lines, no
+// separate 32-byte tail access; blockIdx.y = group of SW slots.  Per (segment, slot) the arithmetic
+// does not depend on SW: slot s of a batch is bitwise what a one-slot context computes.
+//
+// Lane gl of a group owns the VEC consecutive doubles gl * VEC .. of the row (two 16-byte loads per row
+// at VEC = 4).  Dealing the columns out interleaved instead (load instruction j of lane gl = double2
+// number j * G + gl, so that one instruction of a group covers one whole 128-byte line and the two
+// loads of a row never wait on each other's pending miss in the L1 -- TCP_PENDING_STALL_CYCLES is 40 %
+// of the launch) was measured: bitwise-different sums, same accuracy, 98.3 vs 96.9 us per iteration at
+// C3 (16 more VGPRs for the per-instruction addresses); not kept.
+template <int G, int VEC, int B, int SW>
+__device__ __forceinline__ void seg_body(const SegArgs &a, int unit, int dp, int n_slots) {
+  constexpr int GS = G * SW;
+  const int sl = threadIdx.x % GS, gl = sl % G;
+  const int slot = SW == 1 ? static_cast<int>(blockIdx.y) : static_cast<int>(blockIdx.y) * SW + sl / G;
+  if (unit >= a.nseg) return;  // whole (super-)groups leave together
+  const bool slot_ok = SW == 1 || slot < n_slots;
+  const size_t sidx = slot_ok ? slot : 0;
+  const RowTab fixed = slot_tab(a.fixed, sidx), gath = slot_tab(a.gath, sidx), outt = slot_tab(a.out, sidx);
+  int seg = unit, beg, end, part = -1;
+  if (a.items) {
+    const mmsbm::WorkItem it = a.items[unit];
+    seg = it.seg; beg = it.begin; end = it.end; part = it.part;
+    if (seg < 0) return;  // padding of an XCD-local work list
+  } else {
+    beg = a.off[unit];
+    end = a.off[unit + 1];
+  }
+  const bool act = gl * VEC < dp && slot_ok;
+  const int lane_off = gl * VEC < dp ? gl * VEC : 0;
+  double f[VEC], acc[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) acc[v] = 0.0;
+  load_vec<VEC>(rowtab_ptr(fixed, seg, lane_off), f);
+  if (!act) {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) f[v] = 0.0;
+  }
+  // this lane's part of every gathered row: main or tail, fixed for the whole kernel
+  const bool g_main = lane_off < gath.mw;
+  const double *gbase = g_main ? gath.main + lane_off : gath.tail + (lane_off - gath.mw);
+  const size_t gstride = g_main ? gath.rs_m : gath.rs_t;
+
+  // Every lane of the (super-)group fetches one index of the segment (one coalesced load per GS
+  // triples, two per lane in small groups); the indices are then broadcast with ds_bpermute, so the
+  // dependent chain is offsets -> indices -> rows instead of one index load per batch.
+  constexpr int CH = (GS < 16) ? 2 * GS : GS;
+  for (int c0 = beg; c0 < end; c0 += CH) {
+    const int cnt = min(CH, end - c0);
+    const int mine0 = a.idx[c0 + min(sl, cnt - 1)];
+    const int mine1 = (CH > GS) ? a.idx[c0 + min(GS + sl, cnt - 1)] : 0;
+    for (int n = 0; n < cnt; n += B) {
+      double g[B][VEC];
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+        const int jj = min(n + b, cnt - 1);
+        const int id = __shfl((CH > GS && jj >= GS) ? mine1 : mine0, jj, GS);
+        load_vec<VEC>(gbase + static_cast<size_t>(id) * gstride, g[b]);
+      }
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+        if (n + b < cnt) {
+          double pt = 0.0;
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) pt = fma(g[b][v], f[v], pt);
+          const double s = group_sum<G>(pt);
+          const double w = 1.0 / fmax(s, kEps);
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) acc[v] = fma(g[b][v], w, acc[v]);
+        }
+      }
+    }
+  }
+
+  if (!act) return;
+  if (part >= 0) {  // a piece of a long segment: raw partial sum, finished by seg_combine_kernel
+    store_vec<VEC>(a.parts + sidx * a.bs_parts + static_cast<size_t>(part) * dp + lane_off, acc);
+    return;
+  }
+  double o[VEC];
+  if (a.mode == 0) {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) o[v] = acc[v];
+  } else if (a.mode == 1) {
+    const double d = static_cast<double>(max(end - beg, 1));
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) o[v] = (f[v] * acc[v]) / d;
+  } else {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) o[v] = f[v] * acc[v];
+  }
+  store_vec<VEC>(rowtab_ptr(outt, seg, lane_off), o);
+}
+
+// blocks [0, blocks_a) work on segment set `sa`, the rest on `sb`
+template <int G, int VEC, int B>
+__global__ __launch_bounds__(kBlock) void seg_pass_kernel(SegArgs sa, SegArgs sb,
+                                                          int blocks_a, int dp) {
+  const bool first = static_cast<int>(blockIdx.x) < blocks_a;
+  const int blk = first ? blockIdx.x : blockIdx.x - blocks_a;
+  seg_body<G, VEC, B, 1>(first ? sa : sb, blk * (kBlock / G) + threadIdx.x / G, dp, 1);
+}
+
+template <int G, int VEC, int B, int SW>
+__global__ __launch_bounds__(kBlock) void seg_pass_slots_kernel(SegArgs sa, SegArgs sb, int blocks_a,
+                                                                int dp, int n_slots) {
+  const bool first = static_cast<int>(blockIdx.x) < blocks_a;
+  const int blk = first ? blockIdx.x : blockIdx.x - blocks_a;
+  seg_body<G, VEC, B, SW>(first ? sa : sb, blk * (kBlock / (G * SW)) + threadIdx.x / (G * SW), dp, n_slots);
+}
+
+// Long segments: add the pieces' partial rows in piece order and apply the epilogue.
+struct CombineArgs {
+  const mmsbm::SplitSeg *splits;
+  const double *parts;
+  const int32_t *off;
+  RowTab fixed, out;
+  int32_t n_splits, mode;
+  size_t bs_parts;  // restart slots, as in SegArgs
+};
+
+// One workgroup per split segment: its kBlock/G groups add the pieces j = g, g + NG, ... (four
+// loads in flight), the per-group sums meet in LDS and are added in group order.
+template <int G, int VEC>
+__global__ __launch_bounds__(kBlock) void seg_combine_kernel(CombineArgs ca, CombineArgs cb,
+                                                             int blocks_a, int dp) {
+  extern __shared__ double lds[];  // [kBlock / G][dp]
+  constexpr int NG = kBlock / G;
+  const bool first = static_cast<int>(blockIdx.x) < blocks_a;
+  const CombineArgs &a = first ? ca : cb;
+  const int w = first ? blockIdx.x : blockIdx.x - blocks_a;
+  const int grp = threadIdx.x / G, gl = threadIdx.x % G;
+  const bool act = gl * VEC < dp;
+  const int lane_off = act ? gl * VEC : 0;
+  const mmsbm::SplitSeg sp = a.splits[w];
+  const double *parts = a.parts + blockIdx.y * a.bs_parts;
+  double acc[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) acc[v] = 0.0;
+  for (int j0 = grp; j0 < sp.n_parts; j0 += NG * 4) {
+    double t[4][VEC];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      load_vec<VEC>(parts + static_cast<size_t>(sp.first_part + min(j0 + i * NG, sp.n_parts - 1)) * dp +
+                        lane_off, t[i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (j0 + i * NG < sp.n_parts) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] += t[i][v];
+      }
+  }
+  if (act) store_vec<VEC>(lds + grp * dp + lane_off, acc);
+  __syncthreads();
+  if (grp != 0 || !act) return;
+  for (int g = 1; g < NG; ++g) {
+    double t[VEC];
+    load_vec<VEC>(lds + g * dp + lane_off, t);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v] += t[v];
+  }
+  double f[VEC], o[VEC];
+  load_vec<VEC>(rowtab_ptr(slot_tab(a.fixed, blockIdx.y), sp.seg, lane_off), f);
+  const double d = static_cast<double>(max(a.off[sp.seg + 1] - a.off[sp.seg], 1));
+#pragma unroll
+  for (int v = 0; v < VEC; ++v)
+    o[v] = a.mode == 0 ? acc[v] : (a.mode == 1 ? (f[v] * acc[v]) / d : f[v] * acc[v]);
+  store_vec<VEC>(rowtab_ptr(slot_tab(a.out, blockIdx.y), sp.seg, lane_off), o);
+}
+
+// Split segments with few pieces (the usual case when MANY segments are cut: dense data): one group
+// of lanes per split segment adds its pieces in piece order, four loads in flight.
+template <int G, int VEC>
+__global__ __launch_bounds__(kBlock) void seg_combine_small_kernel(CombineArgs ca, CombineArgs cb,
+                                                                   int blocks_a, int dp) {
+  const bool first = static_cast<int>(blockIdx.x) < blocks_a;
+  const CombineArgs &a = first ? ca : cb;
+  const int blk = first ? blockIdx.x : blockIdx.x - blocks_a;
+  const int w = blk * (kBlock / G) + threadIdx.x / G, gl = threadIdx.x % G;
+  if (w >= a.n_splits || gl * VEC >= dp) return;
+  const int lane_off = gl * VEC;
+  const mmsbm::SplitSeg sp = a.splits[w];
+  const double *parts = a.parts + blockIdx.y * a.bs_parts + static_cast<size_t>(sp.first_part) * dp + lane_off;
+  double acc[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) acc[v] = 0.0;
+  for (int j0 = 0; j0 < sp.n_parts; j0 += 4) {
+    double t[4][VEC];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) load_vec<VEC>(parts + static_cast<size_t>(min(j0 + i, sp.n_parts - 1)) * dp, t[i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (j0 + i < sp.n_parts) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] += t[i][v];
+      }
+  }
+  double f[VEC], o[VEC];
+  load_vec<VEC>(rowtab_ptr(slot_tab(a.fixed, blockIdx.y), sp.seg, lane_off), f);
+  const double d = static_cast<double>(max(a.off[sp.seg + 1] - a.off[sp.seg], 1));
+#pragma unroll
+  for (int v = 0; v < VEC; ++v)
+    o[v] = a.mode == 0 ? acc[v] : (a.mode == 1 ? (f[v] * acc[v]) / d : f[v] * acc[v]);
+  store_vec<VEC>(rowtab_ptr(slot_tab(a.out, blockIdx.y), sp.seg, lane_off), o);
+}
+
+
+}  // namespace

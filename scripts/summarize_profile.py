@@ -56,9 +56,10 @@ with open(os.path.join(dst, f"{tag}_pmc.csv"), "w", newline="") as fh:
 
 def kernel_source_sha16():  # the same identity bench.py computes: a profile is only valid for these sources
     h = hashlib.sha256()
-    for rel in ("mmsbm_amd/csrc/mmsbm_hip.hip", "mmsbm_amd/csrc/layout.hpp"):
-        with open(os.path.join(root, rel), "rb") as fh:
-            h.update(fh.read())
+    csrc = os.path.join(root, "mmsbm_amd", "csrc")
+    for name in sorted(f for f in os.listdir(csrc) if f.endswith((".hip", ".hpp"))):
+        with open(os.path.join(csrc, name), "rb") as fh:
+            h.update(name.encode() + b"\0" + fh.read())
     return h.hexdigest()[:16]
 
 summary_path = os.path.join(dst, "pmc_summary.json")
