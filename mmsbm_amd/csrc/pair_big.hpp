@@ -367,9 +367,10 @@ __global__ __launch_bounds__(NT, NT == 512 ? MMSBM_MFMA_WPE : 2) void pair_mfma_
 // (beyond): at K = L = 100 the pair stage took 61 % of the iteration, at K = L = 200 75 %.  Blocked, T and
 // S no longer share a workgroup (T sums over ALL of Din for a block of outputs; S keeps a Din x Dout block
 // in the accumulators over ALL pairs of a chunk), so the T+S stage is two launches:
-//   mfma_rows_kernel<GATHER>  workgroup = (64-pair unit, block of <= 64 output columns): loops over the
-//       64-blocks of Din -- X block transposed + tile block in LDS, the next blocks in flight -- with the
-//       output tiles in the accumulators throughout (wave = 16 rows x 2 column tiles);
+//   mfma_rows_kernel<GATHER>  workgroup = (two 64-pair units, block of <= 64 output columns): loops over the
+//       64-blocks of Din -- the tile block once, then each unit's X block transposed, in LDS; the next step's
+//       blocks in flight -- with the units' output tiles in the accumulators throughout (wave = 16 rows x 2
+//       column tiles per unit);
 //   mfma_slab_kernel          workgroup = (chunk, Din block, Dout block): loops over the chunk's units --
 //       X block transposed + E block in LDS -- with its <= 16 slab tiles dealt to the 8 waves.
 // Operand layouts, clamping of partial tiles and association order as in pair_mfma_kernel.  Each table is
