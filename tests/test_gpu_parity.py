@@ -1054,6 +1054,37 @@ def test_pair_stage_on_the_matrix_cores_blocked(hip, k, l, mode):
                 assert rel_err(a, b) < 1e-12, (swap, s_, nm)
 
 
+def test_big_tiles_on_small_and_degenerate_data(hip):
+    """The matrix-core pair stage on inputs far from its design point: a handful of triples, one rating
+    value, ratings without rows, one item, one user, absent ids, more groups than rows -- random shapes
+    with K, L in 33..140 (one-block and blocked kernels), numerators after one step and parameters after
+    two iterations against the oracle."""
+    rng = np.random.default_rng(77)
+    cases = [(1, 1, 1, 1, 50, 50), (3, 2, 1, 4, 64, 33), (40, 1, 30, 2, 40, 60), (40, 30, 1, 2, 100, 70),
+             (200, 50, 20, 1, 52, 52), (300, 40, 25, 9, 36, 90)]
+    cases += [(int(rng.integers(5, 400)), int(rng.integers(2, 60)), int(rng.integers(2, 40)), int(rng.integers(1, 8)),
+               int(rng.integers(33, 141)), int(rng.integers(33, 141))) for _ in range(8)]
+    for n, n_u, n_i, n_r, k, l in cases:
+        data = np.stack([rng.integers(0, max(1, n_u - 1), n), rng.integers(0, max(1, n_i - 1), n),   # the last ids never occur
+                         rng.integers(0, n_r, n)], axis=1).astype(np.int64)
+        if n_r > 2:
+            data[data[:, 2] == 1, 2] = 0                                                             # a rating value without rows
+        d_u, d_i = orc.degrees(data, n_u, n_i)
+        theta, eta, pr = orc.init_params(n + k, n_u, n_i, n_r, k, l, d_u, d_i)
+        want = orc.update_coefficients(data, theta, eta, pr)
+        t, e, p = theta, eta, pr
+        for _ in range(2):
+            t, e, p = orc.em_step(data, t, e, p, d_u, d_i)
+        with make_ctx(hip, data, theta, eta, pr) as em:
+            assert em.get_option("mfma") in (1.0, 2.0), (k, l)
+            for got, w, nm in zip(em.update_coefficients(), want, ("n_theta", "n_eta", "n_pr")):
+                assert rel_err(got, w) < TOL_STEP, (n, n_u, n_i, n_r, k, l, nm)
+            em.iterate(2)
+            for got, w, nm in zip(em.get_params(), (t, e, p), ("theta", "eta", "pr")):
+                assert rel_err(got, w) < 1e-11, (n, n_u, n_i, n_r, k, l, nm)
+            assert np.allclose(em.prod_dist(data[:20]), orc.prod_dist(data[:20], t, e, p), rtol=1e-11, atol=1e-300)
+
+
 @pytest.mark.parametrize("n_r,k,l", [(1, 3, 4), (33, 5, 6), (100, 4, 3), (7, 20, 20)])
 def test_many_or_single_rating_values(hip, n_r, k, l):
     """R = 1 (p stays 1 everywhere) up to R = 100 (many tiny rating-homogeneous units, several
