@@ -240,9 +240,17 @@ class MMSBM:
         running sum over restarts, argmax and the indicators of src/mmsbm.py:488-528 -- is
         evaluated on the device; per restart only six sums come back."""
         self._check_is_fitted()
-        import pandas as pd
-
         test = self.data_handler.transform(data, self.logger)
+        matrix, raw, per_run = self._predict_runs(test)
+        self.run_stats = per_run
+        self._keep_best_run(int(np.argmax([st["accuracy"] for st in per_run])))  # first best restart, src/mmsbm.py:474-478
+        self.prediction_matrix = matrix
+        self._scored = (matrix, raw)
+        return self.prediction_matrix
+
+    def _predict_runs(self, test):
+        """The restarts held by THIS model (all of them, or this rank's share) on encoded test triples:
+        (mean distribution over them, its six sums, the five scores of every restart)."""
         self.test = test
         dev = self._device_list()[0]
         ctx = self._ctx(dev)
@@ -260,18 +268,19 @@ class MMSBM:
                 ctx.set_params(a["theta"], a["eta"], a["pr"])
             per_run.append(ctx.predict_add())
         matrix, raw = ctx.predict_finish()
-        self.run_stats = [ctx.final_stats(st) for st in per_run]
-        likelihoods = np.array([a["likelihood"] for a in self.results])
-        best = int(np.argmax([st["accuracy"] for st in self.run_stats]))  # first best restart, src/mmsbm.py:474-478
-        enc = self.data_handler
-        res = self.results[best]
-        self.theta = pd.DataFrame(res["theta"], index=enc.user_labels())
-        self.eta = pd.DataFrame(res["eta"], index=enc.item_labels())
-        self.pr = {lab: pd.DataFrame(res["pr"][:, :, j]) for j, lab in enumerate(enc.rating_labels())}
-        self.likelihood = likelihoods[best]
-        self.prediction_matrix = matrix
-        self._scored = (matrix, raw)
-        return self.prediction_matrix
+        return matrix, raw, [ctx.final_stats(st) for st in per_run]
+
+    def _keep_best_run(self, best, res=None):
+        """theta / eta / pr / likelihood of restart ``best`` become the model's stored objects
+        (src/mmsbm.py:303-311); ``res``: its result dict when it is not in self.results."""
+        import pandas as pd
+        enc = self.data_handler  # (None after fit_encoded: rows and ratings keep their integer ids)
+        res = self.results[best] if res is None else res
+        self.theta = pd.DataFrame(res["theta"], index=enc.user_labels() if enc else None)
+        self.eta = pd.DataFrame(res["eta"], index=enc.item_labels() if enc else None)
+        labels = enc.rating_labels() if enc else range(res["pr"].shape[2])
+        self.pr = {lab: pd.DataFrame(res["pr"][:, :, j]) for j, lab in enumerate(labels)}
+        self.likelihood = np.float64(res["likelihood"])
 
     def choose_best_run(self, rats):
         """Index of the first prediction matrix with the highest accuracy (src/mmsbm.py:474-478)."""

@@ -45,6 +45,13 @@ ONE_RANK_NCCL = textwrap.dedent("""
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     assert t.tolist() == [0.0, 1.0, 2.0, 3.0]
     restarts.barrier(device)
+    # predict over the ranks' restarts (one rank here: the reduction is the identity), on the device
+    from oracle import mmsbm_oracle as orc
+    test = train[::2]
+    matrix = restarts.predict_distributed(model, test, device=device)
+    want = np.mean([orc.prod_dist(test, g[f"theta_{{s}}"], g[f"eta_{{s}}"], g[f"pr_{{s}}"]) for s in range(3)], axis=0)
+    assert np.allclose(matrix, want, rtol=1e-9, atol=1e-300), np.max(np.abs(matrix - want))
+    assert len(model.run_stats) == 3 and model.theta.shape == g["theta_0"].shape
     model._release()
     dist.destroy_process_group()
     print("nccl one rank ok")

@@ -115,6 +115,61 @@ WORKER = textwrap.dedent("""
 """)
 
 
+PREDICT_WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+    import numpy as np
+    import torch.distributed as dist
+    import fake_device
+    from mmsbm_amd import restarts, mmsbm as host
+    from conftest import load_golden
+
+    host.HipEM = fake_device.FakeHipEM                  # the oracle behind the device interface
+    host.load_backend = lambda name: (None, None, None, "hip")
+    restarts.check_single_hip_runtime = lambda: None
+    rank, world, local, device = restarts.init_from_env("gloo")
+    g = load_golden("g2_c1_sampling3")
+    train, test = g["train"], g["train"][::3]
+    model = host.MMSBM(2, 2, iterations=10, sampling=3, seed=1)
+    best, best_lik, liks = restarts.fit_distributed(model, train, gather=False, device=device)
+    assert [r for r in model._restart_ids] == ([0, 2] if rank == 0 else [1])
+    assert len(model.results) == len(model._restart_ids)          # nobody holds the other rank's parameters
+    matrix = restarts.predict_distributed(model, test, device=device)
+    # the same three restarts in ONE process
+    solo = host.MMSBM(2, 2, iterations=10, sampling=3, seed=1)
+    solo.fit_encoded(train)
+    want, _, per_run = solo._predict_runs(test)
+    assert np.allclose(matrix, want, rtol=1e-14, atol=0), np.max(np.abs(matrix - want))
+    assert model.run_stats == per_run
+    b = int(np.argmax([st["accuracy"] for st in per_run]))
+    assert np.array_equal(model.theta.values, solo.results[b]["theta"])    # broadcast from its owner
+    assert model.likelihood == solo.results[b]["likelihood"]
+    st = model.score(silent=True)["stats"]
+    assert st["accuracy"] == solo._compute_stats(want)["accuracy"]
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank", rank, "ok")
+""")
+
+
+def test_two_rank_gloo_predict_without_gathering_parameters(tmp_path):
+    """restarts.predict_distributed: each rank scores ITS restarts, one all-reduce(SUM) of the (M, R) matrix;
+    equals the one-process predict of the same restarts; the best-accuracy restart's objects are broadcast."""
+    script = tmp_path / "predict_worker.py"
+    script.write_text(PREDICT_WORKER.format(root=ROOT))
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, out[-3000:]
+        assert f"rank {rank} ok" in out
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
