@@ -188,7 +188,8 @@ int mmsbm_hip_time_stage(mmsbm_hip_ctx *ctx, int stage, int reps, float *mean_us
  * unless a side has fewer than 16 groups; environment MMSBM_HIP_NO_MFMA=1 keeps it off), "mfma_threads" 256/512
  * (workgroup size of its T+S launch), "predict_fast" 0/1 (prod_dist / predict through the table of
  * p_r eta_i over every (item, rating) combination -- the default where the rows are not far fewer than
- * the items -- or always through the one-thread-per-row kernels). */
+ * the items -- or always through the one-thread-per-row kernels), "seg_batch" 4/8 (row gathers a group of
+ * lanes of the triple passes keeps in flight; create() picks 8 for small problems). */
 int mmsbm_hip_set_option(mmsbm_hip_ctx *ctx, const char *name, double value);
 /* Reads a knob back; also the read-only "ranges_pairs" / "ranges_users" (ranges the XCD-local work
  * list of that pass uses, 1 = off), "items_pairs" / "items_users" (work items, 0 = segments as

@@ -158,6 +158,7 @@ struct mmsbm_hip_ctx {
   int grid_n_chunks = 0, mv_chunk_pairs = mmsbm::kMvChunkPairs;
   DevBuf<double> btab;                // [I * R][kp], of the slot being scored
   bool predict_fast = true;
+  int seg_batch = 4;  // row gathers a group of seg_pass keeps in flight (4, or 8)
   bool mfma = false;    // both pair-stage launches run pair_mfma_kernel (tiles beyond the scalar cache, K, L <= 64)
   size_t lds_mt = 0, lds_ma = 0;
   int mfma_threads = kPairBlockMax;  // T+S launch: 512 (eight waves) or 256

@@ -180,6 +180,10 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
     c->wide = c->lds_t > kLdsMax || c->lds_a > kLdsMax || c->pb_nacc > 4 ||
               std::getenv("MMSBM_HIP_FORCE_WIDE") != nullptr;
     c->split_rows = true;
+    // small problems leave most CUs a couple of workgroups: the triple passes are then bound by the rounds of
+    // dependent gathers per segment, and eight rows in flight per group beat four (C1 16.8 -> 16.1 us, C2 29.7 ->
+    // 29.1 us per iteration); at C3 four are better (95.3 vs 97.3 us)
+    c->seg_batch = n_obs <= 300000 ? 8 : 4;
     if (n_ratings > 65535)
       throw ApiError(MMSBM_E_UNSUPPORTED, "more than 65535 distinct ratings are not supported");
 
@@ -1029,6 +1033,9 @@ int mmsbm_hip_set_option(mmsbm_hip_ctx *ctx, const char *name, double value) {
     } else if (key == "quad") {  // 0: the A launch through pair_block like every other shape
       ctx->quad_a = value != 0.0 && !ctx->wide && ctx->kp * ctx->lp > 1024 && ctx->tl_a &&
                     ctx->pb_threads_a == kPairBlockMax && ctx->lds_qa <= kLdsMax - 2048 && ctx->lp <= 64;
+    } else if (key == "seg_batch") {
+      if (value != 4 && value != 8) throw std::invalid_argument("seg_batch: 4 or 8");
+      ctx->seg_batch = static_cast<int>(value);
     } else if (key == "predict_fast") {  // 0: prod_dist / predict through the per-row kernels (R K L multiply-adds per row)
       ctx->predict_fast = value != 0.0;
     } else if (key == "mfma_threads") {
@@ -1055,6 +1062,7 @@ int mmsbm_hip_get_option(const mmsbm_hip_ctx *ctx, const char *name, double *val
     else if (key == "mfma") *value = ctx->mfma ? 1.0 : (ctx->mfma_big ? 2.0 : 0.0);
     else if (key == "mfma_threads") *value = ctx->mfma_threads;
     else if (key == "predict_fast") *value = ctx->predict_fast;
+    else if (key == "seg_batch") *value = ctx->seg_batch;
     else if (key == "wide") *value = ctx->wide;
     else if (key == "slot_waves") *value = ctx->slot_waves;
     else if (key == "lik_fast") *value = ctx->lik_fast;

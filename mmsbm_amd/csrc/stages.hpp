@@ -163,10 +163,17 @@ void stage_seg(mmsbm_hip_ctx *c, bool commit, bool with_pairs, bool with_users, 
   const int bp = (with_pairs && sw == 1) ? (sp.nseg + per - 1) / per : 0;
   const int bu = (with_users && sw == 1) ? (su.nseg + per - 1) / per : 0;
   if (bp + bu > 0) {  // one slot per workgroup (blockIdx.y = slot)
+    if (c->seg_batch == 8) {  // (tuning: eight row gathers in flight per group)
+#define CALL(G, V) \
+  seg_pass_kernel<G, V, 8><<<slot_grid(c, bp + bu), kBlock, 0, st>>>(sp, su, bp, c->kp)
+      DISPATCH_GV(c->code_k, CALL);
+#undef CALL
+    } else {
 #define CALL(G, V) \
   seg_pass_kernel<G, V, 4><<<slot_grid(c, bp + bu), kBlock, 0, st>>>(sp, su, bp, c->kp)
-    DISPATCH_GV(c->code_k, CALL);
+      DISPATCH_GV(c->code_k, CALL);
 #undef CALL
+    }
   }
   // long segments were processed in pieces: add the pieces up (fixed order) and finish them
   // (splits with few pieces come first in the lists: one group of lanes each; the rest: a workgroup each)
