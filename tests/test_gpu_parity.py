@@ -1054,6 +1054,31 @@ def test_pair_stage_on_the_matrix_cores_blocked(hip, k, l, mode):
                 assert rel_err(a, b) < 1e-12, (swap, s_, nm)
 
 
+@pytest.mark.parametrize("k,l,family", [(32, 32, 0.0), (31, 32, 0.0), (31, 33, 1.0), (32, 36, 1.0), (36, 29, 1.0), (64, 64, 1.0), (61, 64, 1.0),
+                                        (64, 65, 2.0), (68, 16, 2.0), (13, 100, 2.0), (12, 100, 0.0), (9, 130, 0.0)])
+def test_pair_stage_families_at_their_borders(hip, k, l, family):
+    """Which kernels take the pair stage is decided from (K, L): vector ALUs while the padded tile is at most
+    1,024 entries or a side has fewer than 16 (padded) groups, the one-block matrix-core kernel up to 64 per
+    side, the blocked kernels beyond.  Shapes on both sides of every border, against the oracle."""
+    rng = np.random.default_rng(k * 131 + l)
+    n_u, n_i, n_r, n = 90, 70, 3, 1500
+    data = np.stack([rng.integers(0, n_u, n), rng.integers(0, n_i, n), rng.integers(0, n_r, n)], axis=1).astype(np.int64)
+    d_u, d_i = orc.degrees(data, n_u, n_i)
+    theta, eta, pr = orc.init_params(k + l, n_u, n_i, n_r, k, l, d_u, d_i)
+    want = orc.update_coefficients(data, theta, eta, pr)
+    t, e, p = theta, eta, pr
+    for _ in range(2):
+        t, e, p = orc.em_step(data, t, e, p, d_u, d_i)
+    with make_ctx(hip, data, theta, eta, pr, swap_sides=0) as em:
+        assert em.get_option("mfma") == family, (k, l, em.get_option("mfma"))
+        for got, w, nm in zip(em.update_coefficients(), want, ("n_theta", "n_eta", "n_pr")):
+            assert rel_err(got, w) < TOL_STEP, nm
+        em.iterate(2)
+        for got, w, nm in zip(em.get_params(), (t, e, p), ("theta", "eta", "pr")):
+            assert rel_err(got, w) < 1e-11, nm
+        assert em.likelihood() == pytest.approx(float(orc.compute_likelihood(data, t, e, p)), rel=1e-11)
+
+
 def test_big_tiles_on_small_and_degenerate_data(hip):
     """The matrix-core pair stage on inputs far from its design point: a handful of triples, one rating
     value, ratings without rows, one item, one user, absent ids, more groups than rows -- random shapes
