@@ -31,6 +31,49 @@ def _as_str(col):
     return np.array([str(v) for v in col], dtype=object).astype(str) if len(col) else np.array([], dtype=str)
 
 
+_POW10 = 10 ** np.arange(1, 20, dtype=np.uint64)   # 10 .. 10^19
+
+
+def _decimal_string_order(values):
+    """Permutation that puts non-negative integers in the lexicographic order of their decimal strings
+    ('10' < '2', '1' < '10') without making a string: compare the digits left-aligned, i.e. the value
+    scaled to the longest length, the shorter string first among equals."""
+    v = values.astype(np.uint64)
+    digits = np.searchsorted(_POW10, v, side="right") + 1
+    scale = np.concatenate([np.ones(1, dtype=np.uint64), _POW10])[int(digits.max()) - digits] if len(v) else v
+    return np.lexsort((digits, v * scale))
+
+
+def _factorize_ints(col, out=None):
+    """_factorize_as_str for a column of non-negative integers (what ids usually are), all in typed numpy
+    passes: a presence table instead of a hash when the ids are reasonably dense, the string order computed
+    numerically, strings made once per distinct value by numpy.  None if the column does not qualify."""
+    lo, hi = int(col.min()), int(col.max())
+    if lo < 0 or hi >= 2 ** 62:  # (negative numbers sort as strings with their sign; huge ones would overflow int64 below)
+        return None
+    span = hi - lo + 1
+    codes = None
+    if span <= max(8 * len(col), 1 << 22):
+        shifted = col.astype(np.int64) - lo if lo else col.astype(np.int64, copy=False)
+        present = np.zeros(span, dtype=bool)
+        present[shifted] = True
+        uniq = np.flatnonzero(present) + lo
+    else:  # sparse ids: hash-factorise
+        import pandas as pd
+        codes, uniq = pd.factorize(col)
+        uniq = np.asarray(uniq)
+    order = _decimal_string_order(uniq)
+    rank = np.empty(len(uniq), dtype=np.int32)
+    rank[order] = np.arange(len(uniq), dtype=np.int32)
+    if codes is None:
+        lookup = np.zeros(span, dtype=np.int32)
+        lookup[uniq - lo] = rank
+        ids = np.take(lookup, shifted, out=out)
+    else:
+        ids = np.take(rank, codes, out=out)
+    return (out if out is not None else ids), uniq[order].astype(str)
+
+
 def _factorize_as_str(col, out=None):
     """(ids, labels): labels = sorted distinct str(value); ids[n] = rank of str(col[n]).
 
@@ -42,6 +85,10 @@ def _factorize_as_str(col, out=None):
     if len(col) == 0:
         return np.zeros(0, dtype=np.int32), np.array([], dtype=str)
     col = np.asarray(col)
+    if col.dtype.kind in "iu":
+        fast = _factorize_ints(col, out)
+        if fast is not None:
+            return fast
     if col.dtype.kind in "US":  # fixed-width numpy strings hash slowly: go through object
         col = col.astype(object)
     codes, uniq = pd.factorize(col, use_na_sentinel=True)

@@ -83,6 +83,43 @@ def test_synthetic_generator_and_byte_accounting():
     assert rd == 332_016_000 and wr == 8 * (u * k + i * l + k * l * r)
 
 
+def test_encoder_integer_columns_take_the_numeric_path_with_the_same_result():
+    """Integer id columns (the usual case) are encoded without a string per row or per distinct value:
+    presence table or hash, lexicographic order of the decimal strings computed numerically.  Same ids and
+    labels as the general path (str(value), sorted), which the reference's DataHandler golden pins."""
+    import pandas as pd
+    from mmsbm_amd import encode
+
+    def general(col):
+        codes, uniq = pd.factorize(np.asarray(col), use_na_sentinel=True)
+        labels, inv = np.unique(np.array([str(v) for v in uniq.tolist()], dtype=object).astype(str), return_inverse=True)
+        return inv.astype(np.int32)[codes], labels
+
+    rng = np.random.default_rng(3)
+    cols = [rng.integers(0, 1000, 5000), rng.integers(0, 10 ** 18, 3000), np.array([0, 0, 10, 1, 100, 2, 20, 19, 9, 99, 1000000]),
+            rng.integers(5, 50, 10).astype(np.int32), rng.integers(0, 2 ** 40, 4000).astype(np.uint64), np.array([7]),
+            rng.integers(10 ** 6, 10 ** 6 + 30, 100), np.array([5, 3, 5, 12], dtype=np.int8),
+            np.array([-1, 5, 3]),                                              # negative: general path
+            np.array([2 ** 63 + 5, 3, 2 ** 63 + 5], dtype=np.uint64)]           # beyond int64: general path
+    for col in cols:
+        ids, labels = encode._factorize_as_str(col)
+        want_ids, want_labels = general(col)
+        assert np.array_equal(ids, want_ids) and labels.tolist() == want_labels.tolist(), col[:5]
+        out = np.empty(len(col), dtype=np.int32)
+        encode._factorize_as_str(col, out=out)
+        assert np.array_equal(out, want_ids)
+    vals = np.array([0, 1, 2, 9, 10, 11, 19, 20, 99, 100, 101, 1000])
+    assert [str(v) for v in vals[encode._decimal_string_order(vals)]] == sorted(str(v) for v in vals)
+    # a frame with integer ids and a test frame holding unseen ones
+    df = pd.DataFrame({"u": [10, 2, 33, 2, 10], "i": [7, 7, 100, 8, 8], "r": [5, 1, 3, 1, 5]})
+    enc = encode.Encoder()
+    got = enc.fit_transform(df)
+    assert enc.user_labels() == ["10", "2", "33"] and enc.item_labels() == ["100", "7", "8"] and enc.rating_labels() == ["1", "3", "5"]
+    assert got.tolist() == [[0, 1, 2], [1, 1, 0], [2, 0, 1], [1, 2, 0], [0, 2, 2]]
+    test = enc.transform(pd.DataFrame({"u": [2, 4, 33], "i": [8, 8, 7], "r": [3, 3, 2]}))
+    assert test.tolist() == [[1, 2, 1]]                                       # user 4 and rating 2 were never seen
+
+
 WORKER = textwrap.dedent("""
     import os, sys
     sys.path.insert(0, {root!r})
