@@ -44,7 +44,7 @@ def _decimal_string_order(values):
     return np.lexsort((digits, v * scale))
 
 
-def _factorize_ints(col, out=None):
+def _factorize_ints(col, out=None, keep_map=None):
     """_factorize_as_str for a column of non-negative integers (what ids usually are), all in typed numpy
     passes: a presence table instead of a hash when the ids are reasonably dense, the string order computed
     numerically, strings made once per distinct value by numpy.  None if the column does not qualify."""
@@ -71,10 +71,16 @@ def _factorize_ints(col, out=None):
         ids = np.take(lookup, shifted, out=out)
     else:
         ids = np.take(rank, codes, out=out)
+    if keep_map is not None:  # value -> id without strings, for Encoder.transform
+        keep_map["values"], keep_map["ids"], keep_map["lo"] = uniq, rank, lo
+        if codes is None:  # dense ids: a table answers a test column in one gather
+            table = np.full(span, -1, dtype=np.int32)
+            table[uniq - lo] = rank
+            keep_map["table"] = table
     return (out if out is not None else ids), uniq[order].astype(str)
 
 
-def _factorize_as_str(col, out=None):
+def _factorize_as_str(col, out=None, keep_map=None):
     """(ids, labels): labels = sorted distinct str(value); ids[n] = rank of str(col[n]).
 
     Hash-factorises the raw values first (pandas, O(N)) and stringifies only the distinct
@@ -86,7 +92,7 @@ def _factorize_as_str(col, out=None):
         return np.zeros(0, dtype=np.int32), np.array([], dtype=str)
     col = np.asarray(col)
     if col.dtype.kind in "iu":
-        fast = _factorize_ints(col, out)
+        fast = _factorize_ints(col, out, keep_map)
         if fast is not None:
             return fast
     if col.dtype.kind in "US":  # fixed-width numpy strings hash slowly: go through object
@@ -108,6 +114,7 @@ class Encoder:
 
     def __init__(self):
         self.labels = None  # three sorted arrays of str: id -> original label
+        self._int_maps = [None, None, None]  # integer training columns: ascending values and their ids
 
     def fit_transform(self, data):
         """(N,3) int32 ids [user, item, rating], column-major so that each column is contiguous
@@ -115,8 +122,10 @@ class Encoder:
         cols, _ = _columns(data)
         out = np.empty((len(cols[0]), 3), dtype=np.int32, order="F")
 
+        maps = [{}, {}, {}]
+
         def one(j):
-            return _factorize_as_str(cols[j], out=out[:, j] if len(cols[j]) else None)[1]
+            return _factorize_as_str(cols[j], out=out[:, j] if len(cols[j]) else None, keep_map=maps[j])[1]
 
         if len(cols[0]) >= 1_000_000:  # the hash passes release the GIL: one thread per column
             from concurrent.futures import ThreadPoolExecutor
@@ -124,6 +133,7 @@ class Encoder:
                 self.labels = list(pool.map(one, range(3)))
         else:
             self.labels = [one(j) for j in range(3)]
+        self._int_maps = [m if m else None for m in maps]
         return out
 
     def transform(self, data, logger=None):
@@ -133,7 +143,28 @@ class Encoder:
         keep = np.ones(len(cols[0]), dtype=bool)
         ids = []
         log = logger or logging.getLogger("MMSBM")
-        for name, col, lab in zip(("users", "items", "ratings"), cols, self.labels):
+        for j, (name, col, lab) in enumerate(zip(("users", "items", "ratings"), cols, self.labels)):
+            col = np.asarray(col)
+            imap = self._int_maps[j]
+            if imap is not None and col.dtype.kind in "iu" and len(col) and int(col.min()) >= 0 and int(col.max()) < 2 ** 62:
+                # integers against an integer training column: binary search on the values, no strings
+                c64 = col.astype(np.int64, copy=False)
+                if "table" in imap:
+                    rel = c64 - imap["lo"]
+                    inside = (rel >= 0) & (rel < len(imap["table"]))
+                    found = np.where(inside, imap["table"][np.where(inside, rel, 0)], -1)
+                else:  # sparse training ids: hash lookup
+                    import pandas as pd
+                    at = pd.Index(imap["values"]).get_indexer(c64)
+                    found = np.where(at >= 0, imap["ids"][np.maximum(at, 0)], -1)
+                hit = found >= 0
+                unseen = np.unique(c64[keep & ~hit])
+                if len(unseen):
+                    log.warning(f"The {name} {', '.join(sorted(str(v) for v in unseen.tolist()))} are in the test set "
+                                f"but weren't in the train set so I'll remove them.")
+                keep &= hit
+                ids.append(found.astype(np.int32, copy=False))
+                continue
             codes, test_labels = _factorize_as_str(col)          # this frame's own dictionary
             pos_l = np.searchsorted(lab, test_labels)
             pos_l = np.minimum(pos_l, max(len(lab) - 1, 0))

@@ -118,6 +118,23 @@ def test_encoder_integer_columns_take_the_numeric_path_with_the_same_result():
     assert got.tolist() == [[0, 1, 2], [1, 1, 0], [2, 0, 1], [1, 2, 0], [0, 2, 2]]
     test = enc.transform(pd.DataFrame({"u": [2, 4, 33], "i": [8, 8, 7], "r": [3, 3, 2]}))
     assert test.tolist() == [[1, 2, 1]]                                       # user 4 and rating 2 were never seen
+    # transform: table lookup (dense ids) / hash lookup (sparse ids) against the general string path
+    import logging
+    logging.disable(logging.WARNING)
+    try:
+        for trial in range(12):
+            n, sparse = int(rng.integers(5, 300)), trial % 3 == 0
+            scale = 10 ** 9 if sparse else 1
+            tr = pd.DataFrame({"u": rng.integers(0, 50, n) * scale, "i": rng.integers(0, 30, n) * scale, "r": rng.integers(1, 6, n)})
+            te = pd.DataFrame({"u": rng.integers(0, 60, 150) * scale, "i": rng.integers(0, 35, 150) * scale, "r": rng.integers(0, 7, 150)})
+            a, b = encode.Encoder(), encode.Encoder()
+            a.fit_transform(tr); b.fit_transform(tr)
+            assert all(m is not None for m in a._int_maps) and ("table" in a._int_maps[0]) == (not sparse or n < 10)
+            b._int_maps = [None] * 3                                               # force the string path
+            assert np.array_equal(a.transform(te), b.transform(te)), trial
+            assert np.array_equal(a.transform(te.astype(str)), b.transform(te))    # strings against integer training ids
+    finally:
+        logging.disable(logging.NOTSET)
 
 
 WORKER = textwrap.dedent("""
