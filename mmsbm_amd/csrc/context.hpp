@@ -221,21 +221,28 @@ struct mmsbm_hip_ctx {
 namespace {
 
 
-struct LaunchScope {  // optional event pair around one launch
+// Optional event pair of one stage (mmsbm_hip_profile_iterations).  Normally the events are recorded on the
+// stream in front of and behind the stage's launches, which adds the launch gaps to what they measure
+// (seg_pass at C3: 64.8 us against 62.2 in the kernel trace).  A stage that is ONE kernel can hand the pair
+// to the launch itself instead (hipExtLaunchKernelGGL): the events then carry the kernel's own begin and end
+// time stamps -- what rocprofv3 reports.
+struct LaunchScope {
   mmsbm_hip_ctx *c;
   int id;
+  bool kernel_events;
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  LaunchScope(mmsbm_hip_ctx *ctx, int kid) : c(ctx), id(kid) {
+  LaunchScope(mmsbm_hip_ctx *ctx, int kid, bool one_kernel = false) : c(ctx), id(kid), kernel_events(one_kernel) {
     if (c->profiling) {
       HIP_CHECK(hipEventCreate(&e0));
       HIP_CHECK(hipEventCreate(&e1));
-      HIP_CHECK(hipEventRecord(e0, c->stream));
+      if (!kernel_events) HIP_CHECK(hipEventRecord(e0, c->stream));
     }
   }
+  bool ext() const { return c->profiling && kernel_events; }  // the launch takes e0 / e1
   void done() {
     HIP_CHECK(hipGetLastError());
     if (c->profiling) {
-      HIP_CHECK(hipEventRecord(e1, c->stream));
+      if (!kernel_events) HIP_CHECK(hipEventRecord(e1, c->stream));
       c->prof_events.push_back({id, {e0, e1}});
     }
   }

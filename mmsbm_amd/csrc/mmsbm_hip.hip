@@ -28,6 +28,7 @@
 // rating tiles.
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <chrono>

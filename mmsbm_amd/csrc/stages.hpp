@@ -127,7 +127,6 @@ EtaPArgs eta_p_args(const mmsbm_hip_ctx *c, bool commit, int cols_per_block) {
 // The two triple passes.  with_pairs / with_users select the segment sets of this launch (both: one
 // launch, the pair segments' workgroups first); `st` is the stream it goes to.
 void stage_seg(mmsbm_hip_ctx *c, bool commit, bool with_pairs, bool with_users, hipStream_t st) {
-  LaunchScope ls(c, K_SEG);
   const SegArgs sp = seg_pairs_args(c), su = seg_users_args(c, commit, c->n_users);
   const int per = kBlock / group_lanes(c->code_k);
   // several restart slots: a super-group of SW x G lanes per segment (seg_pass_slots_kernel)
@@ -136,6 +135,10 @@ void stage_seg(mmsbm_hip_ctx *c, bool commit, bool with_pairs, bool with_users, 
     const int room = 64 / group_lanes(c->code_k);
     while (sw * 2 <= room && sw < c->launch_slots) sw *= 2;
   }
+  // (the stage is one kernel -- and is timed as that kernel -- when no segment was split and the slots share a launch)
+  const bool one_kernel = sw == 1 && c->lay.pair_work.splits.empty() && c->lay.user_work.splits.empty() && st == c->stream &&
+                          (with_pairs ? sp.nseg : 0) + (with_users ? su.nseg : 0) > 0;
+  LaunchScope ls(c, K_SEG, one_kernel);
   if (sw > 1) {
     const int per_s = kBlock / (group_lanes(c->code_k) * sw);
     const int bps = with_pairs ? (sp.nseg + per_s - 1) / per_s : 0;
@@ -163,17 +166,24 @@ void stage_seg(mmsbm_hip_ctx *c, bool commit, bool with_pairs, bool with_users, 
   const int bp = (with_pairs && sw == 1) ? (sp.nseg + per - 1) / per : 0;
   const int bu = (with_users && sw == 1) ? (su.nseg + per - 1) / per : 0;
   if (bp + bu > 0) {  // one slot per workgroup (blockIdx.y = slot)
-    if (c->seg_batch == 8) {  // (tuning: eight row gathers in flight per group)
-#define CALL(G, V) \
-  seg_pass_kernel<G, V, 8><<<slot_grid(c, bp + bu), kBlock, 0, st>>>(sp, su, bp, c->kp)
+#define SEG_GO(G, V, B)                                                                                      \
+  do {                                                                                                      \
+    if (ls.ext())                                                                                           \
+      hipExtLaunchKernelGGL((seg_pass_kernel<G, V, B>), slot_grid(c, bp + bu), dim3(kBlock), 0, st, ls.e0, ls.e1, 0, \
+                            sp, su, bp, c->kp);                                                             \
+    else                                                                                                    \
+      seg_pass_kernel<G, V, B><<<slot_grid(c, bp + bu), kBlock, 0, st>>>(sp, su, bp, c->kp);                \
+  } while (0)
+    if (c->seg_batch == 8) {  // (eight row gathers in flight per group: small problems)
+#define CALL(G, V) SEG_GO(G, V, 8)
       DISPATCH_GV(c->code_k, CALL);
 #undef CALL
     } else {
-#define CALL(G, V) \
-  seg_pass_kernel<G, V, 4><<<slot_grid(c, bp + bu), kBlock, 0, st>>>(sp, su, bp, c->kp)
+#define CALL(G, V) SEG_GO(G, V, 4)
       DISPATCH_GV(c->code_k, CALL);
 #undef CALL
     }
+#undef SEG_GO
   }
   // long segments were processed in pieces: add the pieces up (fixed order) and finish them
   // (splits with few pieces come first in the lists: one group of lanes each; the rest: a workgroup each)
