@@ -4,6 +4,16 @@
 
 namespace {
 
+// One kernel launch of a stage: with the stage's event pair attached to the launch when the stage is timed as
+// that kernel (LaunchScope::ext), else plain.  KERNEL in parentheses when its template arguments hold commas.
+#define LAUNCH_IN(LS, KERNEL, GRID, BLOCK, LDS, STREAM, ...)                                                  \
+  do {                                                                                                       \
+    if ((LS).ext())                                                                                          \
+      hipExtLaunchKernelGGL(KERNEL, GRID, dim3(BLOCK), static_cast<uint32_t>(LDS), STREAM, (LS).e0, (LS).e1, 0, __VA_ARGS__); \
+    else                                                                                                     \
+      hipLaunchKernelGGL(KERNEL, GRID, dim3(BLOCK), static_cast<uint32_t>(LDS), STREAM, __VA_ARGS__);        \
+  } while (0)
+
 constexpr size_t kLdsMax = 160 * 1024;  // with hipFuncAttributeMaxDynamicSharedMemorySize
 
 // dynamic LDS of pair_block: transposed rows + output rows (shared with the eta rows)
@@ -166,14 +176,7 @@ void stage_seg(mmsbm_hip_ctx *c, bool commit, bool with_pairs, bool with_users, 
   const int bp = (with_pairs && sw == 1) ? (sp.nseg + per - 1) / per : 0;
   const int bu = (with_users && sw == 1) ? (su.nseg + per - 1) / per : 0;
   if (bp + bu > 0) {  // one slot per workgroup (blockIdx.y = slot)
-#define SEG_GO(G, V, B)                                                                                      \
-  do {                                                                                                      \
-    if (ls.ext())                                                                                           \
-      hipExtLaunchKernelGGL((seg_pass_kernel<G, V, B>), slot_grid(c, bp + bu), dim3(kBlock), 0, st, ls.e0, ls.e1, 0, \
-                            sp, su, bp, c->kp);                                                             \
-    else                                                                                                    \
-      seg_pass_kernel<G, V, B><<<slot_grid(c, bp + bu), kBlock, 0, st>>>(sp, su, bp, c->kp);                \
-  } while (0)
+#define SEG_GO(G, V, B) LAUNCH_IN(ls, (seg_pass_kernel<G, V, B>), slot_grid(c, bp + bu), kBlock, 0, st, sp, su, bp, c->kp)
     if (c->seg_batch == 8) {  // (eight row gathers in flight per group: small problems)
 #define CALL(G, V) SEG_GO(G, V, 8)
       DISPATCH_GV(c->code_k, CALL);
@@ -250,27 +253,27 @@ void stage_dense(mmsbm_hip_ctx *c) {  // T = P^T C  and the K x L slabs for p
     return;
   }
   if (c->mfma) {
-    LaunchScope ls(c, K_DENSE);
+    LaunchScope ls(c, K_DENSE, true);
     const int nb = static_cast<int>(c->lay.mv_chunks.size());
     const PairBlockArgs pa = pair_block_t_args(c);
     if (c->mfma_threads == kBlock) {
       allow_big_lds(pair_mfma_kernel<false, true, kBlock>, c->lds_mt);
-      pair_mfma_kernel<false, true, kBlock><<<slot_grid(c, nb), kBlock, c->lds_mt, c->stream>>>(pa, pa.tiles);
+      LAUNCH_IN(ls, (pair_mfma_kernel<false, true, kBlock>), slot_grid(c, nb), kBlock, c->lds_mt, c->stream, pa, pa.tiles);
     } else {
       allow_big_lds(pair_mfma_kernel<false, true, kPairBlockMax>, c->lds_mt);
-      pair_mfma_kernel<false, true, kPairBlockMax><<<slot_grid(c, nb), kPairBlockMax, c->lds_mt, c->stream>>>(pa, pa.tiles);
+      LAUNCH_IN(ls, (pair_mfma_kernel<false, true, kPairBlockMax>), slot_grid(c, nb), kPairBlockMax, c->lds_mt, c->stream, pa, pa.tiles);
     }
     ls.done();
     return;
   }
   {
-    LaunchScope ls(c, K_DENSE);
+    LaunchScope ls(c, K_DENSE, true);
     const int nb = static_cast<int>(c->lay.mv_chunks.size());
     const PairBlockArgs pa = pair_block_t_args(c);
 #define PB_D(N, TL, NT, KT, D)                                                              \
   do {                                                                                      \
     allow_big_lds(pair_block_kernel<false, true, N, TL, NT, KT, D>, c->lds_t);              \
-    pair_block_kernel<false, true, N, TL, NT, KT, D><<<slot_grid(c, nb), NT, c->lds_t, c->stream>>>(pa, pa.tiles); \
+    LAUNCH_IN(ls, (pair_block_kernel<false, true, N, TL, NT, KT, D>), slot_grid(c, nb), NT, c->lds_t, c->stream, pa, pa.tiles); \
   } while (0)
 #define PB_KT(N, TL, NT, KT)                                                                \
   do {                                                                                      \
@@ -302,11 +305,11 @@ void stage_dense(mmsbm_hip_ctx *c) {  // T = P^T C  and the K x L slabs for p
 }
 
 void stage_eta_p(mmsbm_hip_ctx *c, bool commit) {  // eta_new ; p_new, pT_new, raw n_p
-  LaunchScope ls(c, K_ETAP);
+  LaunchScope ls(c, K_ETAP, true);
   const EtaPArgs a = eta_p_args(c, commit, kRedCols);
   const int per = kRedThreads / group_lanes(c->code_l);
   const int nb_i = (c->n_items + per - 1) / per;
-#define CALL(G, V) eta_p_kernel<G, V><<<slot_grid(c, a.nb_p + nb_i), kRedThreads, 0, c->stream>>>(a)
+#define CALL(G, V) LAUNCH_IN(ls, (eta_p_kernel<G, V>), slot_grid(c, a.nb_p + nb_i), kRedThreads, 0, c->stream, a)
   DISPATCH_GV(c->code_l, CALL);
 #undef CALL
   ls.done();
@@ -317,7 +320,7 @@ void stage_eta_p(mmsbm_hip_ctx *c, bool commit) {  // eta_new ; p_new, pT_new, r
 void stage_matvec_a(mmsbm_hip_ctx *c, int slot, int a_slot, bool grid = false) {
   const int nb = grid ? c->grid_n_chunks : static_cast<int>(c->lay.mv_chunks.size());
   if (nb == 0) return;
-  LaunchScope ls(c, K_MATVEC_A);
+  LaunchScope ls(c, K_MATVEC_A, true);
   PairBlockArgs pa = pair_block_a_args(c, slot, a_slot);
   if (grid) {
     pa.pair_item = c->grid_item.ptr; pa.chunks = c->grid_chunks.ptr;
@@ -328,21 +331,21 @@ void stage_matvec_a(mmsbm_hip_ctx *c, int slot, int a_slot, bool grid = false) {
     const int subs = (c->mv_chunk_pairs + kRowsUnits * kUnitPairs - 1) / (kRowsUnits * kUnitPairs);
     const int n_kb = (c->kp + kMfmaBlk - 1) / kMfmaBlk;  // (outputs: K columns)
     allow_big_lds(mfma_rows_kernel<true>, kMfmaRowsLds);
-    mfma_rows_kernel<true><<<slot_grid(c, nb * subs * n_kb), kPairBlockMax, kMfmaRowsLds, c->stream>>>(pa, pa.tiles, subs, n_kb);
+    LAUNCH_IN(ls, (mfma_rows_kernel<true>), slot_grid(c, nb * subs * n_kb), kPairBlockMax, kMfmaRowsLds, c->stream, pa, pa.tiles, subs, n_kb);
   } else if (c->wide) {
     const int subs = kWideChunkPairs / kWidePairs;
     const size_t lds = static_cast<size_t>(kWidePairs) * c->lp * sizeof(double);
     allow_big_lds(wide_matvec_kernel<true>, lds);
-    wide_matvec_kernel<true><<<slot_grid(c, nb * subs), kBlock, lds, c->stream>>>(pa, subs);
+    LAUNCH_IN(ls, (wide_matvec_kernel<true>), slot_grid(c, nb * subs), kBlock, lds, c->stream, pa, subs);
   } else if (c->mfma) {
     allow_big_lds(pair_mfma_kernel<true, false, kBlock>, c->lds_ma);
-    pair_mfma_kernel<true, false, kBlock><<<slot_grid(c, nb), kBlock, c->lds_ma, c->stream>>>(pa, pa.tiles);
+    LAUNCH_IN(ls, (pair_mfma_kernel<true, false, kBlock>), slot_grid(c, nb), kBlock, c->lds_ma, c->stream, pa, pa.tiles);
   } else if (c->quad_a) {
     const dim3 grid = slot_grid(c, std::min(nb, c->n_cus));
 #define QA(NL)                                                                                    \
   do {                                                                                            \
     allow_big_lds(pair_quad_a_kernel<NL>, c->lds_qa);                                             \
-    pair_quad_a_kernel<NL><<<grid, kPairBlockMax, c->lds_qa, c->stream>>>(pa, pa.tiles, nb);      \
+    LAUNCH_IN(ls, (pair_quad_a_kernel<NL>), grid, kPairBlockMax, c->lds_qa, c->stream, pa, pa.tiles, nb); \
   } while (0)
     const int nl = (c->lp + 3) / 4;  // dinp of the A launch = lp
     if (nl <= 8) QA(8); else if (nl <= 10) QA(10); else if (nl <= 12) QA(12);
@@ -352,7 +355,7 @@ void stage_matvec_a(mmsbm_hip_ctx *c, int slot, int a_slot, bool grid = false) {
 #define PA_D(TL, NT, D)                                                                     \
   do {                                                                                      \
     allow_big_lds(pair_block_kernel<true, false, 1, TL, NT, 4, D>, c->lds_a);               \
-    pair_block_kernel<true, false, 1, TL, NT, 4, D><<<slot_grid(c, nb), NT, c->lds_a, c->stream>>>(pa, pa.tiles); \
+    LAUNCH_IN(ls, (pair_block_kernel<true, false, 1, TL, NT, 4, D>), slot_grid(c, nb), NT, c->lds_a, c->stream, pa, pa.tiles); \
   } while (0)
 #define PA_GO(TL, NT)                                                                       \
   do {                                                                                      \
