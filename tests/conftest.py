@@ -14,6 +14,13 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: takes more than a few seconds on CPU")
+    # a fresh clone has no libmmsbm_hip.so yet (it is not tracked): build it once (hipcc cross-compiles
+    # without a GPU); a machine without hipcc just lets the tests that need the library say so
+    try:
+        from mmsbm_amd.build import ensure_library
+        ensure_library()
+    except Exception as exc:  # noqa: BLE001
+        sys.stderr.write(f"[conftest] library not built: {exc}\n")
 
 
 def load_golden(name):
