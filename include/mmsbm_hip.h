@@ -127,6 +127,11 @@ int mmsbm_hip_update_coefficients(mmsbm_hip_ctx *ctx, double *n_theta, double *n
 
 /* src/expectation_maximization.py:157-167 on the current parameters. */
 int mmsbm_hip_likelihood(mmsbm_hip_ctx *ctx, double *out);
+/* What a finished restart hands back (src/mmsbm.py:256-269): the likelihood and the parameters of the
+ * selected slot in one call -- the same values as mmsbm_hip_likelihood + mmsbm_hip_get_params, with the
+ * parameter download and its host-side unpacking overlapped with the likelihood kernels (at K = L = 50 and
+ * 10M ratings each of the two takes ~33 ms).  theta / eta / pr may be NULL. */
+int mmsbm_hip_result(mmsbm_hip_ctx *ctx, double *theta, double *eta, double *pr, double *likelihood);
 
 /* src/kernels_numpy.py:21-36: (N,K,L) tensor in the ORIGINAL row order of the triples
  * given to create().  Contract / test use only: refuses if N*K*L > capacity_elems. */

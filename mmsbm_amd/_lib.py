@@ -41,6 +41,7 @@ SIGNATURES = {
     "mmsbm_hip_synchronize": (C.c_int, [C.c_void_p]),
     "mmsbm_hip_update_coefficients": (C.c_int, [C.c_void_p, c_f64p, c_f64p, c_f64p]),
     "mmsbm_hip_likelihood": (C.c_int, [C.c_void_p, c_f64p]),
+    "mmsbm_hip_result": (C.c_int, [C.c_void_p, c_f64p, c_f64p, c_f64p, c_f64p]),
     "mmsbm_hip_compute_omegas": (C.c_int, [C.c_void_p, c_f64p, C.c_int64]),
     "mmsbm_hip_prod_dist": (C.c_int, [C.c_void_p, C.c_int64, c_i32p, c_i32p, c_f64p]),
     "mmsbm_hip_predict_begin": (C.c_int, [C.c_void_p, C.c_int64, c_i32p, c_i32p, c_i32p, c_f64p]),

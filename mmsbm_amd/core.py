@@ -208,6 +208,15 @@ class HipEM:
                   _p(pr, C.c_double))
         return theta, eta, pr
 
+    def result(self):
+        """(likelihood, theta, eta, pr) of the selected slot: what likelihood() and get_params() return, the
+        download overlapped with the likelihood kernels."""
+        theta, eta, pr = (np.empty(s, dtype=np.float64) for s in self._shapes())
+        out = C.c_double(0.0)
+        _lib.call("mmsbm_hip_result", self._h, _p(theta, C.c_double), _p(eta, C.c_double), _p(pr, C.c_double),
+                  C.byref(out))
+        return np.float64(out.value), theta, eta, pr
+
     def degrees(self):
         d_u = np.empty(self.n_users, dtype=np.int64)
         d_i = np.empty(self.n_items, dtype=np.int64)

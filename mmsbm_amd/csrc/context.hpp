@@ -135,6 +135,8 @@ const char *const kKernelNames[K_COUNT] = {"seg_pass_kernel", "pair_block_kernel
 struct mmsbm_hip_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t copy_stream = nullptr;  // parameter downloads that overlap kernels of `stream` (mmsbm_hip_result)
+  hipStream_t xfer = nullptr;         // when set: the stream copy_rows / fetch_params use instead of `stream`
   bool swapped = false;
   // external dims
   int64_t n_obs = 0;
@@ -214,6 +216,7 @@ struct mmsbm_hip_ctx {
       (void)hipEventDestroy(pe.second.first);
       (void)hipEventDestroy(pe.second.second);
     }
+    if (copy_stream) (void)hipStreamDestroy(copy_stream);
     if (stream) (void)hipStreamDestroy(stream);
   }
 };

@@ -194,6 +194,7 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
     // are uploaded first in both cases (the element-wise kernels keep them in the original order).
     HIP_CHECK(hipSetDevice(device));
     HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_CHECK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     bool gpu_layout = n_obs >= kGpuLayoutMin;
     if (const char *g = std::getenv("MMSBM_HIP_GPU_LAYOUT")) gpu_layout = std::atoi(g) != 0;
     // (the device sort packs (rating, item) into 31 bits; sparser key spaces stay on the host)
@@ -629,17 +630,15 @@ int likelihood_fast(mmsbm_hip_ctx *c) {
 }
 }  // namespace
 
-int mmsbm_hip_likelihood(mmsbm_hip_ctx *ctx, double *out) {
-  return guarded([&] {
-    require_params(ctx);
-    if (!out) throw std::invalid_argument("null out");
-    use_device(ctx);
-    OneSlot one(ctx);
-    const int cur = ctx->cur, sl = ctx->sel;
-    int nb;
-    if (lik_fast_usable(ctx)) {
-      nb = likelihood_fast(ctx);
-    } else {
+namespace {
+// likelihood of the selected slot (the caller holds a OneSlot): kernels onto the context's stream, no wait;
+// returns the number of partial sums likelihood_finish adds up
+int likelihood_enqueue(mmsbm_hip_ctx *ctx) {
+  const int cur = ctx->cur, sl = ctx->sel;
+  int nb;
+  if (lik_fast_usable(ctx)) {
+    nb = likelihood_fast(ctx);
+  } else {
     const size_t lik_lds = static_cast<size_t>(ctx->kp + ctx->lp) * kLikThreads * sizeof(double);
     if (lik_lds <= kLdsMax - 2048 && ctx->n_lik_units > 0) {
       nb = ctx->n_lik_units;
@@ -657,15 +656,51 @@ int mmsbm_hip_likelihood(mmsbm_hip_ctx *ctx, double *out) {
           ctx->eta[cur].at(sl), ctx->p[cur].at(sl), ctx->lik_part.ptr, ctx->n_obs, ctx->k, ctx->l,
           ctx->kp, ctx->lp);
     }
+  }
+  HIP_CHECK(hipGetLastError());
+  return nb;
+}
+double likelihood_finish(mmsbm_hip_ctx *ctx, int nb) {  // workgroup sums added in workgroup order
+  std::vector<double> part(nb);
+  HIP_CHECK(hipMemcpyAsync(part.data(), ctx->lik_part.ptr, sizeof(double) * nb, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  double tot = 0.0;
+  for (double v : part) tot += v;
+  return tot;
+}
+}  // namespace
+
+int mmsbm_hip_likelihood(mmsbm_hip_ctx *ctx, double *out) {
+  return guarded([&] {
+    require_params(ctx);
+    if (!out) throw std::invalid_argument("null out");
+    use_device(ctx);
+    OneSlot one(ctx);
+    *out = likelihood_finish(ctx, likelihood_enqueue(ctx));
+  });
+}
+
+int mmsbm_hip_result(mmsbm_hip_ctx *ctx, double *theta, double *eta, double *pr, double *likelihood) {
+  return guarded([&] {
+    require_params(ctx);
+    if (!likelihood) throw std::invalid_argument("null likelihood");
+    use_device(ctx);
+    OneSlot one(ctx);
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));  // the parameters are final
+    const int nb = likelihood_enqueue(ctx);        // the likelihood kernels run ...
+    struct Xfer {                                   // ... while the tables travel on the copy stream and are unpacked
+      mmsbm_hip_ctx *c;
+      explicit Xfer(mmsbm_hip_ctx *x) : c(x) { c->xfer = c->copy_stream; }
+      ~Xfer() { c->xfer = nullptr; }
+    };
+    {
+      Xfer on(ctx);
+      double *it = ctx->swapped ? eta : theta;
+      double *ie = ctx->swapped ? theta : eta;
+      fetch_params(ctx, theta_tab(ctx, ctx->cur), plain_tab(ctx->eta[ctx->cur].at(ctx->sel), ctx->lp),
+                   ctx->p[ctx->cur].at(ctx->sel), it, ie, pr);
     }
-    HIP_CHECK(hipGetLastError());
-    std::vector<double> part(nb);
-    HIP_CHECK(hipMemcpyAsync(part.data(), ctx->lik_part.ptr, sizeof(double) * nb,
-                             hipMemcpyDeviceToHost, ctx->stream));
-    HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    double tot = 0.0;
-    for (double v : part) tot += v;
-    *out = tot;
+    *likelihood = likelihood_finish(ctx, nb);
   });
 }
 

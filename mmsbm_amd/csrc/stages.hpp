@@ -466,23 +466,24 @@ bool tab_is_packed(const RowTab &t, int rows) {
 }
 void copy_rows(mmsbm_hip_ctx *c, const RowTab &t, double *stage, int rows, bool to_device) {
   const size_t e = sizeof(double);
+  hipStream_t xs = c->xfer ? c->xfer : c->stream;
   if (rows == 0) return;
   if (tab_is_packed(t, rows)) {
     if (to_device)
-      HIP_CHECK(hipMemcpyAsync(t.main, stage, e * rows * (t.mw + t.tw), hipMemcpyHostToDevice, c->stream));
+      HIP_CHECK(hipMemcpyAsync(t.main, stage, e * rows * (t.mw + t.tw), hipMemcpyHostToDevice, xs));
     else
-      HIP_CHECK(hipMemcpyAsync(stage, t.main, e * rows * (t.mw + t.tw), hipMemcpyDeviceToHost, c->stream));
+      HIP_CHECK(hipMemcpyAsync(stage, t.main, e * rows * (t.mw + t.tw), hipMemcpyDeviceToHost, xs));
     return;
   }
   double *stage_t = stage + static_cast<size_t>(rows) * t.mw;
   if (to_device) {
-    HIP_CHECK(hipMemcpy2DAsync(t.main, e * t.rs_m, stage, e * t.mw, e * t.mw, rows, hipMemcpyHostToDevice, c->stream));
+    HIP_CHECK(hipMemcpy2DAsync(t.main, e * t.rs_m, stage, e * t.mw, e * t.mw, rows, hipMemcpyHostToDevice, xs));
     if (t.tw > 0)
-      HIP_CHECK(hipMemcpy2DAsync(t.tail, e * t.rs_t, stage_t, e * t.tw, e * t.tw, rows, hipMemcpyHostToDevice, c->stream));
+      HIP_CHECK(hipMemcpy2DAsync(t.tail, e * t.rs_t, stage_t, e * t.tw, e * t.tw, rows, hipMemcpyHostToDevice, xs));
   } else {
-    HIP_CHECK(hipMemcpy2DAsync(stage, e * t.mw, t.main, e * t.rs_m, e * t.mw, rows, hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipMemcpy2DAsync(stage, e * t.mw, t.main, e * t.rs_m, e * t.mw, rows, hipMemcpyDeviceToHost, xs));
     if (t.tw > 0)
-      HIP_CHECK(hipMemcpy2DAsync(stage_t, e * t.tw, t.tail, e * t.rs_t, e * t.tw, rows, hipMemcpyDeviceToHost, c->stream));
+      HIP_CHECK(hipMemcpy2DAsync(stage_t, e * t.tw, t.tail, e * t.rs_t, e * t.tw, rows, hipMemcpyDeviceToHost, xs));
   }
 }
 void zero_rows(mmsbm_hip_ctx *c, const RowTab &t, int rows) {
@@ -569,7 +570,8 @@ void p_dev_to_host(const mmsbm_hip_ctx *c, const double *p, double *pr) {
 // (theta, eta, p) tables of one slot -> host arrays in host layout; any output may be null
 void fetch_params(mmsbm_hip_ctx *c, const RowTab &tt, const RowTab &et, const double *p_dev,
                   double *theta, double *eta, double *pr) {
-  HIP_CHECK(hipStreamSynchronize(c->stream));
+  hipStream_t xs = c->xfer ? c->xfer : c->stream;
+  HIP_CHECK(hipStreamSynchronize(xs));
   c->pin.reset(rows_doubles(c));
   const size_t klr = static_cast<size_t>(c->n_ratings) * c->kp * c->lp;
   const double *st = theta ? download_rows(c, tt, c->n_users) : nullptr;
@@ -577,9 +579,9 @@ void fetch_params(mmsbm_hip_ctx *c, const RowTab &tt, const RowTab &et, const do
   double *sp = nullptr;
   if (pr) {
     sp = c->pin.take(klr);
-    HIP_CHECK(hipMemcpyAsync(sp, p_dev, sizeof(double) * klr, hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipMemcpyAsync(sp, p_dev, sizeof(double) * klr, hipMemcpyDeviceToHost, xs));
   }
-  HIP_CHECK(hipStreamSynchronize(c->stream));
+  HIP_CHECK(hipStreamSynchronize(xs));
   if (theta) unpack_rows(theta, st, tt, c->n_users, c->k);
   if (eta) unpack_rows(eta, se, et, c->n_items, c->l);
   if (pr) p_dev_to_host(c, sp, pr);

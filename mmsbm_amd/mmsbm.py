@@ -216,8 +216,7 @@ class MMSBM:
             self.iterations_run[i] = done
         out = []
         for s in range(len(ids)):
-            likelihood = ctx.select(s).likelihood()
-            theta, eta, pr = ctx.get_params()
+            likelihood, theta, eta, pr = ctx.select(s).result()
             out.append({"likelihood": likelihood, "pr": pr, "theta": theta, "eta": eta})
         self._resident[(device, slot)] = ids
         return out

@@ -44,6 +44,9 @@ class FakeHipEM:
     def selected(self):
         return self._sel
 
+    def result(self):
+        return (self.likelihood(),) + tuple(self.get_params())
+
     def max_slots(self, fraction=0.5, sharers=1):
         return getattr(FakeHipEM, "MAX_SLOTS", 1 << 20)
 

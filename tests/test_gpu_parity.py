@@ -1079,6 +1079,28 @@ def test_pair_stage_families_at_their_borders(hip, k, l, family):
         assert em.likelihood() == pytest.approx(float(orc.compute_likelihood(data, t, e, p)), rel=1e-11)
 
 
+@pytest.mark.parametrize("swap", [0, 1])
+def test_result_is_likelihood_plus_parameters(hip, swap):
+    """mmsbm_hip_result (the parameter download overlapped with the likelihood kernels) returns bit for bit
+    what likelihood() and get_params() return, for every slot, either orientation, and leaves the context
+    ready to go on iterating."""
+    rng = np.random.default_rng(5)
+    n_u, n_i, n_r, k, l = 700, 300, 5, 12, 9
+    data = np.stack([rng.integers(0, n_u, 20000), rng.integers(0, n_i, 20000), rng.integers(0, n_r, 20000)], axis=1).astype(np.int64)
+    with hip.HipEM(data, k, l, n_u, n_i, n_r, slots=3, swap_sides=swap) as em:
+        for s_ in range(3):
+            em.select(s_).init_params(10 + s_)
+        em.iterate(7)
+        for s_ in range(3):
+            lik, t, e, p = em.select(s_).result()
+            assert lik == em.likelihood()
+            for a, b in zip((t, e, p), em.get_params()):
+                assert np.array_equal(a, b)
+        em.iterate(2)
+        lik2, t2, e2, p2 = em.select(1).result()
+        assert lik2 == em.likelihood() and not np.array_equal(t2, t)
+
+
 def test_big_tiles_on_small_and_degenerate_data(hip):
     """The matrix-core pair stage on inputs far from its design point: a handful of triples, one rating
     value, ratings without rows, one item, one user, absent ids, more groups than rows -- random shapes
