@@ -53,6 +53,10 @@ def parse_args():
                          "GPU advancing as slots of one context (e.g. 8); never part of `value`.  Off by "
                          "default so that a kernel trace of the default command holds one-restart "
                          "launches only")
+    ap.add_argument("--steady-steps", type=int, default=1000,
+                    help="after the timed region, every rank also times this many iterations with HIP events "
+                         "(`steady_state`: a 20-step region sits inside the ~1.7 ms clock ramp that follows an idle "
+                         "period, DESIGN.md section 5); 0 = skip")
     ap.add_argument("--graph", action="store_true", help="replay a captured hipGraph instead of eager launches")
     ap.add_argument("--dist-backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
     ap.add_argument("--share-gpu", action="store_true",
@@ -78,13 +82,20 @@ def self_launch(args):
 
 def kernel_source_sha16():
     """Identity of the kernels a profile was taken with (profiles/pmc_summary.json records it): every
-    source under mmsbm_amd/csrc, in name order."""
-    h = hashlib.sha256()
-    csrc = os.path.join(ROOT, "mmsbm_amd", "csrc")
-    for name in sorted(f for f in os.listdir(csrc) if f.endswith((".hip", ".hpp"))):
-        with open(os.path.join(csrc, name), "rb") as fh:
-            h.update(name.encode() + b"\0" + fh.read())
-    return h.hexdigest()[:16]
+    source under mmsbm_amd/csrc, in name order -- the same digest the library is compiled with
+    (mmsbm_hip_build_id)."""
+    from mmsbm_amd.build import source_id
+    return source_id()
+
+
+def gather_ranks(mine, world):
+    """[per-rank record] on every rank, in rank order (one all_gather_object; a list of one without a group)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or world == 1:
+        return [mine]
+    parts = [None] * world
+    dist.all_gather_object(parts, mine)
+    return parts
 
 
 def cpu_baseline(cfg, sample_rows, iters):
@@ -257,6 +268,12 @@ def main():
     if dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed_max = float(t.item())
+    # the binary that ran IS the one built from the sources in the tree (ensure_library rebuilds a stale one;
+    # MMSBM_HIP_LIBRARY may point elsewhere): recorded, and `traffic` is dropped when it is not
+    from mmsbm_amd import _lib
+    build_id = _lib.build_id()
+    # steady state: the same loop, long enough to leave the clock ramp behind (HIP events on the library's stream)
+    steady_ms = ctx.time_iterations(args.steady_steps) / args.steady_steps if args.steady_steps > 0 else None
 
     # end of the job: likelihood of this rank's restart + ONE all-reduce to pick the best
     coll_error = None
@@ -267,6 +284,15 @@ def main():
             coll_error = f"{type(exc).__name__}: {exc}"
     lik = ctx.likelihood()
     best, best_lik, liks = restarts.pick_max_likelihood({rank: lik}, world, device)
+    # who ran what: one record per rank (device identity from the library's own HIP runtime), gathered with
+    # one all_gather_object -- so that a line from an 8-GPU node shows eight different PCI bus ids, each
+    # rank's own time for the K steps and its restart's likelihood
+    ident = _lib.device_identity(local)
+    ranks = gather_ranks({"rank": rank, "local_rank": local, "device_index": local, "device_name": ident["name"],
+                          "pci_bus_id": ident["pci_bus_id"], "compute_units": ident["compute_units"],
+                          "hostname": socket.gethostname(), "pid": os.getpid(), "restart": rank,
+                          "ms_per_step": 1000.0 * elapsed / args.steps,
+                          "steady_ms_per_step": steady_ms, "likelihood": float(lik), "build_id": build_id}, world)
 
     out = None
     if rank == 0:
@@ -292,6 +318,16 @@ def main():
                        "pair_stage": {0.0: "vector ALUs (pair_block_kernel)", 1.0: "matrix cores (pair_mfma_kernel)",
                                       2.0: "matrix cores, blocked (mfma_rows_kernel + mfma_slab_kernel)"}[ctx.get_option("mfma")]},
             "collective": coll,
+            "ranks": ranks,
+            "distinct_devices": len({(r["hostname"], r["pci_bus_id"]) for r in ranks}),
+            "steady_state": (None if steady_ms is None else
+                             {"steps": args.steady_steps, "ms_per_step": max(r["steady_ms_per_step"] for r in ranks),
+                              "value": world * 1000.0 / max(r["steady_ms_per_step"] for r in ranks), "unit": "it/s",
+                              "frac_of_hbm_peak": rd * (1000.0 / max(r["steady_ms_per_step"] for r in ranks)) / 1e9 / HBM_PEAK_GBPS,
+                              "source": "HIP events on the library's stream around `steps` iterations, after the "
+                                        "timed region; max over ranks"}),
+            "library": {"build_id": build_id, "source_id": kernel_source_sha16(),
+                        "matches_sources": build_id == kernel_source_sha16()},
             "roofline": roofline_object(args, ctx, prof, n, k, l),
             "iteration": {"algorithmic_read_bytes": rd, "algorithmic_write_bytes": wr,
                           "achieved_gbps_per_gpu": rd * (its / world) / 1e9,

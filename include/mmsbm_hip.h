@@ -52,11 +52,19 @@ typedef struct mmsbm_hip_ctx mmsbm_hip_ctx;
 
 /* ---- library / device ---------------------------------------------------------- */
 int mmsbm_hip_abi_version(void);
+/* Identity of the kernel sources this binary was compiled from: the first 16 hex digits of the SHA-256 over
+ * every file under mmsbm_amd/csrc (name, NUL, contents; in name order) -- what mmsbm_amd/build.py computes
+ * and bench.py / profiles/pmc_summary.json record, so that a measurement can say which kernels really ran.
+ * "unknown" when the library was built without the build script. */
+const char *mmsbm_hip_build_id(void);
 const char *mmsbm_hip_last_error(void);
 int mmsbm_hip_device_count(int *count);
 /* name: caller buffer of name_len bytes; arch e.g. "gfx950:sramecc+:xnack-". */
 int mmsbm_hip_device_info(int device, char *name, int name_len, int *compute_units,
                           int64_t *global_mem_bytes);
+/* PCI bus id of the device ("0000:05:00.0", hipDeviceGetPCIBusId): with the name, what tells the ranks of a
+ * multi-GPU job apart -- bench.py prints it per rank so that a line proves which GPUs it ran on. */
+int mmsbm_hip_device_pci(int device, char *bus_id, int bus_id_len);
 /* Device memory that is free right now / in total (hipMemGetInfo): what batches of restart
  * slots are sized from -- other contexts and processes on the same GPU already count. */
 int mmsbm_hip_device_mem(int device, int64_t *free_bytes, int64_t *total_bytes);

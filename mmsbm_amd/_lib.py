@@ -20,9 +20,11 @@ c_intp = C.POINTER(C.c_int)
 # name -> (restype, argtypes); every symbol include/mmsbm_hip.h declares
 SIGNATURES = {
     "mmsbm_hip_abi_version": (C.c_int, []),
+    "mmsbm_hip_build_id": (C.c_char_p, []),
     "mmsbm_hip_last_error": (C.c_char_p, []),
     "mmsbm_hip_device_count": (C.c_int, [c_intp]),
     "mmsbm_hip_device_info": (C.c_int, [C.c_int, C.c_char_p, C.c_int, c_intp, c_i64p]),
+    "mmsbm_hip_device_pci": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
     "mmsbm_hip_device_mem": (C.c_int, [C.c_int, c_i64p, c_i64p]),
     "mmsbm_hip_create": (C.c_int, [C.c_int, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                    C.c_int32, c_i32p, c_i32p, c_i32p, C.c_int,
@@ -101,6 +103,21 @@ def check(func_name, code):
 
 def call(func_name, *args):
     check(func_name, getattr(load(), func_name)(*args))
+
+
+def build_id() -> str:
+    """Source identity the LOADED binary was compiled from (see mmsbm_hip_build_id in the header)."""
+    return load().mmsbm_hip_build_id().decode()
+
+
+def device_identity(device: int) -> dict:
+    """{"name", "compute_units", "memory_bytes", "pci_bus_id"} of a HIP device, from the library's own runtime."""
+    name, bus = C.create_string_buffer(256), C.create_string_buffer(64)
+    cus, mem = C.c_int(0), C.c_int64(0)
+    call("mmsbm_hip_device_info", int(device), name, 256, C.byref(cus), C.byref(mem))
+    call("mmsbm_hip_device_pci", int(device), bus, 64)
+    return {"name": name.value.decode(), "compute_units": int(cus.value), "memory_bytes": int(mem.value),
+            "pci_bus_id": bus.value.decode()}
 
 
 def device_count() -> int:

@@ -66,6 +66,11 @@ extern "C" {
 
 int mmsbm_hip_abi_version(void) { return MMSBM_HIP_ABI_VERSION; }
 
+#ifndef MMSBM_BUILD_ID
+#define MMSBM_BUILD_ID "unknown"
+#endif
+const char *mmsbm_hip_build_id(void) { return MMSBM_BUILD_ID; }
+
 const char *mmsbm_hip_last_error(void) { return g_last_error.c_str(); }
 
 int mmsbm_hip_device_count(int *count) {
@@ -91,6 +96,17 @@ int mmsbm_hip_device_info(int device, char *name, int name_len, int *compute_uni
     }
     if (compute_units) *compute_units = prop.multiProcessorCount;
     if (global_mem_bytes) *global_mem_bytes = static_cast<int64_t>(prop.totalGlobalMem);
+  });
+}
+
+int mmsbm_hip_device_pci(int device, char *bus_id, int bus_id_len) {
+  return guarded([&] {
+    if (!bus_id || bus_id_len < 16) throw std::invalid_argument("bus_id buffer of at least 16 bytes needed");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+      throw ApiError(MMSBM_E_NODEVICE, "no HIP device available");
+    if (device < 0 || device >= ndev) throw std::invalid_argument("device index out of range");
+    HIP_CHECK(hipDeviceGetPCIBusId(bus_id, bus_id_len, device));
   });
 }
 
@@ -193,6 +209,11 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
     // kGpuLayoutMin triples (layout_gpu.hpp; MMSBM_HIP_GPU_LAYOUT=0/1 forces either).  The id columns
     // are uploaded first in both cases (the element-wise kernels keep them in the original order).
     HIP_CHECK(hipSetDevice(device));
+    {  // (before anything is sized from it: chunk lengths, persistent grids)
+      int cus = 0;
+      if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
+        c->n_cus = cus;
+    }
     HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIP_CHECK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     bool gpu_layout = n_obs >= kGpuLayoutMin;
@@ -302,11 +323,6 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
     }
     lap("xcd-local work lists");
 
-    {
-      int cus = 0;
-      if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
-        c->n_cus = cus;
-    }
     hipStream_t s = c->stream;
     c->pair_off.upload(c->lay.pair_off, s);
     c->pair_item.upload(c->lay.pair_item, s);
@@ -1105,6 +1121,8 @@ int mmsbm_hip_get_option(const mmsbm_hip_ctx *ctx, const char *name, double *val
     else if (key == "lik_g") *value = ctx->lik_g;
     else if (key == "ranges_pairs") *value = ctx->ranges_pairs;   // read-only: XCD-local work lists,
     else if (key == "ranges_users") *value = ctx->ranges_users;   // ranges per pass (1 = off)
+    else if (key == "chunk_pairs") *value = ctx->mv_chunk_pairs;   // read-only: pairs per pair-stage workgroup at most
+    else if (key == "n_chunks") *value = ctx->n_chunks;            // read-only: pair-stage workgroups (= slabs), padding included
     else if (key == "items_pairs") *value = static_cast<double>(ctx->lay.pair_work.items.size());
     else if (key == "items_users") *value = static_cast<double>(ctx->lay.user_work.items.size());
     else throw std::invalid_argument("unknown option: " + key);

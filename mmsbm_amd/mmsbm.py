@@ -247,12 +247,14 @@ class MMSBM:
         self._scored = (matrix, raw)
         return self.prediction_matrix
 
-    def _predict_runs(self, test):
+    def _predict_runs(self, test, subset=None):
         """The restarts held by THIS model (all of them, or this rank's share) on encoded test triples:
-        (mean distribution over them, its six sums, the five scores of every restart)."""
+        (mean distribution over them, its six sums, the five scores of every restart).  ``subset``:
+        positions in ``self.results`` to score instead of all of them (restarts.predict_distributed)."""
         self.test = test
         dev = self._device_list()[0]
         ctx = self._ctx(dev)
+        picked = list(range(len(self.results))) if subset is None else list(subset)
         # restarts whose final parameters still sit in this context's slots need no upload
         resident = self._resident.get((dev, 0)) == list(self._restart_ids) and ctx.slots == len(self.results)
         if not resident:
@@ -260,7 +262,8 @@ class MMSBM:
             self._resident.pop((dev, 0), None)
         ctx.predict_begin(test, np.asarray(self.ratings, dtype=np.float64))
         per_run = []
-        for j, a in enumerate(self.results):
+        for j in picked:
+            a = self.results[j]
             if resident:
                 ctx.select(j)
             else:

@@ -151,7 +151,8 @@ def fit_distributed(model, train, runner=None, gather=True, device=None):
 
 def predict_distributed(model, data, device=None, share_best=True):
     """``MMSBM.predict`` (src/mmsbm.py:279-317) for restarts that live on different ranks
-    (``fit_distributed(..., gather=False)``): every rank adds the rating distributions of ITS restarts on
+    (``fit_distributed(..., gather=False)``; after ``gather=True`` every rank holds all restarts and each is
+    scored by the lowest rank holding it): every rank adds the rating distributions of ITS restarts on
     its GPU, ONE all-reduce(SUM) of the (M, R) matrix makes the mean over all restarts -- no rank ever holds
     another rank's parameters (at BASELINE's config 5 a restart is 440 MB; the matrix of 1M test rows is
     80 MB).  ``data``: what ``model.predict`` takes, or encoded (M,3) triples after ``fit_encoded``.
@@ -159,16 +160,33 @@ def predict_distributed(model, data, device=None, share_best=True):
     best test accuracy on the rank that ran it -- on all ranks with ``share_best`` (one broadcast).
     The mean differs from a one-process predict only in the association order of the sum over restarts."""
     test = model.data_handler.transform(data, model.logger) if model.data_handler is not None else np.asarray(data)
-    mine = list(model._restart_ids)
+    held = list(model._restart_ids)
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    mine = held
+    if multi:
+        # A restart may be held by SEVERAL ranks (fit_distributed(gather=True) leaves every rank with all of
+        # them): it is scored once, by the lowest rank that holds it -- otherwise the all-reduce(SUM) below
+        # would count it once per holder and the mean would come out world-size times too large.
+        everyone = [None] * dist.get_world_size()
+        dist.all_gather_object(everyone, held)
+        me = dist.get_rank()
+        first = {}
+        for r, ids in enumerate(everyone):
+            for i in ids:
+                first.setdefault(i, r)
+        missing = [i for i in range(model.sampling) if i not in first]
+        if missing:
+            raise RuntimeError(f"predict_distributed: no rank holds restart(s) {missing}")
+        mine = [i for i in held if first[i] == me]
     if mine:
-        mean_local, _, stats_local = model._predict_runs(test)
+        mean_local, _, stats_local = model._predict_runs(test, subset=[held.index(i) for i in mine])
         total = np.ascontiguousarray(mean_local * float(len(mine)), dtype=np.float64)
     else:   # more ranks than restarts: this one only takes part in the collectives
         model.test, stats_local = test, []
         total = np.zeros((len(test), len(model.ratings)), dtype=np.float64)
     per_run = dict(zip(mine, stats_local))
     owner = {i: 0 for i in mine}
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if multi:
         dev = _collective_device(device)
         t = torch.from_numpy(total).to(dev)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -184,8 +202,8 @@ def predict_distributed(model, data, device=None, share_best=True):
     model._scored = None                            # score(): from the matrix (host side)
     best = int(np.argmax([st["accuracy"] for st in model.run_stats]))    # first best restart, src/mmsbm.py:474-478
     rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
-    res = model.results[mine.index(best)] if best in mine else None
-    if share_best and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    res = model.results[held.index(best)] if best in mine else None
+    if share_best and multi:
         box = [res]
         dist.broadcast_object_list(box, src=owner[best])
         res = box[0]

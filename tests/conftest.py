@@ -39,3 +39,30 @@ def rel_err(got, want):
     want = np.asarray(want, dtype=np.float64)
     denom = np.max(np.abs(want)) if want.size else 1.0
     return float(np.max(np.abs(got - want)) / (denom if denom > 0 else 1.0)) if want.size else 0.0
+
+
+ELEMENT_FLOOR = 1e-290   # below this an entry is within a few binades of the subnormals: relative error means nothing
+ELEMENT_RTOL = 1e-9      # north_star's bar is 1e-5 relative; every multiplicative update should hold far inside it
+
+
+def elem_rel_err(got, want, floor=ELEMENT_FLOOR):
+    """max over the entries with |want| > floor of |got - want| / |want| -- ELEMENT-WISE relative error,
+    next to rel_err's max-norm (in which an entry of 1e-20 that is wrong by a factor of ten is invisible).
+    Entries at or below the floor must agree to within the floor itself."""
+    got = np.asarray(got, dtype=np.float64)
+    want = np.asarray(want, dtype=np.float64)
+    assert got.shape == want.shape, (got.shape, want.shape)
+    if not want.size:
+        return 0.0
+    big = np.abs(want) > floor
+    small_ok = np.all(np.abs(got[~big] - want[~big]) <= floor)
+    if not small_ok:
+        return float("inf")
+    if not big.any():
+        return 0.0
+    return float(np.max(np.abs(got[big] - want[big]) / np.abs(want[big])))
+
+
+def assert_elementwise(got, want, what="", rtol=ELEMENT_RTOL):
+    err = elem_rel_err(got, want)
+    assert err <= rtol, f"{what}: element-wise relative error {err:.3e} > {rtol:.1e}"

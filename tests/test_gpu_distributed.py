@@ -99,6 +99,15 @@ def test_bench_one_gpu_line_has_roofline_cpu_baseline_and_rccl_collective():
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "all 100000 triples" in cb["sample"]
     assert 0.5 < cb["port_over_reference"] < 2.0
     assert out["value"] == pytest.approx(20 / (out["ms_per_step"] * 20e-3), rel=1e-6)
+    # the line says what it ran on and with which binary, and carries the long-run figure beside the short one
+    assert len(out["ranks"]) == 1 and out["distinct_devices"] == 1
+    r0 = out["ranks"][0]
+    assert r0["rank"] == 0 and r0["device_index"] == 0 and "gfx950" in r0["device_name"] and ":" in r0["pci_bus_id"]
+    assert r0["ms_per_step"] == pytest.approx(out["ms_per_step"], rel=1e-9) and r0["likelihood"] == out["likelihoods"][0]
+    assert out["library"]["matches_sources"] and out["library"]["build_id"] == r0["build_id"]
+    ss = out["steady_state"]
+    assert ss["steps"] == 1000 and 0 < ss["ms_per_step"] < 2 * out["ms_per_step"]
+    assert ss["value"] == pytest.approx(1000.0 / ss["ms_per_step"], rel=1e-9)
 
 
 def test_bench_gpus2_starts_its_own_ranks():
@@ -115,3 +124,16 @@ def test_bench_gpus2_starts_its_own_ranks():
     assert out["best_restart"] == int(np.argmax(out["likelihoods"]))
     assert "cpu_baseline" not in out                                              # rank 0 at N=1 only
     assert out["value"] == pytest.approx(2 * 20 / (out["ms_per_step"] * 20e-3), rel=1e-6)
+    # self-validation for the day a driver has N GPUs: one record per rank, gathered over the process group
+    ranks = out["ranks"]
+    assert [r["rank"] for r in ranks] == [0, 1] and [r["restart"] for r in ranks] == [0, 1]
+    assert len({r["pid"] for r in ranks}) == 2                                    # two processes ...
+    assert out["distinct_devices"] == 1 and {r["pci_bus_id"] for r in ranks} == {ranks[0]["pci_bus_id"]}   # ... sharing GPU 0 here
+    for r in ranks:
+        assert set(r) >= {"rank", "device_index", "device_name", "pci_bus_id", "ms_per_step", "steady_ms_per_step",
+                          "likelihood", "build_id", "hostname"}
+        assert "gfx950" in r["device_name"] and r["ms_per_step"] > 0 and r["build_id"] == out["library"]["build_id"]
+    assert [r["likelihood"] for r in ranks] == out["likelihoods"]                 # len = sampling = world size
+    assert out["ms_per_step"] == pytest.approx(max(r["ms_per_step"] for r in ranks), rel=1e-9)   # max over ranks
+    assert out["steady_state"]["ms_per_step"] == max(r["steady_ms_per_step"] for r in ranks)
+    assert out["steady_state"]["value"] == pytest.approx(2 * 1000.0 / out["steady_state"]["ms_per_step"], rel=1e-9)

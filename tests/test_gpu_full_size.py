@@ -11,7 +11,8 @@ mmsbm_amd/restarts.py -- and restart i does not depend on where it runs).
 import numpy as np
 import pytest
 
-from conftest import rel_err
+from conftest import assert_elementwise, rel_err
+from oracle import mmsbm_factorised as fac
 from oracle import mmsbm_oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -49,35 +50,60 @@ def _argmax_agreement(got, want):
     return float(np.mean(np.argmax(got, 1)[clear] == np.argmax(want, 1)[clear])), float(clear.mean())
 
 
-def _full_parity(hip, train, k, l, iters, seed):
+def _oracle_case(train, k, l, iters, seed):
+    """What the dense oracle gives for restart 0 of MMSBM(k, l, seed=seed) on `train`: the start, the
+    numerators of one step, the parameters after `iters` iterations, their likelihood and prod_dist."""
     n_u, n_i, n_r = (int(train[:, j].max()) + 1 for j in range(3))
-    mm = hip.MMSBM(k, l, iterations=iters, seed=seed)
-    mm._prepare_objects(train)
-    ctx = mm._ctx(0)
-    d_u, d_i = ctx.degrees()
-    od_u, od_i = orc.degrees(train, n_u, n_i)
-    assert np.array_equal(d_u, od_u) and np.array_equal(d_i, od_i)
-    theta, eta, pr = mm.init_params(mm.child_states[0], d_u, d_i)
-    ctx.set_params(theta, eta, pr)
-    # --- one un-normalised step: ALL three numerators, every entry
-    got = ctx.update_coefficients()
-    want = orc.update_coefficients(train, theta, eta, pr)
-    for g, w, nm in zip(got, want, ("n_theta", "n_eta", "n_pr")):
-        assert g.shape == w.shape
-        assert rel_err(g, w) < TOL_STEP, (nm, rel_err(g, w))
-    # --- `iters` full iterations: parameters, likelihood, predictions
-    ctx.iterate(iters)
+    d_u, d_i = orc.degrees(train, n_u, n_i)
+    start = orc.init_params(orc.child_seeds(seed, 1)[0], n_u, n_i, n_r, k, l, d_u, d_i)
+    numer = orc.update_coefficients(train, *start)
+    theta, eta, pr = start
     for _ in range(iters):
         theta, eta, pr = orc.em_step(train, theta, eta, pr, d_u, d_i)
-    for g, w, nm in zip(ctx.get_params(), (theta, eta, pr), ("theta", "eta", "pr")):
+    return {"d_u": d_u, "d_i": d_i, "start": start, "numer": numer, "params": (theta, eta, pr),
+            "lik": float(orc.compute_likelihood(train, theta, eta, pr)),
+            "pd": orc.prod_dist(train, theta, eta, pr), "iters": iters, "k": k, "l": l, "seed": seed}
+
+
+def _check_against(hip, train, case, options=()):
+    """One context on `train` against an _oracle_case: EVERY entry of the three numerators after one step
+    and of theta / eta / p after the iterations -- in max-norm (rel_err) and element by element
+    (|diff| <= 1e-9 |want| for every entry above 1e-290; north_star's bar is 1e-5) -- the likelihood,
+    prod_dist and the argmax of every row.  Returns what the context says it ran."""
+    mm = hip.MMSBM(case["k"], case["l"], iterations=case["iters"], seed=case["seed"])
+    mm._prepare_objects(train)
+    ctx = mm._ctx(0)
+    for name, value in options:
+        ctx.set_option(name, value)
+        assert ctx.get_option(name) == float(value), (name, value, ctx.get_option(name))
+    d_u, d_i = ctx.degrees()
+    assert np.array_equal(d_u, case["d_u"]) and np.array_equal(d_i, case["d_i"])
+    theta, eta, pr = mm.init_params(mm.child_states[0], d_u, d_i)
+    for a, b in zip((theta, eta, pr), case["start"]):
+        assert np.array_equal(a, b)
+    ctx.set_params(theta, eta, pr)
+    got = ctx.update_coefficients()
+    for g, w, nm in zip(got, case["numer"], ("n_theta", "n_eta", "n_pr")):
+        assert g.shape == w.shape
+        assert rel_err(g, w) < TOL_STEP, (nm, rel_err(g, w))
+        assert_elementwise(g, w, nm)
+    ctx.iterate(case["iters"])
+    for g, w, nm in zip(ctx.get_params(), case["params"], ("theta", "eta", "pr")):
         assert rel_err(g, w) < TOL_FEW, (nm, rel_err(g, w))
-    lik, lik_o = ctx.likelihood(), float(orc.compute_likelihood(train, theta, eta, pr))
-    assert abs(lik - lik_o) <= 1e-11 * abs(lik_o), (lik, lik_o)
-    pd_h, pd_o = ctx.prod_dist(train), orc.prod_dist(train, theta, eta, pr)
-    assert rel_err(pd_h, pd_o) < TOL_FEW
-    agree, clear = _argmax_agreement(pd_h, pd_o)
+        assert_elementwise(g, w, nm)
+    lik = ctx.likelihood()
+    assert abs(lik - case["lik"]) <= 1e-11 * abs(case["lik"]), (lik, case["lik"])
+    pd_h = ctx.prod_dist(train)
+    assert rel_err(pd_h, case["pd"]) < TOL_FEW
+    agree, clear = _argmax_agreement(pd_h, case["pd"])
     assert agree == 1.0 and clear > 0.99, (agree, clear)
+    info = {nm: ctx.get_option(nm) for nm in ("mfma", "quad", "chunk_pairs", "n_chunks")}
     mm._release()
+    return info
+
+
+def _full_parity(hip, train, k, l, iters, seed):
+    return _check_against(hip, train, _oracle_case(train, k, l, iters, seed))
 
 
 def test_c3_full_size_all_numerators_parameters_likelihood_argmax(hip, c3_train):
@@ -85,11 +111,40 @@ def test_c3_full_size_all_numerators_parameters_likelihood_argmax(hip, c3_train)
     _full_parity(hip, c3_train, 20, 20, iters=3, seed=0)
 
 
-def test_c5_shape_dense_subproblem_all_numerators_parameters_likelihood_argmax(hip):
-    """C5's shape (K = L = 50, R = 10, 10 ratings per user, 100 per item -- the LDS-tile pair stage
-    and the persistent A pipeline) at 120k ratings, where the dense oracle (2 GB per tensor) fits."""
+@pytest.fixture(scope="module")
+def c5_shape():
+    """C5's shape (K = L = 50, R = 10, 10 ratings per user, 100 per item) at 120k ratings, where the dense
+    oracle (2.4 GB per tensor) fits; 1,200 pairs per rating: every chunk size leaves a ragged last chunk."""
     train = orc.synthetic_triples(120_000, 12_000, 1_200, 10, seed=5)
-    _full_parity(hip, train, 50, 50, iters=3, seed=11)
+    return train, _oracle_case(train, 50, 50, iters=3, seed=11)
+
+
+def test_c5_shape_dense_subproblem_all_numerators_parameters_likelihood_argmax(hip, c5_shape):
+    """The library's own choice for this shape: the matrix-core pair stage, 256-pair chunks."""
+    info = _check_against(hip, *c5_shape)
+    assert info["mfma"] == 1.0 and info["chunk_pairs"] == 256
+
+
+@pytest.mark.parametrize("chunk", [512, 1024])
+def test_c5_shape_with_the_chunk_sizes_full_size_c5_runs(hip, c5_shape, chunk, monkeypatch):
+    """From 524,288 pairs on (only full-size C5 gets there) `mmsbm_hip_create` gives every matrix-core
+    workgroup 512 pairs = 8 units; the kernel takes up to 1,024.  Forced here (MMSBM_HIP_MFMA_CHUNK) on the
+    120k-rating problem the dense oracle can hold: 1,200 pairs per rating = chunks of 512 + 512 + 176
+    (resp. 1,024 + 176) and empty padding chunks up to 8 per rating.  EVERY entry of n_theta / n_eta /
+    n_p and of theta / eta / p is compared, element-wise too: a permuted or mis-accumulated (k, l) tile of
+    a slab cannot pass (src/kernels_numpy.py:43-79)."""
+    monkeypatch.setenv("MMSBM_HIP_MFMA_CHUNK", str(chunk))
+    info = _check_against(hip, *c5_shape)
+    assert info["mfma"] == 1.0 and info["chunk_pairs"] == chunk
+    assert info["n_chunks"] == 10 * 8          # ceil(1200 / chunk) = 3 or 2 real chunks per rating, padded to 8
+
+
+def test_c5_shape_on_the_vector_alus_with_the_persistent_a_pipeline(hip, c5_shape):
+    """The same problem with the matrix cores off: pair_block_kernel (tile in LDS) for T + S and the
+    persistent four-unit pipeline pair_quad_a_kernel for A -- what C5 ran before round 2 and what
+    MMSBM_HIP_NO_MFMA / option mfma = 0 still select."""
+    info = _check_against(hip, *c5_shape, options=(("mfma", 0), ("quad", 1)))
+    assert info["mfma"] == 0.0 and info["quad"] == 1.0
 
 
 def _check_invariants(train, res, d_u, d_i):
@@ -131,13 +186,21 @@ def test_c4_sampling8_on_the_c3_workload(hip, c3_train):
 
 def test_c5_sampling8_full_size(hip, c5_train):
     """BASELINE configs[4] on one GPU: 10M ratings, 1M x 100k, R=10, K=L=50, sampling = 8 as 8 slots
-    (HBM-capacity stress: ~2.5 GB per slot).  The dense oracle cannot hold this (omega = 200 GB), so:
-    invariants for every restart, restart 0 bitwise the one-slot run, and for a restart that is not
-    slot 0 the numerators of a user block and of an item block against the oracle on those rows."""
+    (HBM-capacity stress: ~2.5 GB per slot).  The dense oracle cannot hold this (omega = 200 GB); the
+    factorised float64 checker (oracle/mmsbm_factorised.py, pinned to the dense oracle at 1e-13 in
+    tests/test_oracle_golden.py) can: for a restart that is NOT slot 0, EVERY entry of n_theta / n_eta /
+    n_p after one step and of theta / eta / p after two iterations, in max-norm and element-wise, and the
+    likelihood (src/kernels_numpy.py:43-79, src/expectation_maximization.py:152-167); beside it a user
+    block and an item block against the dense oracle itself, invariants for every restart, and restart 0
+    bitwise the one-slot run.  This is the only test that reaches the 512-pair (8-unit) matrix-core
+    workgroups by the library's own choice."""
     train = c5_train
     n_u, n_i, n_r = (int(train[:, j].max()) + 1 for j in range(3))
     seeds = orc.child_seeds(0, 8)
+    pairs = fac.Pairs(train, n_u, n_i, n_r)
     with hip.HipEM(train, 50, 50, n_u, n_i, n_r, device=0) as em:
+        assert em.n_pairs == pairs.n_pairs
+        assert em.get_option("mfma") == 1.0 and em.get_option("chunk_pairs") == 512
         assert em.max_slots(0.5) >= 8, "8 restarts of C5 must fit one MI355X"
         em.set_slots(8)
         assert em.slots == 8
@@ -145,18 +208,25 @@ def test_c5_sampling8_full_size(hip, c5_train):
         assert np.array_equal(d_u, np.bincount(train[:, 0])) and np.array_equal(d_i, np.bincount(train[:, 1]))
         for s in range(8):
             em.select(s).init_params(seeds[s])
-        # slot 6: un-normalised numerators vs the oracle (rows of 40 users / of 3 items are complete)
+        # slot 6: un-normalised numerators, every entry against the factorised checker
         s = 6
         theta, eta, pr = orc.init_params(seeds[s], n_u, n_i, n_r, 50, 50, d_u, d_i)
         n_t, n_e, n_p = em.select(s).update_coefficients()
+        for g, w, nm in zip((n_t, n_e, n_p), fac.update_coefficients(train, theta, eta, pr, pairs),
+                            ("n_theta", "n_eta", "n_pr")):
+            assert rel_err(g, w) < TOL_STEP, (nm, rel_err(g, w))
+            assert_elementwise(g, w, nm)
+        # ... and two blocks against the dense oracle itself (rows of 40 users / of 3 items are complete)
         sub = train[train[:, 0] < 40]
         assert rel_err(n_t[:40], orc.update_coefficients(sub, theta, eta, pr)[0][:40]) < TOL_STEP
         sub = train[train[:, 1] < 3]
         assert rel_err(n_e[:3], orc.update_coefficients(sub, theta, eta, pr)[1][:3]) < TOL_STEP
         assert np.allclose(n_t.sum(1), d_u, rtol=1e-12) and np.allclose(n_e.sum(1), d_i, rtol=1e-12)
         assert np.allclose(n_p.sum(axis=(0, 1)), np.bincount(train[:, 2]), rtol=1e-11)
-        del n_t, n_e, theta, eta
+        del n_t, n_e
         em.iterate(2)
+        for _ in range(2):
+            theta, eta, pr = fac.em_step(train, theta, eta, pr, d_u, d_i, pairs)
         liks = []
         first = None
         for s in range(8):
@@ -166,6 +236,13 @@ def test_c5_sampling8_full_size(hip, c5_train):
             liks.append(lik)
             if s == 0:
                 first = (t, e, p, lik)
+            if s == 6:
+                for g, w, nm in zip((t, e, p), (theta, eta, pr), ("theta", "eta", "pr")):
+                    assert rel_err(g, w) < TOL_FEW, (nm, rel_err(g, w))
+                    assert_elementwise(g, w, nm)
+                lik_f = float(fac.compute_likelihood(train, theta, eta, pr, pairs))
+                assert abs(lik - lik_f) <= 1e-11 * abs(lik_f), (lik, lik_f)
+        del theta, eta
         assert len(set(liks)) == 8
         # the same through a one-slot context: slot 0 of the batch is bitwise that
         em.set_slots(1)

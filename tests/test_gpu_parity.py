@@ -3,7 +3,7 @@ golden vectors.  Needs a real MI355X: run with ``-m gpu``."""
 import numpy as np
 import pytest
 
-from conftest import load_golden, rel_err
+from conftest import assert_elementwise, load_golden, rel_err
 from oracle import mmsbm_oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -99,12 +99,16 @@ def test_c1_500_iterations_vs_reference(hip):
         assert em.likelihood() == pytest.approx(float(g["c1_likelihood_at"][0]), rel=1e-12)
         for got, nm in zip(em.update_coefficients(), ("n_theta", "n_eta", "n_pr")):
             assert rel_err(got, g[f"c1_{nm}_1"]) < TOL_STEP
+            assert_elementwise(got, g[f"c1_{nm}_1"], nm, rtol=1e-12)
         done = 0
         for it in (1, 10, 500):
             em.iterate(it - done)
             done = it
             for got, nm in zip(em.get_params(), ("theta", "eta", "pr")):
                 assert rel_err(got, g[f"c1_{nm}_{it}"]) < TOL_LOOP, (it, nm)
+                # every entry on its own scale (p entries of this run go down to 1e-251):
+                # max-norm alone would not see an entry of 1e-20 that is off by a factor of ten
+                assert_elementwise(got, g[f"c1_{nm}_{it}"], f"{nm} after {it} iterations")
         assert em.likelihood() == pytest.approx(-9.470339454833308, rel=1e-9)
 
 
@@ -253,6 +257,9 @@ def test_c2_50_iterations_sampled_entries_and_argmax(hip):
         assert rel_err(t[g["ut"], g["kt"]], g[f"theta_s_{it}"]) < TOL_LOOP, it
         assert rel_err(e[g["ie"], g["le"]], g[f"eta_s_{it}"]) < TOL_LOOP, it
         assert rel_err(p, g[f"pr_{it}"]) < TOL_LOOP, it
+        assert_elementwise(t[g["ut"], g["kt"]], g[f"theta_s_{it}"], f"theta entries after {it}")
+        assert_elementwise(e[g["ie"], g["le"]], g[f"eta_s_{it}"], f"eta entries after {it}")
+        assert_elementwise(p, g[f"pr_{it}"], f"p after {it}")
         assert rel_err(t.sum(0), g[f"theta_colsum_{it}"]) < TOL_LOOP
         assert ctx.likelihood() == pytest.approx(float(g["likelihood_at"][(1, 10, 50).index(it)]), rel=1e-9)
     pdist = ctx.prod_dist(train)
@@ -323,11 +330,13 @@ def test_c5_shape_small(hip):
         want = orc.update_coefficients(data, theta, eta, pr)
         for got, w, nm in zip(em.update_coefficients(), want, ("n_theta", "n_eta", "n_pr")):
             assert rel_err(got, w) < TOL_STEP, nm
+            assert_elementwise(got, w, nm, rtol=1e-12)
         em.iterate(5)
         for _ in range(5):
             theta, eta, pr = orc.em_step(data, theta, eta, pr, d_u, d_i)
         for got, w, nm in zip(em.get_params(), (theta, eta, pr), ("theta", "eta", "pr")):
             assert rel_err(got, w) < 1e-11, nm
+            assert_elementwise(got, w, nm)
         assert em.likelihood() == pytest.approx(float(orc.compute_likelihood(data, theta, eta, pr)), rel=1e-11)
 
 
@@ -999,6 +1008,7 @@ def test_pair_stage_on_the_matrix_cores(hip, k, l, forced):
                 if on:
                     for got, w, nm in zip(em.update_coefficients(), want, ("n_theta", "n_eta", "n_pr")):
                         assert rel_err(got, w) < TOL_STEP, (swap, nm)
+                        assert_elementwise(got, w, f"{nm} (swap {swap})", rtol=1e-12)
                 em.iterate(3)
                 outs[on] = [em.select(s).get_params() for s in range(2)]
                 if on:
@@ -1042,6 +1052,7 @@ def test_pair_stage_on_the_matrix_cores_blocked(hip, k, l, mode):
                 if on:
                     for got, w, nm in zip(em.update_coefficients(), want, ("n_theta", "n_eta", "n_pr")):
                         assert rel_err(got, w) < TOL_STEP, (swap, nm)
+                        assert_elementwise(got, w, f"{nm} (swap {swap})", rtol=1e-12)
                 em.iterate(2)
                 outs[on] = [em.select(s_).get_params() for s_ in range(2)]
                 if on:

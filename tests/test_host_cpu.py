@@ -185,15 +185,20 @@ PREDICT_WORKER = textwrap.dedent("""
     g = load_golden("g2_c1_sampling3")
     train, test = g["train"], g["train"][::3]
     model = host.MMSBM(2, 2, iterations=10, sampling=3, seed=1)
-    best, best_lik, liks = restarts.fit_distributed(model, train, gather=False, device=device)
-    assert [r for r in model._restart_ids] == ([0, 2] if rank == 0 else [1])
-    assert len(model.results) == len(model._restart_ids)          # nobody holds the other rank's parameters
+    gather = {gather}
+    best, best_lik, liks = restarts.fit_distributed(model, train, gather=gather, device=device)
+    if gather:    # every rank holds all three restarts: each must still be counted ONCE in the mean
+        assert list(model._restart_ids) == [0, 1, 2] and len(model.results) == 3
+    else:
+        assert [r for r in model._restart_ids] == ([0, 2] if rank == 0 else [1])
+        assert len(model.results) == len(model._restart_ids)      # nobody holds the other rank's parameters
     matrix = restarts.predict_distributed(model, test, device=device)
     # the same three restarts in ONE process
     solo = host.MMSBM(2, 2, iterations=10, sampling=3, seed=1)
     solo.fit_encoded(train)
     want, _, per_run = solo._predict_runs(test)
     assert np.allclose(matrix, want, rtol=1e-14, atol=0), np.max(np.abs(matrix - want))
+    assert np.allclose(matrix.sum(axis=1), 1.0, atol=1e-12)       # a mean of distributions, not a multiple of it
     assert model.run_stats == per_run
     b = int(np.argmax([st["accuracy"] for st in per_run]))
     assert np.array_equal(model.theta.values, solo.results[b]["theta"])    # broadcast from its owner
@@ -206,11 +211,14 @@ PREDICT_WORKER = textwrap.dedent("""
 """)
 
 
-def test_two_rank_gloo_predict_without_gathering_parameters(tmp_path):
+@pytest.mark.parametrize("gather", [False, True])
+def test_two_rank_gloo_predict_without_gathering_parameters(tmp_path, gather):
     """restarts.predict_distributed: each rank scores ITS restarts, one all-reduce(SUM) of the (M, R) matrix;
-    equals the one-process predict of the same restarts; the best-accuracy restart's objects are broadcast."""
+    equals the one-process predict of the same restarts; the best-accuracy restart's objects are broadcast.
+    After fit_distributed(gather=True) every rank holds every restart: each is still counted once (the
+    lowest rank holding it scores it), so the matrix is the mean and its rows sum to 1."""
     script = tmp_path / "predict_worker.py"
-    script.write_text(PREDICT_WORKER.format(root=ROOT))
+    script.write_text(PREDICT_WORKER.format(root=ROOT, gather=gather))
     port = _free_port()
     procs = []
     for rank in range(2):

@@ -3,7 +3,8 @@ reference (tests/golden/make_golden.py).  CPU only."""
 import numpy as np
 import pytest
 
-from conftest import load_golden, rel_err
+from conftest import elem_rel_err, load_golden, rel_err
+from oracle import mmsbm_factorised as fac
 from oracle import mmsbm_oracle as orc
 
 
@@ -123,3 +124,59 @@ def test_g5_c2_sampled_entries():
         assert rel_err(t[g["ut"], g["kt"]], g[f"theta_s_{it}"]) < 1e-13
         assert rel_err(e[g["ie"], g["le"]], g[f"eta_s_{it}"]) < 1e-13
         assert rel_err(p, g[f"pr_{it}"]) < 1e-13
+
+
+# ---- the factorised checker (oracle/mmsbm_factorised.py): pinned to the dense oracle above ------------------
+FAC_TOL = 1e-13
+
+
+def _pin_factorised(train, k, l, seed, iters):
+    n_u, n_i, n_r = (int(train[:, j].max()) + 1 for j in range(3))
+    d_u, d_i = orc.degrees(train, n_u, n_i)
+    theta, eta, pr = orc.init_params(orc.child_seeds(seed, 1)[0], n_u, n_i, n_r, k, l, d_u, d_i)
+    pairs = fac.Pairs(train, n_u, n_i, n_r)
+    assert pairs.n_pairs == len(set(zip(train[:, 1].tolist(), train[:, 2].tolist())))
+    for g, w, nm in zip(fac.update_coefficients(train, theta, eta, pr, pairs),
+                        orc.update_coefficients(train, theta, eta, pr), ("n_theta", "n_eta", "n_pr")):
+        assert rel_err(g, w) < FAC_TOL and elem_rel_err(g, w) < FAC_TOL, (nm, rel_err(g, w), elem_rel_err(g, w))
+    ft, fe, fp = theta, eta, pr
+    for _ in range(iters):
+        theta, eta, pr = orc.em_step(train, theta, eta, pr, d_u, d_i)
+        ft, fe, fp = fac.em_step(train, ft, fe, fp, d_u, d_i, pairs)
+    for g, w, nm in zip((ft, fe, fp), (theta, eta, pr), ("theta", "eta", "pr")):
+        assert rel_err(g, w) < 20 * FAC_TOL and elem_rel_err(g, w) < 1e-11, (nm, rel_err(g, w), elem_rel_err(g, w))
+    lik_f, lik_o = fac.compute_likelihood(train, theta, eta, pr, pairs), orc.compute_likelihood(train, theta, eta, pr)
+    assert abs(lik_f - lik_o) <= FAC_TOL * abs(lik_o), (lik_f, lik_o)
+    pd_f, pd_o = fac.prod_dist(train[:500], theta, eta, pr), orc.prod_dist(train[:500], theta, eta, pr)
+    assert rel_err(pd_f, pd_o) < FAC_TOL
+
+
+def test_factorised_checker_pinned_on_g4():
+    g = load_golden("g4_2k_k10")
+    _pin_factorised(g["train"], 10, 10, seed=0, iters=5)
+    # ... and against the reference's own numbers for that fixture, not only the oracle's
+    train = g["train"]
+    d_u, d_i = orc.degrees(train)
+    start = orc.init_params(orc.child_seeds(0, 1)[0], len(d_u), len(d_i), 5, 10, 10, d_u, d_i)
+    for got, nm in zip(fac.update_coefficients(train, *start), ("n_theta_1", "n_eta_1", "n_pr_1")):
+        assert elem_rel_err(got, g[nm]) < FAC_TOL, nm
+
+
+@pytest.mark.slow
+def test_factorised_checker_pinned_on_c2():
+    train = orc.synthetic_triples(100_000, 10_000, 5_000, 5, seed=0)
+    _pin_factorised(train, 10, 10, seed=0, iters=3)
+
+
+def test_factorised_checker_edge_cases():
+    """Zero rows of p, duplicate triples, s_n < eps (every element clamped) and a mix: the numerators and
+    the reference's likelihood formula with its clamps."""
+    g = load_golden("edge_cases")
+    for tag in ("zero", "dup", "tiny", "mix"):
+        args = (g[f"{tag}_data"], g[f"{tag}_theta"], g[f"{tag}_eta"], g[f"{tag}_pr"])
+        for got, nm in zip(fac.update_coefficients(*args), ("n_theta", "n_eta", "n_pr")):
+            assert np.allclose(got, g[f"{tag}_{nm}"], rtol=1e-12, atol=1e-300), (tag, nm)
+    for tag in ("tiny", "mix"):
+        args = (g[f"{tag}_data"], g[f"{tag}_theta"], g[f"{tag}_eta"], g[f"{tag}_pr"])
+        lik = fac.compute_likelihood(*args)
+        assert abs(lik - g[f"{tag}_likelihood"]) <= 1e-13 * abs(g[f"{tag}_likelihood"]), tag
