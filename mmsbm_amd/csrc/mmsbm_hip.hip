@@ -54,6 +54,7 @@
 #include "pair_block.hpp"
 #include "eta_p.hpp"
 #include "once_kernels.hpp"
+#include "lik_fact.hpp"
 #include "context.hpp"
 #include "pair_big.hpp"
 #include "stages.hpp"
@@ -584,7 +585,7 @@ bool lik_fast_tile_lds(const mmsbm_hip_ctx *c) {
 }
 bool lik_fast_usable(const mmsbm_hip_ctx *c) {
   const size_t lds = lik_fast_tile_lds(c) ? 2 * static_cast<size_t>(c->kp) * c->lp * sizeof(double) : 0;
-  return c->lik_fast && c->lp <= 160 && c->n_lik_units > 0 && lds <= kLdsMax - 4096;
+  return c->lik_mode >= 1 && c->lp <= 160 && c->n_lik_units > 0 && lds <= kLdsMax - 4096;
 }
 // likelihood of the selected slot through the logarithm tables; returns the number of partial sums
 int likelihood_fast(mmsbm_hip_ctx *c) {
@@ -647,12 +648,109 @@ int likelihood_fast(mmsbm_hip_ctx *c) {
 }  // namespace
 
 namespace {
+// ---- the likelihood through the factorisation (lik_fact.hpp): log tables, per-pair D tables and bounds, the
+// pair-order pass, then the mixed rows element by element.  Returns the number of partial sums.
+int lik_rows_g(const mmsbm_hip_ctx *c) {
+  int G = c->lp <= 20 ? 1 : (c->lp <= 40 ? 2 : 4);
+  if (c->lik_g > 0) G = c->lik_g;
+  while (G < 8 && (c->lp + G - 1) / G > 20) G *= 2;
+  return G;
+}
+size_t lik_rows_lds(const mmsbm_hip_ctx *c) {
+  const int tpb = kLikThreads / lik_rows_g(c);
+  return (2 * static_cast<size_t>(c->kp) * c->lp + 2 * static_cast<size_t>(tpb) * c->kp) * sizeof(double);
+}
+bool lik_fact_usable(const mmsbm_hip_ctx *c) {
+  return c->lik_mode == 2 && c->lp <= 160 && c->n_lik_units > 0 && c->n_pairs > 0 && lik_rows_lds(c) <= kLdsMax - 4096;
+}
+int likelihood_factorised(mmsbm_hip_ctx *c) {
+  const int cur = c->cur, sl = c->sel;
+  hipStream_t st = c->stream;
+  const size_t nt = static_cast<size_t>(c->n_users) * c->kp, ne = static_cast<size_t>(c->n_items) * c->lp;
+  const size_t np = static_cast<size_t>(c->n_ratings) * c->kp * c->lp, nq = static_cast<size_t>(c->n_pairs) * c->kp;
+  const size_t n_obs = static_cast<size_t>(c->n_obs);
+  auto need = [](DevBuf<double> &b, size_t n) { if (b.count < n) b.alloc(n); };
+  need(c->lg_theta, nt); need(c->lg_eta, ne); need(c->lg_p, np);
+  need(c->lk_etaxl, ne); need(c->lk_ptxl, np); need(c->lk_d1, nq); need(c->lk_d2, nq);
+  need(c->lk_eta_mm, 2 * static_cast<size_t>(c->n_items)); need(c->lk_p_mm, 2 * static_cast<size_t>(c->n_ratings));
+  need(c->lk_bounds, 2 * static_cast<size_t>(c->n_pairs)); need(c->lk_ls, n_obs);
+  if (c->lk_flag.count < n_obs) c->lk_flag.alloc(n_obs);
+  if (c->rating_off_dev.count != c->lay.rating_off.size()) {
+    c->rating_off_dev.upload(c->lay.rating_off, st);
+    HIP_CHECK(hipStreamSynchronize(st));
+  }
+  auto blocks = [](size_t n) { return static_cast<unsigned>((n + kBlock - 1) / kBlock); };
+  const RowTab th = theta_tab(c, cur);
+  const RowTab lth{c->lg_theta.ptr, c->lg_theta.ptr + static_cast<size_t>(c->n_users) * th.mw, th.mw, th.tw,
+                   th.mw, th.tw, 0, 0};  // main + tail like theta, one slot
+  const double *eta = c->eta[cur].at(sl), *p = c->p[cur].at(sl), *pt = c->pt[cur].at(sl);
+  if (nt > 0) log_rows_kernel<<<blocks(nt), kBlock, 0, st>>>(th, lth, static_cast<size_t>(c->n_users), c->kp);
+  if (ne > 0) {
+    log_table_kernel<<<blocks(ne), kBlock, 0, st>>>(eta, c->lg_eta.ptr, ne);
+    xlogx_table_kernel<<<blocks(ne), kBlock, 0, st>>>(eta, c->lk_etaxl.ptr, ne);
+    row_minmax_kernel<<<blocks(c->n_items), kBlock, 0, st>>>(eta, c->lk_eta_mm.ptr, c->n_items, c->l, c->lp);
+  }
+  log_table_kernel<<<blocks(np), kBlock, 0, st>>>(p, c->lg_p.ptr, np);
+  xlogx_table_kernel<<<blocks(np), kBlock, 0, st>>>(pt, c->lk_ptxl.ptr, np);
+  tile_minmax_kernel<<<c->n_ratings, kBlock, 0, st>>>(p, c->lk_p_mm.ptr, c->k, c->l, c->kp, c->lp);
+  {
+    int most = 0;
+    for (int r = 0; r < c->n_ratings; ++r) most = std::max(most, c->lay.rating_off[r + 1] - c->lay.rating_off[r]);
+    const dim3 grid(blocks(static_cast<size_t>(most)), static_cast<unsigned>(c->n_ratings), 1);
+    pair_bounds_kernel<<<grid, kBlock, 0, st>>>(c->rating_off_dev.ptr, c->pair_item.ptr, c->lk_eta_mm.ptr,
+                                                c->lk_p_mm.ptr, c->lk_bounds.ptr);
+  }
+  HIP_CHECK(hipGetLastError());
+  // D = P (eta log eta) + (P log P) eta: the A launch's mat-vec twice, other inputs
+  const MatvecOverride o1{c->lk_etaxl.ptr, pt, c->lk_d1.ptr}, o2{eta, c->lk_ptxl.ptr, c->lk_d2.ptr};
+  stage_matvec_a(c, cur, cur, false, &o1);
+  stage_matvec_a(c, cur, cur, false, &o2);
+  // the pair-order pass
+  const bool items = !c->lay.pair_work.items.empty();
+  const int per = kBlock / group_lanes(c->code_k);
+  const int nseg = items ? static_cast<int>(c->lay.pair_work.items.size()) : c->n_pairs;
+  const int nb1 = (nseg + per - 1) / per, nb2 = c->n_lik_units;
+  if (c->lik_part.count < static_cast<size_t>(nb1 + nb2)) c->lik_part.alloc(static_cast<size_t>(nb1 + nb2));
+  LikPassArgs la{a_tab(c, cur), c->lk_d1.ptr, c->lk_d2.ptr, c->lk_bounds.ptr, th, c->pair_off.ptr, c->pair_user.ptr,
+                 items ? c->pair_items.ptr : nullptr, nseg, c->k, c->l, c->lk_ls.ptr, c->lk_flag.ptr, c->lik_part.ptr};
+#define CALL(G, V) lik_pass_kernel<G, V, 4><<<nb1, kBlock, 0, st>>>(la, c->kp)
+  DISPATCH_GV(c->code_k, CALL);
+#undef CALL
+  HIP_CHECK(hipGetLastError());
+  // the mixed rows
+  const int G = lik_rows_g(c);
+  const int LW = ((c->lp + G - 1) / G + 3) / 4 * 4;
+  const size_t lds = lik_rows_lds(c);
+#define ROWS_GO(LW_, G_)                                                                           \
+  allow_big_lds(lik_rows_kernel<LW_, G_>, lds);                                                    \
+  lik_rows_kernel<LW_, G_><<<nb2, kLikThreads, lds, st>>>(                                         \
+      c->lik_units.ptr, c->pair_off.ptr, c->pair_user.ptr, c->pair_item.ptr, th, lth, eta,         \
+      c->lg_eta.ptr, p, c->lg_p.ptr, c->lk_bounds.ptr, c->lk_ls.ptr, c->lk_flag.ptr,               \
+      c->lik_part.ptr + nb1, c->k, c->l, c->kp, c->lp)
+#define ROWS_LW(G_)                                                                                \
+  do {                                                                                             \
+    switch (LW) {                                                                                  \
+      case 4: ROWS_GO(4, G_); break;                                                               \
+      case 8: ROWS_GO(8, G_); break;                                                               \
+      case 12: ROWS_GO(12, G_); break;                                                             \
+      case 16: ROWS_GO(16, G_); break;                                                             \
+      default: ROWS_GO(20, G_); break;                                                             \
+    }                                                                                              \
+  } while (0)
+  if (G == 1) ROWS_LW(1); else if (G == 2) ROWS_LW(2); else if (G == 4) ROWS_LW(4); else ROWS_LW(8);
+#undef ROWS_LW
+#undef ROWS_GO
+  return nb1 + nb2;
+}
+
 // likelihood of the selected slot (the caller holds a OneSlot): kernels onto the context's stream, no wait;
 // returns the number of partial sums likelihood_finish adds up
 int likelihood_enqueue(mmsbm_hip_ctx *ctx) {
   const int cur = ctx->cur, sl = ctx->sel;
   int nb;
-  if (lik_fast_usable(ctx)) {
+  if (lik_fact_usable(ctx)) {
+    nb = likelihood_factorised(ctx);
+  } else if (lik_fast_usable(ctx)) {
     nb = likelihood_fast(ctx);
   } else {
     const size_t lik_lds = static_cast<size_t>(ctx->kp + ctx->lp) * kLikThreads * sizeof(double);
@@ -1074,8 +1172,10 @@ int mmsbm_hip_set_option(mmsbm_hip_ctx *ctx, const char *name, double value) {
 
     } else if (key == "slot_waves") {  // 0: restart slots as separate workgroups (blockIdx.y) in the triple passes
       ctx->slot_waves = value != 0.0;
-    } else if (key == "lik_fast") {
-      ctx->lik_fast = value != 0.0;
+    } else if (key == "lik_fast") {  // 0: a logarithm per element; 1: logarithm tables, every element (round 2);
+                                     // 2: through the factorisation, element work for the mixed rows only
+      if (value != 0.0 && value != 1.0 && value != 2.0) throw std::invalid_argument("lik_fast: 0, 1 or 2");
+      ctx->lik_mode = static_cast<int>(value);
     } else if (key == "lik_g") {
       const int g = static_cast<int>(value);
       if (g != 0 && g != 1 && g != 2 && g != 4 && g != 8) throw std::invalid_argument("lik_g: 0, 1, 2, 4 or 8");
@@ -1117,7 +1217,7 @@ int mmsbm_hip_get_option(const mmsbm_hip_ctx *ctx, const char *name, double *val
     else if (key == "seg_batch") *value = ctx->seg_batch;
     else if (key == "wide") *value = ctx->wide;
     else if (key == "slot_waves") *value = ctx->slot_waves;
-    else if (key == "lik_fast") *value = ctx->lik_fast;
+    else if (key == "lik_fast") *value = ctx->lik_mode;
     else if (key == "lik_g") *value = ctx->lik_g;
     else if (key == "ranges_pairs") *value = ctx->ranges_pairs;   // read-only: XCD-local work lists,
     else if (key == "ranges_users") *value = ctx->ranges_users;   // ranges per pass (1 = off)

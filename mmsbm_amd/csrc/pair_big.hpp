@@ -313,23 +313,15 @@ __global__ __launch_bounds__(NT, NT == 512 ? MMSBM_MFMA_WPE : 2) void pair_mfma_
 #pragma unroll
     for (int n = 0; n < TC; ++n) acc_t[n] = mfma_d4{0.0, 0.0, 0.0, 0.0};
     if (tn0 < nto) {
-      // (two steps per trip, written out: `#pragma unroll 2` on this run-time trip count was not honoured --
-      // -Wpass-failed -- so the operands of step s + 1 were not fetched while step s multiplied)
-#define MFMA_T_STEP(S)                                                                                   \
-  do {                                                                                                   \
-    const double x = cst[(4 * (S) + lk) * CS + trow0 + li];                                              \
-    const double *trow = tile_l + (4 * (S) + lk) * doutp;                                                \
-    _Pragma("unroll") for (int n = 0; n < TC; ++n) /* (a column tile beyond Dout repeats the last column and is never stored) */ \
-      acc_t[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(x, trow[bcol[n]], acc_t[n], 0, 0, 0);              \
-  } while (0)
-      const int ns = dinp / 4;
-      int s = 0;
-      for (; s + 2 <= ns; s += 2) {
-        MFMA_T_STEP(s);
-        MFMA_T_STEP(s + 1);
+      // (no unroll pragma: `#pragma unroll 2` on this run-time trip count was never honoured -- -Wpass-failed --
+      // and two steps per trip written out by hand are SLOWER: C5's T+S launch 366 -> 434 us, round 3)
+      for (int s = 0; s < dinp / 4; ++s) {
+        const double x = cst[(4 * s + lk) * CS + trow0 + li];
+        const double *trow = tile_l + (4 * s + lk) * doutp;
+#pragma unroll
+        for (int n = 0; n < TC; ++n)  // (a column tile beyond Dout repeats the last column and is never stored)
+          acc_t[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(x, trow[bcol[n]], acc_t[n], 0, 0, 0);
       }
-      if (s < ns) MFMA_T_STEP(s);
-#undef MFMA_T_STEP
     }
     STAMP(6);
 #pragma unroll
@@ -496,22 +488,12 @@ __global__ __launch_bounds__(kPairBlockMax, 4) void mfma_rows_kernel(PairBlockAr
           ROWS_FETCH_T(kb0 + kMfmaBlk);
           ROWS_FETCH_X(kb0 + kMfmaBlk, 0);
         }
-        {  // (two steps per trip, written out: see pair_mfma_kernel)
-#define ROWS_STEP(S)                                                                                     \
-  do {                                                                                                   \
-    const double x = cst[(4 * (S) + lk) * CS + trow0 + li];                                              \
-    const double *trow = tile_b + (4 * (S) + lk) * kMfmaBlk;                                             \
-    _Pragma("unroll") for (int n = 0; n < 2; ++n)                                                        \
-      acc[u][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(x, trow[bcol[n]], acc[u][n], 0, 0, 0);            \
-  } while (0)
-          const int ns = kbw / 4;
-          int s = 0;
-          for (; s + 2 <= ns; s += 2) {
-            ROWS_STEP(s);
-            ROWS_STEP(s + 1);
-          }
-          if (s < ns) ROWS_STEP(s);
-#undef ROWS_STEP
+        for (int s = 0; s < kbw / 4; ++s) {  // (no unroll pragma: see pair_mfma_kernel)
+          const double x = cst[(4 * s + lk) * CS + trow0 + li];
+          const double *trow = tile_b + (4 * s + lk) * kMfmaBlk;
+#pragma unroll
+          for (int n = 0; n < 2; ++n)
+            acc[u][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(x, trow[bcol[n]], acc[u][n], 0, 0, 0);
         }
       }
     }

@@ -14,7 +14,7 @@ mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
 bench="python3 $root/bench.py --config $config --steps $steps --warmup 20 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof_${tag}_trace" -- $bench > "$out/prof_${tag}_trace.log" 2>&1 || exit 1
-short="python3 $root/bench.py --config $config --steps 20 --warmup 2 --no-cpu-baseline --profile-iters 2"
+short="python3 $root/bench.py --config $config --steps 20 --warmup 2 --no-cpu-baseline --profile-iters 2 --steady-steps 0"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/prof_${tag}_fetch" -- $short > "$out/prof_${tag}_fetch.log" 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/prof_${tag}_write" -- $short > "$out/prof_${tag}_write.log" 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$out/prof_${tag}_l2" -- $short > "$out/prof_${tag}_l2.log" 2>&1 || exit 1

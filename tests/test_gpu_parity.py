@@ -861,6 +861,65 @@ def test_likelihood_kernels_agree_with_the_reference_formula(hip, k, l):
             for g in (1, 2, 4, 8):
                 em.set_option("lik_g", g)
                 assert em.likelihood() == pytest.approx(want, rel=1e-12), g
+            em.set_option("lik_g", 0)
+            em.set_option("lik_fast", 2)       # through the factorisation (the default): live / dead / mixed rows
+            assert em.get_option("lik_fast") == 2.0
+            assert em.likelihood() == pytest.approx(want, rel=1e-12)
+            for g in (1, 2, 4, 8):
+                em.set_option("lik_g", g)
+                assert em.likelihood() == pytest.approx(want, rel=1e-12), g
+
+
+@pytest.mark.parametrize("k,l,stage", [(20, 20, "early"), (20, 20, "late"), (20, 20, "border"), (50, 50, "late"),
+                                       (7, 70, "late"), (70, 9, "border"), (130, 40, "late"), (3, 5, "tiny")])
+def test_likelihood_through_the_factorisation_live_dead_and_mixed_rows(hip, k, l, stage):
+    """lik_fact.hpp: rows of a triple's K x L block are summed in factorised form when no element can be
+    clamped (live), counted when every element is (dead), and visited element by element otherwise (mixed).
+    early = a random start (everything live); late = concentrated memberships, most entries far below eps
+    (dead rows, a few mixed ones); border = entries scattered around eps / (eta p) so that the three classes
+    and the clamp inside mixed rows all occur in one triple; tiny = every s_n below eps.  Against the dense
+    oracle's src/expectation_maximization.py:157-167 at 1e-12, and against the element-wise device forms."""
+    rng = np.random.default_rng(k * 131 + l)
+    n_u, n_i, n_r, n = 120, 80, 5, 4000
+    data = np.stack([rng.integers(0, n_u, n), rng.integers(0, n_i, n), rng.integers(0, n_r, n)], axis=1).astype(np.int64)
+    d_u, d_i = orc.degrees(data, n_u, n_i)
+    theta, eta, pr = orc.init_params(3, n_u, n_i, n_r, k, l, d_u, d_i)
+    if stage == "early":
+        theta, eta, pr = orc.em_step(data, theta, eta, pr, d_u, d_i)
+    elif stage == "late":       # memberships concentrated on a few groups, the rest decayed towards zero
+        theta = theta ** rng.integers(1, 40, theta.shape)
+        eta = eta ** rng.integers(1, 40, eta.shape)
+        theta /= theta.sum(1, keepdims=True); eta /= eta.sum(1, keepdims=True)
+        pr = orc.normalize_with_self(pr ** rng.integers(1, 12, pr.shape))
+    elif stage == "border":     # products theta eta p scattered over a few decades either side of eps
+        theta = 10.0 ** rng.uniform(-9, -3, theta.shape)
+        eta = 10.0 ** rng.uniform(-9, -3, eta.shape)
+        theta[rng.random(theta.shape) < 0.1] = 0.0
+    else:                       # tiny: s_n < eps for every triple
+        theta, eta = theta * 1e-110, eta * 1e-110
+    want = float(orc.compute_likelihood(data, theta, eta, pr))
+    om = orc.compute_omegas(data, theta, eta, pr)
+    clamped_share = float(np.mean(om < orc.EPS))
+    if stage == "early":
+        assert clamped_share == 0.0
+    elif stage in ("late", "border"):
+        assert 0.05 < clamped_share < 0.999, clamped_share
+    for swap in (0, 1):
+        with make_ctx(hip, data, theta, eta, pr, swap_sides=swap) as em:
+            assert em.get_option("lik_fast") == 2.0
+            got = em.likelihood()
+            assert got == pytest.approx(want, rel=1e-12), (stage, swap, clamped_share)
+            em.set_option("lik_fast", 1)
+            assert em.likelihood() == pytest.approx(got, rel=1e-12)
+            em.set_option("lik_fast", 2)
+            assert em.likelihood() == got      # bitwise reproducible
+    # two restart slots with different parameters: the selected slot's tables are the ones that are read
+    theta2, eta2, pr2 = orc.init_params(4, n_u, n_i, n_r, k, l, d_u, d_i)
+    with hip.HipEM(data, k, l, n_u, n_i, n_r, slots=2) as em:
+        em.select(0).set_params(theta2, eta2, pr2)
+        em.select(1).set_params(theta, eta, pr)
+        assert em.select(1).likelihood() == pytest.approx(want, rel=1e-12)
+        assert em.select(0).likelihood() == pytest.approx(float(orc.compute_likelihood(data, theta2, eta2, pr2)), rel=1e-12)
 
 
 @pytest.mark.parametrize("k,l,swap", [(2, 4, 0), (20, 20, 0), (20, 20, 1), (7, 13, 1), (50, 36, 0), (1, 1, 0)])
