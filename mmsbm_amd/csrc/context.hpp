@@ -188,10 +188,7 @@ struct mmsbm_hip_ctx {
   SlotBuf theta[2], eta[2], p[2], pt[2], atab[2], ctab, ttab, partial, npr;
   DevBuf<double> lik_part;
   DevBuf<double> lg_theta, lg_eta, lg_p;  // logarithm tables of the selected slot (likelihood)
-  int lik_mode = 2;                       // option "lik_fast": 0 log per element, 1 log tables, 2 factorised (lik_fact.hpp)
-  DevBuf<double> lk_etaxl, lk_ptxl, lk_d1, lk_d2, lk_eta_mm, lk_p_mm, lk_bounds, lk_ls;  // likelihood_factorised scratch
-  DevBuf<unsigned char> lk_flag;
-  DevBuf<int32_t> rating_off_dev;
+  int lik_mode = 2;                       // option "lik_fast": 0 log per element, 1 log tables, 2 a wave per pair where it applies
   int lik_g = 0;                          // option "lik_g": lanes per triple (0 = automatic)
   PinBuf pin;  // host staging for set_params / get_params / update_coefficients
   // predict/score session (mmsbm_hip_predict_begin .. finish)

@@ -648,99 +648,43 @@ int likelihood_fast(mmsbm_hip_ctx *c) {
 }  // namespace
 
 namespace {
-// ---- the likelihood through the factorisation (lik_fact.hpp): log tables, per-pair D tables and bounds, the
-// pair-order pass, then the mixed rows element by element.  Returns the number of partial sums.
-int lik_rows_g(const mmsbm_hip_ctx *c) {
-  int G = c->lp <= 20 ? 1 : (c->lp <= 40 ? 2 : 4);
-  if (c->lik_g > 0) G = c->lik_g;
-  while (G < 8 && (c->lp + G - 1) / G > 20) G *= 2;
-  return G;
+// ---- the likelihood pair by pair (lik_fact.hpp): logarithm tables, then one wave per (item, rating) pair.
+// For rows of more than 32 groups (one column per lane: narrower rows would leave most of a wave idle), tiles
+// that fit the LDS beside their logarithms, and data with a few triples per pair (the pair's eta p products
+// are shared by four triples at a time).  Returns the number of partial sums.
+bool lik_pairs_usable(const mmsbm_hip_ctx *c) {
+  return c->lik_mode == 2 && c->lp > 32 && c->lp <= 192 && c->kp <= 192 && c->n_lik_units > 0 && c->n_pairs > 0 &&
+         2 * static_cast<size_t>(c->kp) * c->lp * sizeof(double) <= kLdsMax - 4096 &&
+         c->n_obs * 2 >= static_cast<int64_t>(c->n_pairs) * 5;
 }
-size_t lik_rows_lds(const mmsbm_hip_ctx *c) {
-  const int tpb = kLikThreads / lik_rows_g(c);
-  return (2 * static_cast<size_t>(c->kp) * c->lp + 2 * static_cast<size_t>(tpb) * c->kp) * sizeof(double);
-}
-bool lik_fact_usable(const mmsbm_hip_ctx *c) {
-  return c->lik_mode == 2 && c->lp <= 160 && c->n_lik_units > 0 && c->n_pairs > 0 && lik_rows_lds(c) <= kLdsMax - 4096;
-}
-int likelihood_factorised(mmsbm_hip_ctx *c) {
+int likelihood_pairs(mmsbm_hip_ctx *c) {
   const int cur = c->cur, sl = c->sel;
   hipStream_t st = c->stream;
   const size_t nt = static_cast<size_t>(c->n_users) * c->kp, ne = static_cast<size_t>(c->n_items) * c->lp;
-  const size_t np = static_cast<size_t>(c->n_ratings) * c->kp * c->lp, nq = static_cast<size_t>(c->n_pairs) * c->kp;
-  const size_t n_obs = static_cast<size_t>(c->n_obs);
-  auto need = [](DevBuf<double> &b, size_t n) { if (b.count < n) b.alloc(n); };
-  need(c->lg_theta, nt); need(c->lg_eta, ne); need(c->lg_p, np);
-  need(c->lk_etaxl, ne); need(c->lk_ptxl, np); need(c->lk_d1, nq); need(c->lk_d2, nq);
-  need(c->lk_eta_mm, 2 * static_cast<size_t>(c->n_items)); need(c->lk_p_mm, 2 * static_cast<size_t>(c->n_ratings));
-  need(c->lk_bounds, 2 * static_cast<size_t>(c->n_pairs)); need(c->lk_ls, n_obs);
-  if (c->lk_flag.count < n_obs) c->lk_flag.alloc(n_obs);
-  if (c->rating_off_dev.count != c->lay.rating_off.size()) {
-    c->rating_off_dev.upload(c->lay.rating_off, st);
-    HIP_CHECK(hipStreamSynchronize(st));
-  }
+  const size_t np = static_cast<size_t>(c->n_ratings) * c->kp * c->lp;
+  if (c->lg_theta.count < 2 * nt) c->lg_theta.alloc(2 * nt);  // here: (theta, log theta) pairs, plain rows
+  if (c->lg_eta.count < ne) c->lg_eta.alloc(ne);
+  if (c->lg_p.count < np) c->lg_p.alloc(np);
   auto blocks = [](size_t n) { return static_cast<unsigned>((n + kBlock - 1) / kBlock); };
   const RowTab th = theta_tab(c, cur);
-  const RowTab lth{c->lg_theta.ptr, c->lg_theta.ptr + static_cast<size_t>(c->n_users) * th.mw, th.mw, th.tw,
-                   th.mw, th.tw, 0, 0};  // main + tail like theta, one slot
-  const double *eta = c->eta[cur].at(sl), *p = c->p[cur].at(sl), *pt = c->pt[cur].at(sl);
-  if (nt > 0) log_rows_kernel<<<blocks(nt), kBlock, 0, st>>>(th, lth, static_cast<size_t>(c->n_users), c->kp);
-  if (ne > 0) {
-    log_table_kernel<<<blocks(ne), kBlock, 0, st>>>(eta, c->lg_eta.ptr, ne);
-    xlogx_table_kernel<<<blocks(ne), kBlock, 0, st>>>(eta, c->lk_etaxl.ptr, ne);
-    row_minmax_kernel<<<blocks(c->n_items), kBlock, 0, st>>>(eta, c->lk_eta_mm.ptr, c->n_items, c->l, c->lp);
-  }
+  double2 *tl = reinterpret_cast<double2 *>(c->lg_theta.ptr);
+  const double *eta = c->eta[cur].at(sl), *p = c->p[cur].at(sl);
+  if (nt > 0) theta_log_pairs_kernel<<<blocks(nt), kBlock, 0, st>>>(th, tl, static_cast<size_t>(c->n_users), c->kp);
+  if (ne > 0) log_table_kernel<<<blocks(ne), kBlock, 0, st>>>(eta, c->lg_eta.ptr, ne);
   log_table_kernel<<<blocks(np), kBlock, 0, st>>>(p, c->lg_p.ptr, np);
-  xlogx_table_kernel<<<blocks(np), kBlock, 0, st>>>(pt, c->lk_ptxl.ptr, np);
-  tile_minmax_kernel<<<c->n_ratings, kBlock, 0, st>>>(p, c->lk_p_mm.ptr, c->k, c->l, c->kp, c->lp);
-  {
-    int most = 0;
-    for (int r = 0; r < c->n_ratings; ++r) most = std::max(most, c->lay.rating_off[r + 1] - c->lay.rating_off[r]);
-    const dim3 grid(blocks(static_cast<size_t>(most)), static_cast<unsigned>(c->n_ratings), 1);
-    pair_bounds_kernel<<<grid, kBlock, 0, st>>>(c->rating_off_dev.ptr, c->pair_item.ptr, c->lk_eta_mm.ptr,
-                                                c->lk_p_mm.ptr, c->lk_bounds.ptr);
-  }
-  HIP_CHECK(hipGetLastError());
-  // D = P (eta log eta) + (P log P) eta: the A launch's mat-vec twice, other inputs
-  const MatvecOverride o1{c->lk_etaxl.ptr, pt, c->lk_d1.ptr}, o2{eta, c->lk_ptxl.ptr, c->lk_d2.ptr};
-  stage_matvec_a(c, cur, cur, false, &o1);
-  stage_matvec_a(c, cur, cur, false, &o2);
-  // the pair-order pass
-  const bool items = !c->lay.pair_work.items.empty();
-  const int per = kBlock / group_lanes(c->code_k);
-  const int nseg = items ? static_cast<int>(c->lay.pair_work.items.size()) : c->n_pairs;
-  const int nb1 = (nseg + per - 1) / per, nb2 = c->n_lik_units;
-  if (c->lik_part.count < static_cast<size_t>(nb1 + nb2)) c->lik_part.alloc(static_cast<size_t>(nb1 + nb2));
-  LikPassArgs la{a_tab(c, cur), c->lk_d1.ptr, c->lk_d2.ptr, c->lk_bounds.ptr, th, c->pair_off.ptr, c->pair_user.ptr,
-                 items ? c->pair_items.ptr : nullptr, nseg, c->k, c->l, c->lk_ls.ptr, c->lk_flag.ptr, c->lik_part.ptr};
-#define CALL(G, V) lik_pass_kernel<G, V, 4><<<nb1, kBlock, 0, st>>>(la, c->kp)
-  DISPATCH_GV(c->code_k, CALL);
-#undef CALL
-  HIP_CHECK(hipGetLastError());
-  // the mixed rows
-  const int G = lik_rows_g(c);
-  const int LW = ((c->lp + G - 1) / G + 3) / 4 * 4;
-  const size_t lds = lik_rows_lds(c);
-#define ROWS_GO(LW_, G_)                                                                           \
-  allow_big_lds(lik_rows_kernel<LW_, G_>, lds);                                                    \
-  lik_rows_kernel<LW_, G_><<<nb2, kLikThreads, lds, st>>>(                                         \
-      c->lik_units.ptr, c->pair_off.ptr, c->pair_user.ptr, c->pair_item.ptr, th, lth, eta,         \
-      c->lg_eta.ptr, p, c->lg_p.ptr, c->lk_bounds.ptr, c->lk_ls.ptr, c->lk_flag.ptr,               \
-      c->lik_part.ptr + nb1, c->k, c->l, c->kp, c->lp)
-#define ROWS_LW(G_)                                                                                \
-  do {                                                                                             \
-    switch (LW) {                                                                                  \
-      case 4: ROWS_GO(4, G_); break;                                                               \
-      case 8: ROWS_GO(8, G_); break;                                                               \
-      case 12: ROWS_GO(12, G_); break;                                                             \
-      case 16: ROWS_GO(16, G_); break;                                                             \
-      default: ROWS_GO(20, G_); break;                                                             \
-    }                                                                                              \
+  const int nb = c->n_lik_units;
+  if (c->lik_part.count < static_cast<size_t>(nb)) c->lik_part.alloc(static_cast<size_t>(nb));
+  const size_t lds = 2 * static_cast<size_t>(c->kp) * c->lp * sizeof(double);
+#define WAVE_GO(LW_)                                                                                 \
+  do {                                                                                               \
+    allow_big_lds(lik_wave_kernel<LW_>, lds);                                                        \
+    lik_wave_kernel<LW_><<<nb, kLikWaveThreads, lds, st>>>(                                          \
+        c->lik_units.ptr, c->pair_off.ptr, c->pair_user.ptr, c->pair_item.ptr, tl, a_tab(c, cur),    \
+        eta, c->lg_eta.ptr, p, c->lg_p.ptr, c->lik_part.ptr, c->k, c->l, c->kp, c->lp);              \
   } while (0)
-  if (G == 1) ROWS_LW(1); else if (G == 2) ROWS_LW(2); else if (G == 4) ROWS_LW(4); else ROWS_LW(8);
-#undef ROWS_LW
-#undef ROWS_GO
-  return nb1 + nb2;
+  if (c->lp <= 64) WAVE_GO(1); else if (c->lp <= 128) WAVE_GO(2); else WAVE_GO(3);
+#undef WAVE_GO
+  return nb;
 }
 
 // likelihood of the selected slot (the caller holds a OneSlot): kernels onto the context's stream, no wait;
@@ -748,8 +692,8 @@ int likelihood_factorised(mmsbm_hip_ctx *c) {
 int likelihood_enqueue(mmsbm_hip_ctx *ctx) {
   const int cur = ctx->cur, sl = ctx->sel;
   int nb;
-  if (lik_fact_usable(ctx)) {
-    nb = likelihood_factorised(ctx);
+  if (lik_pairs_usable(ctx)) {
+    nb = likelihood_pairs(ctx);
   } else if (lik_fast_usable(ctx)) {
     nb = likelihood_fast(ctx);
   } else {
@@ -1172,8 +1116,8 @@ int mmsbm_hip_set_option(mmsbm_hip_ctx *ctx, const char *name, double value) {
 
     } else if (key == "slot_waves") {  // 0: restart slots as separate workgroups (blockIdx.y) in the triple passes
       ctx->slot_waves = value != 0.0;
-    } else if (key == "lik_fast") {  // 0: a logarithm per element; 1: logarithm tables, every element (round 2);
-                                     // 2: through the factorisation, element work for the mixed rows only
+    } else if (key == "lik_fast") {  // 0: a logarithm per element; 1: logarithm tables, a group of lanes per triple
+                                     // (round 2); 2: where it applies a wave per pair (lik_fact.hpp), else as 1
       if (value != 0.0 && value != 1.0 && value != 2.0) throw std::invalid_argument("lik_fast: 0, 1 or 2");
       ctx->lik_mode = static_cast<int>(value);
     } else if (key == "lik_g") {

@@ -126,8 +126,8 @@ __global__ __launch_bounds__(kLikThreads) void likelihood_units_kernel(
 //   sum_{omega >= eps} omega (log omega - ls)  +  #{omega < eps} * eps (log eps - ls)
 // and log omega = log theta_k + log eta_l + log p_kl comes from tables of logarithms that
 // log_table_kernel fills once per evaluation (U*K + I*L + R*K*L logs instead of N*K*L).  One
-// pass gathers A = sum omega log omega, W = sum omega over the unclamped elements, their count
-// and s; ls enters at the end: A - ls W + count eps (log eps - ls).  The element sum is
+// pass gathers A = sum w max(log omega, log eps), W = sum w with w = max(omega, eps), and s; ls enters at the
+// end: A - ls W.  The element sum is
 // re-associated relative to the reference (agreement ~1e-15 relative), the formula is not
 // changed.  G lanes share a triple, each holding LW columns of the eta row and of its logarithms
 // in registers; the rating's tile (and its logarithms) is lane-uniform for G = 1 (scalar loads)
@@ -195,23 +195,26 @@ __global__ __launch_bounds__(kLikThreads) void likelihood_fast_kernel(
     const size_t urow = static_cast<size_t>(pair_user[nn]);
     const size_t irow = static_cast<size_t>(pair_item[ch.q_begin + lo]);
     double e[LW], le[LW];
+    int n_fake = 0;  // this lane's columns beyond L: they run on omega = 0, log omega = -inf and are taken off below
 #pragma unroll
-    for (int j = 0; j < LW; j += 2) {  // (columns past lp: any in-range address, masked below)
+    for (int j = 0; j < LW; j += 2) {  // (columns past lp: any in-range address)
       const int cc = min(LIK_COL(j), lp - 2);
       const double2 v = *reinterpret_cast<const double2 *>(eta + irow * lp + cc);
       const double2 lv = *reinterpret_cast<const double2 *>(leta + irow * lp + cc);
-      e[j] = v.x; e[j + 1] = v.y;
-      le[j] = lv.x; le[j + 1] = lv.y;
+      const bool r0 = LIK_COL(j) < l_groups, r1 = LIK_COL(j + 1) < l_groups;
+      e[j] = r0 ? v.x : 0.0; e[j + 1] = r1 ? v.y : 0.0;
+      le[j] = r0 ? lv.x : -INFINITY; le[j + 1] = r1 ? lv.y : -INFINITY;
+      n_fake += (r0 ? 0 : 1) + (r1 ? 0 : 1);
     }
-    double s = 0.0, a_sum = 0.0, w_sum = 0.0, clamped = 0.0;
+    // The clamp as two maxima (round 3): log is monotone, so with w = max(omega, eps) the element is
+    // w * max(log omega, log eps) - ls * w -- no compare, no select, no counter of clamped elements.
+    double s = 0.0, a_sum = 0.0, w_sum = 0.0;
     for (int k = 0; k < k_groups; ++k) {
       const double tk = *rowtab_ptr(theta, urow, k);
       const double ltk = *rowtab_ptr(ltheta, urow, k);
 #pragma unroll
       for (int j = 0; j < LW; ++j) {
-        const int l = LIK_COL(j);
-        const bool real = l < l_groups;
-        const int lc = min(l, lp - 1);
+        const int lc = min(LIK_COL(j), lp - 1);
         double pv, lpv;
         if (TLDS) {
           pv = lds[k * lp + lc];
@@ -220,20 +223,19 @@ __global__ __launch_bounds__(kLikThreads) void likelihood_fast_kernel(
           pv = gtile[k * lp + lc];
           lpv = gltile[k * lp + lc];
         }
-        const double w = (tk * e[j]) * pv;
-        const bool big = real && w >= kEps;
-        s += real ? w : 0.0;
-        a_sum += big ? w * ((ltk + le[j]) + lpv) : 0.0;
-        w_sum += big ? w : 0.0;
-        clamped += (real && !big) ? 1.0 : 0.0;
+        const double om = (tk * e[j]) * pv;
+        s += om;
+        const double w = fmax(om, kEps);
+        a_sum = fma(w, fmax((ltk + le[j]) + lpv, log_eps), a_sum);
+        w_sum += w;
       }
     }
     s = group_sum<G>(s);
     a_sum = group_sum<G>(a_sum);
     w_sum = group_sum<G>(w_sum);
-    clamped = group_sum<G>(clamped);
+    const double fake = static_cast<double>(group_sum<G>(static_cast<double>(n_fake * k_groups)));
     const double ls = log(fmax(s, kEps));
-    if (have && g == 0) total += (a_sum - ls * w_sum) + clamped * (kEps * (log_eps - ls));
+    if (have && g == 0) total += (a_sum - ls * w_sum) - fake * (kEps * (log_eps - ls));
   }
   red[tid] = total;
   __syncthreads();

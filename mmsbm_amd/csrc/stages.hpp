@@ -317,10 +317,7 @@ void stage_eta_p(mmsbm_hip_ctx *c, bool commit) {  // eta_new ; p_new, pT_new, r
 
 // A[q,:] from (eta, pT) of parameter slot `slot` into atab[a_slot] -- or, with `grid` set, the same
 // mat-vec over every (item, rating) combination into the plain table btab (prod_dist / predict)
-// (`ov`: the same mat-vec over the context's pairs with other inputs -- rows `in_tab` [I][lp], tiles [R][lp][kp]
-// -- into a plain table `out` [Q][kp]; one slot: the likelihood's D tables, lik_fact.hpp)
-struct MatvecOverride { const double *in_tab; const double *tiles; double *out; };
-void stage_matvec_a(mmsbm_hip_ctx *c, int slot, int a_slot, bool grid = false, const MatvecOverride *ov = nullptr) {
+void stage_matvec_a(mmsbm_hip_ctx *c, int slot, int a_slot, bool grid = false) {
   const int nb = grid ? c->grid_n_chunks : static_cast<int>(c->lay.mv_chunks.size());
   if (nb == 0) return;
   LaunchScope ls(c, K_MATVEC_A, true);
@@ -329,11 +326,6 @@ void stage_matvec_a(mmsbm_hip_ctx *c, int slot, int a_slot, bool grid = false, c
     pa.pair_item = c->grid_item.ptr; pa.chunks = c->grid_chunks.ptr;
     pa.out = c->btab.ptr; pa.out_tail = nullptr;
     pa.out_mw = pa.doutp; pa.out_rs_m = pa.doutp; pa.out_rs_t = 0; pa.bs_out = 0; pa.bs_out_t = 0;
-  }
-  if (ov) {
-    pa.in_tab = ov->in_tab; pa.tiles = ov->tiles; pa.out = ov->out; pa.out_tail = nullptr;
-    pa.out_mw = pa.doutp; pa.out_rs_m = pa.doutp; pa.out_rs_t = 0;
-    pa.bs_out = 0; pa.bs_out_t = 0; pa.bs_tiles = 0; pa.bs_in = 0;
   }
   if (c->mfma_big) {
     const int subs = (c->mv_chunk_pairs + kRowsUnits * kUnitPairs - 1) / (kRowsUnits * kUnitPairs);

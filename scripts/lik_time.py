@@ -32,9 +32,6 @@ for tag in sys.argv[1:] or ["c2", "c3"]:
         v = run("tables"); ref = v if n > 2_000_000 and its != 30 else ref
         print(f"      relative difference {abs(v - ref) / abs(ref):.2e}")
         ctx.set_option("lik_fast", 2)
-        for g in (0, 1, 2, 4, 8) if its == 30 else (0,):
-            ctx.set_option("lik_g", g)
-            v = run(f"factorised G={g}")
-            print(f"      relative difference {abs(v - ref) / abs(ref):.2e}")
-        ctx.set_option("lik_g", 0)
+        v = run("wave per pair")
+        print(f"      relative difference {abs(v - ref) / abs(ref):.2e}")
     mm._release()

@@ -862,7 +862,7 @@ def test_likelihood_kernels_agree_with_the_reference_formula(hip, k, l):
                 em.set_option("lik_g", g)
                 assert em.likelihood() == pytest.approx(want, rel=1e-12), g
             em.set_option("lik_g", 0)
-            em.set_option("lik_fast", 2)       # through the factorisation (the default): live / dead / mixed rows
+            em.set_option("lik_fast", 2)       # the default: a wave per pair where rows have more than 32 groups
             assert em.get_option("lik_fast") == 2.0
             assert em.likelihood() == pytest.approx(want, rel=1e-12)
             for g in (1, 2, 4, 8):
@@ -870,15 +870,18 @@ def test_likelihood_kernels_agree_with_the_reference_formula(hip, k, l):
                 assert em.likelihood() == pytest.approx(want, rel=1e-12), g
 
 
-@pytest.mark.parametrize("k,l,stage", [(20, 20, "early"), (20, 20, "late"), (20, 20, "border"), (50, 50, "late"),
-                                       (7, 70, "late"), (70, 9, "border"), (130, 40, "late"), (3, 5, "tiny")])
-def test_likelihood_through_the_factorisation_live_dead_and_mixed_rows(hip, k, l, stage):
-    """lik_fact.hpp: rows of a triple's K x L block are summed in factorised form when no element can be
-    clamped (live), counted when every element is (dead), and visited element by element otherwise (mixed).
-    early = a random start (everything live); late = concentrated memberships, most entries far below eps
-    (dead rows, a few mixed ones); border = entries scattered around eps / (eta p) so that the three classes
-    and the clamp inside mixed rows all occur in one triple; tiny = every s_n below eps.  Against the dense
-    oracle's src/expectation_maximization.py:157-167 at 1e-12, and against the element-wise device forms."""
+@pytest.mark.parametrize("k,l,stage", [(50, 50, "early"), (50, 50, "late"), (50, 50, "border"), (7, 70, "late"),
+                                       (70, 9, "border"), (130, 40, "late"), (40, 100, "border"), (12, 150, "late"),
+                                       (33, 64, "border"), (64, 33, "late"), (20, 20, "late"), (3, 5, "tiny"),
+                                       (50, 50, "tiny")])
+def test_likelihood_a_wave_per_pair(hip, k, l, stage):
+    """lik_fact.hpp: for rows of more than 32 groups a wave takes one (item, rating) pair and walks its triples
+    four at a time, theta through scalar loads, the clamp as two maxima, padding taken off in closed form
+    (1, 2 or 3 columns per lane; either side paired with the rating; narrower rows keep the round-2 kernel).
+    early = after one EM step (nothing clamped); late = concentrated memberships, most elements far below eps;
+    border = products scattered a few decades either side of eps, exact zeros among them; tiny = every s_n
+    below eps.  Against the dense oracle's src/expectation_maximization.py:157-167 at 1e-12 and against the
+    two element-wise device forms."""
     rng = np.random.default_rng(k * 131 + l)
     n_u, n_i, n_r, n = 120, 80, 5, 4000
     data = np.stack([rng.integers(0, n_u, n), rng.integers(0, n_i, n), rng.integers(0, n_r, n)], axis=1).astype(np.int64)
@@ -895,11 +898,12 @@ def test_likelihood_through_the_factorisation_live_dead_and_mixed_rows(hip, k, l
         theta = 10.0 ** rng.uniform(-9, -3, theta.shape)
         eta = 10.0 ** rng.uniform(-9, -3, eta.shape)
         theta[rng.random(theta.shape) < 0.1] = 0.0
+        eta[rng.random(eta.shape) < 0.05] = 0.0
+        pr[rng.random(pr.shape) < 0.05] = 0.0
     else:                       # tiny: s_n < eps for every triple
         theta, eta = theta * 1e-110, eta * 1e-110
     want = float(orc.compute_likelihood(data, theta, eta, pr))
-    om = orc.compute_omegas(data, theta, eta, pr)
-    clamped_share = float(np.mean(om < orc.EPS))
+    clamped_share = float(np.mean(orc.compute_omegas(data, theta, eta, pr) < orc.EPS))
     if stage == "early":
         assert clamped_share == 0.0
     elif stage in ("late", "border"):
@@ -910,6 +914,8 @@ def test_likelihood_through_the_factorisation_live_dead_and_mixed_rows(hip, k, l
             got = em.likelihood()
             assert got == pytest.approx(want, rel=1e-12), (stage, swap, clamped_share)
             em.set_option("lik_fast", 1)
+            assert em.likelihood() == pytest.approx(got, rel=1e-12)
+            em.set_option("lik_fast", 0)
             assert em.likelihood() == pytest.approx(got, rel=1e-12)
             em.set_option("lik_fast", 2)
             assert em.likelihood() == got      # bitwise reproducible
