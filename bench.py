@@ -170,16 +170,23 @@ def roofline_object(args, ctx, prof, n, k, l):
     # 8(d): per triple three int32 indices + one theta row + one eta-side row.  Every triple-level
     # index load and row gather of the iteration happens in seg_pass (its two passes), so that
     # launch is charged all of N (12 + 8K + 8L); the K*L*R tile bytes belong to the pair stage.
-    served = n * (12 + 8 * k + 8 * l) if dom == "seg_pass_kernel" else model_rd
+    # Small problems run two launches per iteration (fused_small.hpp), one triple pass in each: each is charged
+    # half of 8(d)'s bytes.
+    if dom == "seg_pass_kernel":
+        served, basis = n * (12 + 8 * k + 8 * l), ("SURVEY 8(d): N(12+8K+8L) -- all triple-level index loads and row "
+                                                   "gathers of the iteration are in this launch")
+    elif dom in ("pairs_fused_kernel", "tail_fused_kernel"):
+        served, basis = n * (12 + 8 * k + 8 * l) // 2, ("SURVEY 8(d): N(12+8K+8L) / 2 -- the two launches of a small "
+                                                        "problem's iteration hold one of the two triple passes each")
+    else:
+        served, basis = model_rd, "per-launch model (DESIGN.md section 4)"
     achieved = served / (dom_us * 1e-6) / 1e9
     resident = ctx.bytes_per_slot + 4 * (2 * n + 3 * ctx.n_pairs + ctx.n_users + ctx.n_items)
     out = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
            "frac": achieved / HBM_PEAK_GBPS,
            "frac_of_measured_copy_ceiling": achieved / HBM_MEASURED_GBPS,
            "algorithmic_bytes_per_launch": served,
-           "algorithmic_bytes_basis": ("SURVEY 8(d): N(12+8K+8L) -- all triple-level index loads and row "
-                                       "gathers of the iteration are in this launch" if dom == "seg_pass_kernel"
-                                       else "per-launch model (DESIGN.md section 4)"),
+           "algorithmic_bytes_basis": basis,
            "avg_launch_us": dom_us, "avg_launch_source": "HIP event pairs on the library's stream (bench.py, live)",
            "rocprof_avg_us": None, "rocprof_source": None,
            "algorithmic_bytes_model": model_rd,
@@ -315,6 +322,7 @@ def main():
                                    f"(sampling={world}), uniform generator seed 0, model seed 0",
                        "launch": "hipGraph replay" if args.graph else "eager",
                        "pairs": ctx.n_pairs,
+                       "launches_per_iteration": 2 if ctx.get_option("fused") else 4,
                        "pair_stage": {0.0: "vector ALUs (pair_block_kernel)", 1.0: "matrix cores (pair_mfma_kernel)",
                                       2.0: "matrix cores, blocked (mfma_rows_kernel + mfma_slab_kernel)"}[ctx.get_option("mfma")]},
             "collective": coll,

@@ -123,10 +123,10 @@ void for_row_blocks(int rows, size_t row_doubles, F &&fn) {
   for (auto &x : th) x.join();
 }
 
-enum KernelId { K_SEG = 0, K_DENSE, K_ETAP, K_MATVEC_A, K_COUNT };
-// The four launches of an iteration.
-const char *const kKernelNames[K_COUNT] = {"seg_pass_kernel", "pair_block_kernel(T+S)",
-                                           "eta_p_kernel", "pair_block_kernel(A)"};
+enum KernelId { K_SEG = 0, K_DENSE, K_ETAP, K_MATVEC_A, K_FUSED_PAIRS, K_FUSED_TAIL, K_COUNT };
+// The four launches of an iteration -- or, for small problems, the two of fused_small.hpp.
+const char *const kKernelNames[K_COUNT] = {"seg_pass_kernel", "pair_block_kernel(T+S)", "eta_p_kernel",
+                                           "pair_block_kernel(A)", "pairs_fused_kernel", "tail_fused_kernel"};
 
 
 }  // namespace
@@ -161,6 +161,9 @@ struct mmsbm_hip_ctx {
   DevBuf<double> btab;                // [I * R][kp], of the slot being scored
   bool predict_fast = true;
   int seg_batch = 4;  // row gathers a group of seg_pass keeps in flight (4, or 8)
+  bool fused = false;          // small problems: two launches per iteration (fused_small.hpp)
+  std::vector<char> a_ok;      // per slot: atab[cur] holds A of the CURRENT parameters (the fused form computes A at
+                               // the start of an iteration, so after a committed fused iteration it does not)
   bool mfma = false;    // both pair-stage launches run pair_mfma_kernel (tiles beyond the scalar cache, K, L <= 64)
   size_t lds_mt = 0, lds_ma = 0;
   int mfma_threads = kPairBlockMax;  // T+S launch: 512 (eight waves) or 256

@@ -17,12 +17,16 @@ namespace {
 constexpr int kRedCols = 16, kRedRows = 64, kRedGroup = 6;  // ratings per LDS pass
 constexpr int kRedThreads = kRedCols * kRedRows, kRedBatch = 5;  // 64 x 5 = 320 slabs per rating in one round (C3: 313)
 
-template <int ROWS>
+// ROWS = rows of the reduction pattern (which fixes the association order of the sum over slabs); NTY = rows of
+// threads that carry it out, ROWS / NTY pattern rows each.  eta_p_kernel: 64 / 64.  tail_fused_kernel
+// (fused_small.hpp) has 256 threads: 64 / 16 -- the same sums in the same order, four rounds of loads per thread.
+template <int ROWS, int NTY = ROWS>
 __device__ __forceinline__ void p_update_block(
     double (*red)[ROWS][kRedCols], int block, const double *__restrict__ partial,
     const int32_t *__restrict__ chunk_off, const double *__restrict__ p_old,
     double *__restrict__ p_new, double *__restrict__ pt_new, double *__restrict__ npr,
     int n_ratings, int kp, int lp, int normalize) {
+  static_assert(ROWS % NTY == 0 && NTY >= 8, "pattern rows are dealt to the thread rows; the tree's second level needs 8");
   const int tx = threadIdx.x % kRedCols, ty = threadIdx.x / kRedCols;
   const int kl = kp * lp;
   const int col = block * kRedCols + tx;
@@ -44,24 +48,28 @@ __device__ __forceinline__ void p_update_block(
       longest = max(longest, c1[j] - c0[j]);
       s[j] = 0.0;
     }
-    if (ok) {
-      for (int off = ty; off < longest; off += ROWS * kRedBatch) {
-        double v[kRedGroup][kRedBatch];
+    for (int vty = ty; vty < ROWS; vty += NTY) {  // (one trip when every pattern row has its own thread row)
 #pragma unroll
-        for (int j = 0; j < kRedGroup; ++j)
+      for (int j = 0; j < kRedGroup; ++j) s[j] = 0.0;
+      if (ok) {
+        for (int off = vty; off < longest; off += ROWS * kRedBatch) {
+          double v[kRedGroup][kRedBatch];
 #pragma unroll
-          for (int i = 0; i < kRedBatch; ++i) {  // every rating's slab loads issued together
-            const int c = c0[j] + off + i * ROWS;
-            v[j][i] = (c < c1[j]) ? partial[static_cast<size_t>(c) * kl + col] : 0.0;
-          }
+          for (int j = 0; j < kRedGroup; ++j)
 #pragma unroll
-        for (int j = 0; j < kRedGroup; ++j)
+            for (int i = 0; i < kRedBatch; ++i) {  // every rating's slab loads issued together
+              const int c = c0[j] + off + i * ROWS;
+              v[j][i] = (c < c1[j]) ? partial[static_cast<size_t>(c) * kl + col] : 0.0;
+            }
 #pragma unroll
-          for (int i = 0; i < kRedBatch; ++i) s[j] += v[j][i];
+          for (int j = 0; j < kRedGroup; ++j)
+#pragma unroll
+            for (int i = 0; i < kRedBatch; ++i) s[j] += v[j][i];
+        }
       }
-    }
 #pragma unroll
-    for (int j = 0; j < kRedGroup; ++j) red[j][ty][tx] = s[j];
+      for (int j = 0; j < kRedGroup; ++j) red[j][vty][tx] = s[j];
+    }
     __syncthreads();
     if (ty < 8) {  // ROWS rows -> 8 partial sums (fixed order)
 #pragma unroll

@@ -53,6 +53,7 @@
 #include "seg_pass.hpp"
 #include "pair_block.hpp"
 #include "eta_p.hpp"
+#include "fused_small.hpp"
 #include "once_kernels.hpp"
 #include "lik_fact.hpp"
 #include "context.hpp"
@@ -323,6 +324,8 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
       c->ranges_users = ru;
     }
     lap("xcd-local work lists");
+    // small problems (where eight rows in flight pay, above): two launches per iteration instead of four
+    c->fused = n_obs <= 300000 && fused_possible(c.get()) && std::getenv("MMSBM_HIP_NO_FUSED") == nullptr;
 
     hipStream_t s = c->stream;
     c->pair_off.upload(c->lay.pair_off, s);
@@ -423,6 +426,7 @@ int mmsbm_hip_set_params(mmsbm_hip_ctx *ctx, const double *theta, const double *
     stage_matvec_a(ctx, cur, cur);
     HIP_CHECK(hipStreamSynchronize(ctx->stream));  // the staging area is free again
     ctx->have[sl] = 1;
+    ctx->a_ok[sl] = 1;
   });
 }
 
@@ -463,6 +467,7 @@ int mmsbm_hip_init_params(mmsbm_hip_ctx *ctx, const uint64_t pcg64_state[4], con
     stage_matvec_a(ctx, cur, cur);
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
     ctx->have[sl] = 1;
+    ctx->a_ok[sl] = 1;
   });
 }
 
@@ -495,6 +500,7 @@ int mmsbm_hip_set_slots(mmsbm_hip_ctx *ctx, int n_slots) {
     use_device(ctx);
     if (n_slots == ctx->n_slots) {
       ctx->have.assign(static_cast<size_t>(n_slots), 0);
+      ctx->a_ok.assign(static_cast<size_t>(n_slots), 0);
       ctx->sel = 0;
       return;
     }
@@ -658,6 +664,7 @@ bool lik_pairs_usable(const mmsbm_hip_ctx *c) {
          c->n_obs * 2 >= static_cast<int64_t>(c->n_pairs) * 5;
 }
 int likelihood_pairs(mmsbm_hip_ctx *c) {
+  ensure_a(c);  // (s_t = theta_t . A[q])
   const int cur = c->cur, sl = c->sel;
   hipStream_t st = c->stream;
   const size_t nt = static_cast<size_t>(c->n_users) * c->kp, ne = static_cast<size_t>(c->n_items) * c->lp;
@@ -1067,6 +1074,14 @@ int mmsbm_hip_kernel_bytes(const mmsbm_hip_ctx *ctx, int index, int64_t *bytes_r
         wr = 3 * R * 8 * K * L + I * 8 * L;
         break;
       case K_MATVEC_A: rd = Q * (8 * L + 4) + C * 8 * K * L; wr = Q * 8 * K; break;
+      case K_FUSED_PAIRS:  // gathered eta rows + ids, the pair pass's index + theta row per triple, two tiles per block
+        rd = Q * (8 * L + 4 + 4) + N * (4 + 8 * K) + 2 * C * 8 * K * L;
+        wr = Q * (8 * K + 8 * L) + C * 8 * K * L;
+        break;
+      case K_FUSED_TAIL:   // the user pass + the slabs and p + T rows through the item lists
+        rd = N * (4 + 8 * K) + U * (8 * K + 4) + C * 8 * K * L + R * 8 * K * L + Q * (8 * L + 4) + I * (8 * L + 8);
+        wr = U * 8 * K + 3 * R * 8 * K * L + I * 8 * L;
+        break;
       default: throw std::invalid_argument("kernel index out of range");
     }
     *bytes_read = rd * ctx->n_slots;  // one launch covers every restart slot
@@ -1083,11 +1098,14 @@ int mmsbm_hip_time_stage(mmsbm_hip_ctx *ctx, int stage, int reps, float *mean_us
     if (!mean_us || reps <= 0 || stage < 0 || stage >= K_COUNT)
       throw std::invalid_argument("bad argument");
     use_device(ctx);
+    ensure_a(ctx);
     auto one = [&] {
       switch (stage) {
         case K_SEG: stage_seg(ctx, true, true, true, ctx->stream); break;
         case K_DENSE: stage_dense(ctx); break;
         case K_ETAP: stage_eta_p(ctx, true); break;
+        case K_FUSED_PAIRS: stage_fused_pairs(ctx); break;
+        case K_FUSED_TAIL: stage_fused_tail(ctx, true); break;
         default: stage_matvec_a(ctx, ctx->cur, ctx->cur ^ 1); break;
       }
     };
@@ -1129,6 +1147,9 @@ int mmsbm_hip_set_option(mmsbm_hip_ctx *ctx, const char *name, double value) {
     } else if (key == "quad") {  // 0: the A launch through pair_block like every other shape
       ctx->quad_a = value != 0.0 && !ctx->wide && ctx->kp * ctx->lp > 1024 && ctx->tl_a &&
                     ctx->pb_threads_a == kPairBlockMax && ctx->lds_qa <= kLdsMax - 2048 && ctx->lp <= 64;
+    } else if (key == "fused") {  // two launches per iteration (small tiles, unsplit segments); any problem size
+      if (value != 0.0 && !fused_possible(ctx)) throw std::invalid_argument("fused: not available for this shape / data");
+      ctx->fused = value != 0.0;
     } else if (key == "seg_batch") {
       if (value != 4 && value != 8) throw std::invalid_argument("seg_batch: 4 or 8");
       ctx->seg_batch = static_cast<int>(value);
@@ -1159,6 +1180,7 @@ int mmsbm_hip_get_option(const mmsbm_hip_ctx *ctx, const char *name, double *val
     else if (key == "mfma_threads") *value = ctx->mfma_threads;
     else if (key == "predict_fast") *value = ctx->predict_fast;
     else if (key == "seg_batch") *value = ctx->seg_batch;
+    else if (key == "fused") *value = ctx->fused;
     else if (key == "wide") *value = ctx->wide;
     else if (key == "slot_waves") *value = ctx->slot_waves;
     else if (key == "lik_fast") *value = ctx->lik_mode;

@@ -372,13 +372,80 @@ void stage_matvec_a(mmsbm_hip_ctx *c, int slot, int a_slot, bool grid = false) {
   ls.done();
 }
 
+// ---- small problems: the iteration in two launches (fused_small.hpp) -------------------------------------
+bool fused_possible(const mmsbm_hip_ctx *c) {
+  // (rows of up to 24 groups: beyond that the four-launch pair stage runs 512-thread workgroups, whose split of a
+  // unit's pairs among the copies of the slab grid -- hence the association order of S -- 256 threads cannot mirror)
+  return c->code_k <= 1 && c->code_l <= 1 && c->pb_threads_t == kBlock && c->pb_threads_a == kBlock && !c->tl_t &&
+         !c->tl_a && c->pb_nacc == 1 && c->pb_kt == 2 && c->pb_spb * c->pb_nsub <= kBlock && !c->wide &&
+         !c->mfma && !c->mfma_big && !c->direct_out && c->mv_chunk_pairs == mmsbm::kMvChunkPairs && c->n_chunks > 0 &&
+         // (no segment cut into pieces; a work list that only ORDERS whole segments is fine: the pair units ignore it
+         // -- every segment's result is its own -- and the user pass follows it as before)
+         c->lay.pair_work.splits.empty() && c->lay.user_work.splits.empty() && pairs_fused_lds(c->kp, c->lp) <= kLdsBudget;
+}
+void stage_fused_pairs(mmsbm_hip_ctx *c) {
+  LaunchScope ls(c, K_FUSED_PAIRS, true);
+  const int s = c->base_slot, cur = c->cur;
+  FusedPairArgs fa{};
+  fa.pt_tiles = c->pt[cur].at(s); fa.p_tiles = c->p[cur].at(s); fa.eta = c->eta[cur].at(s);
+  fa.theta = theta_tab(c, cur); fa.a_out = a_tab(c, cur);
+  fa.pair_off = c->pair_off.ptr; fa.pair_user = c->pair_user.ptr; fa.pair_item = c->pair_item.ptr;
+  fa.chunks = c->mv_chunks.ptr; fa.t_out = c->ttab.at(s); fa.partial = c->partial.at(s);
+  fa.kp = c->kp; fa.lp = c->lp; fa.spb = c->pb_spb; fa.nsub = c->pb_nsub;
+  fa.bs_tiles = c->p[0].stride; fa.bs_eta = c->eta[0].stride; fa.bs_t = c->ttab.stride; fa.bs_partial = c->partial.stride;
+  const size_t lds = pairs_fused_lds(c->kp, c->lp);
+  const dim3 grid = slot_grid(c, c->n_chunks);
+  if (c->code_k == 0) LAUNCH_IN(ls, (pairs_fused_kernel<4, 4>), grid, kBlock, lds, c->stream, fa);
+  else LAUNCH_IN(ls, (pairs_fused_kernel<8, 4>), grid, kBlock, lds, c->stream, fa);
+  ls.done();
+}
+void stage_fused_tail(mmsbm_hip_ctx *c, bool commit) {
+  LaunchScope ls(c, K_FUSED_TAIL, true);
+  const SegArgs su = seg_users_args(c, commit, c->n_users);
+  const EtaPArgs a = eta_p_args(c, commit, kRedCols);
+  const int per_u = kBlock / group_lanes(c->code_k), per_i = kBlock / group_lanes(c->code_l);
+  const int bu = (su.nseg + per_u - 1) / per_u, nb_i = (c->n_items + per_i - 1) / per_i;
+  const dim3 grid = slot_grid(c, bu + a.nb_p + nb_i);
+  switch (c->code_k * 2 + c->code_l) {
+    case 0: LAUNCH_IN(ls, (tail_fused_kernel<4, 4, 4, 4>), grid, kBlock, 0, c->stream, su, a, bu, c->kp); break;
+    case 1: LAUNCH_IN(ls, (tail_fused_kernel<4, 4, 8, 4>), grid, kBlock, 0, c->stream, su, a, bu, c->kp); break;
+    case 2: LAUNCH_IN(ls, (tail_fused_kernel<8, 4, 4, 4>), grid, kBlock, 0, c->stream, su, a, bu, c->kp); break;
+    default: LAUNCH_IN(ls, (tail_fused_kernel<8, 4, 8, 4>), grid, kBlock, 0, c->stream, su, a, bu, c->kp); break;
+  }
+  ls.done();
+}
+
+// atab[cur] = A of the current parameters, for every slot the next launches cover (see mmsbm_hip_ctx::a_ok)
+void ensure_a(mmsbm_hip_ctx *c) {
+  bool ok = true;
+  for (int s = c->base_slot; s < c->base_slot + c->launch_slots; ++s) ok = ok && c->a_ok[static_cast<size_t>(s)];
+  if (ok) return;
+  const bool prof = c->profiling;  // (not a launch of the iteration being profiled)
+  c->profiling = false;
+  stage_matvec_a(c, c->cur, c->cur);
+  c->profiling = prof;
+  for (int s = c->base_slot; s < c->base_slot + c->launch_slots; ++s) c->a_ok[static_cast<size_t>(s)] = 1;
+}
+void mark_a(mmsbm_hip_ctx *c, bool ok) {
+  for (int s = c->base_slot; s < c->base_slot + c->launch_slots; ++s) c->a_ok[static_cast<size_t>(s)] = ok ? 1 : 0;
+}
+
 void launch_iteration(mmsbm_hip_ctx *c, bool commit) {
+  if (c->fused) {
+    stage_fused_pairs(c);  // (writes A of the current parameters on its way)
+    stage_fused_tail(c, commit);
+    if (commit) c->cur ^= 1;
+    mark_a(c, !commit);
+    return;
+  }
+  ensure_a(c);
   stage_seg(c, commit, true, true, c->stream);
   stage_dense(c);
   stage_eta_p(c, commit);
   if (commit) {
     stage_matvec_a(c, c->cur ^ 1, c->cur ^ 1);
     c->cur ^= 1;
+    mark_a(c, true);
   }
 }
 
@@ -388,6 +455,7 @@ void run_iterations(mmsbm_hip_ctx *c, int n) {
     while (n >= 2) {
       const int slot = c->cur;
       if (!c->graph_exec[slot]) {
+        if (!c->fused) ensure_a(c);  // (outside the capture: a replay must not repeat it)
         hipGraph_t graph = nullptr;
         HIP_CHECK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
         try {
@@ -456,6 +524,7 @@ void alloc_state(mmsbm_hip_ctx *c, int slots) {
   c->launch_slots = slots;
   c->cur = 0;
   c->have.assign(static_cast<size_t>(slots), 0);
+  c->a_ok.assign(static_cast<size_t>(slots), 0);
 }
 
 // host (rows, d) row-major  <->  device RowTab (rows, dp) zero-padded, main + tail parts, staged

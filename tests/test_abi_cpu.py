@@ -31,7 +31,7 @@ def test_abi_version_and_kernel_names():
     assert lib.mmsbm_hip_abi_version() == 1
     n = lib.mmsbm_hip_kernel_count()
     names = [lib.mmsbm_hip_kernel_name(j).decode() for j in range(n)]
-    assert n == 4 and names[0] == "seg_pass_kernel" and all(names)
+    assert n == 6 and names[0] == "seg_pass_kernel" and names[4] == "pairs_fused_kernel" and all(names)
     assert lib.mmsbm_hip_kernel_name(99) == b""
 
 

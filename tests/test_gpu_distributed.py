@@ -94,7 +94,9 @@ def test_bench_one_gpu_line_has_roofline_cpu_baseline_and_rccl_collective():
     rf = out["roofline"]
     assert rf["bound"] == "hbm" and rf["kernel"] and 0 < rf["frac"] < 1.5
     assert rf["achieved"] == pytest.approx(rf["algorithmic_bytes_per_launch"] / (rf["avg_launch_us"] * 1e-6) / 1e9)
-    assert rf["algorithmic_bytes_per_launch"] == 100_000 * (12 + 8 * 10 + 8 * 10)   # N(12+8K+8L)
+    # N(12+8K+8L) per iteration; C2 runs the two-launch iteration, one triple pass in each launch
+    assert out["config"]["launches_per_iteration"] == 2 and rf["kernel"] in ("pairs_fused_kernel", "tail_fused_kernel")
+    assert rf["algorithmic_bytes_per_launch"] == 100_000 * (12 + 8 * 10 + 8 * 10) // 2
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "all 100000 triples" in cb["sample"]
     assert 0.5 < cb["port_over_reference"] < 2.0

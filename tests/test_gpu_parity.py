@@ -360,6 +360,91 @@ def test_launch_modes_give_identical_results(hip, slots):
             assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("shape", ["c1", "g4", "k20", "k12x24", "ragged", "c2"])
+def test_two_launch_iteration_is_bitwise_the_four_launch_one(hip, shape):
+    """fused_small.hpp: for small problems an iteration is pairs_fused_kernel (A, the pair pass and T + S
+    of a 64-pair unit in one workgroup, C never leaving LDS) + tail_fused_kernel (user pass || p_update ||
+    item_sum).  Every output keeps its arithmetic and association order: numerators after one step and the
+    parameters after 1, 2 and 9 iterations are bit for bit those of the four launches; restart slots, graph
+    replay, the likelihood (which needs A of the NEW parameters) and a switch between the forms in mid-run."""
+    if shape == "c1":
+        g = load_golden("g1_c1_mock")
+        data, start, k, l = g["train"], (g["c1_theta_0"], g["c1_eta_0"], g["c1_pr_0"]), 2, 4
+    elif shape == "g4":
+        g = load_golden("g4_2k_k10")
+        data, start, k, l = g["train"], (g["theta_0"], g["eta_0"], g["pr_0"]), 10, 10
+    else:
+        rng = np.random.default_rng(len(shape))
+        if shape == "c2":
+            data, k, l = orc.synthetic_triples(100_000, 10_000, 5_000, 5, seed=0), 10, 10
+        elif shape == "ragged":   # unequal rating counts (units of 1..64 pairs, an almost empty rating), absent ids
+            n = 9_000
+            r_col = np.minimum(rng.geometric(0.5, n) - 1, 5)
+            i_col = rng.integers(0, 400, n) * 3 % 401
+            u_col = rng.integers(0, 900, n) * 2
+            data, k, l = np.stack([u_col, i_col, r_col], axis=1).astype(np.int64), 7, 13
+        else:
+            data = orc.synthetic_triples(20_000, 2_000, 500, 4, seed=9)
+            k, l = (20, 20) if shape == "k20" else (12, 24)
+        n_u, n_i, n_r = (int(data[:, j].max()) + 1 for j in range(3))
+        start = orc.init_params(5, n_u, n_i, n_r, k, l, *orc.degrees(data, n_u, n_i))
+    n_u, n_i, n_r = start[0].shape[0], start[1].shape[0], start[2].shape[2]
+    runs = {}
+    for fused in (1, 0):
+        with hip.HipEM(data, k, l, n_u, n_i, n_r, slots=2) as em:
+            if fused:
+                assert em.get_option("fused") == 1.0     # the library's own choice for a problem of this size
+            em.set_option("fused", fused)
+            em.select(0).set_params(*start)
+            em.select(1).set_params(start[0] * 0.5 + 0.01, start[1], start[2])
+            out = [em.select(0).update_coefficients()]
+            for its in (1, 1, 7):
+                em.iterate(its)
+                out.append([em.select(s).get_params() for s in range(2)])
+                out.append(em.select(1).likelihood())
+            em.set_graph_mode(1)
+            em.iterate(4)
+            em.set_graph_mode(0)
+            out.append([em.select(s).get_params() for s in range(2)])
+            em.set_option("fused", 1 - fused)            # ... and on in the other form
+            em.iterate(3)
+            out.append([em.select(s).get_params() for s in range(2)])
+            out.append(em.select(0).likelihood())
+            runs[fused] = out
+
+    def same(a, b):
+        if isinstance(a, (list, tuple)):
+            assert len(a) == len(b)
+            for x, y in zip(a, b):
+                same(x, y)
+        else:
+            assert np.array_equal(np.asarray(a), np.asarray(b))
+    same(runs[1], runs[0])
+    # and right: the fused numerators against the oracle
+    for got, want, nm in zip(runs[1][0], orc.update_coefficients(data, *start), ("n_theta", "n_eta", "n_pr")):
+        assert rel_err(got, want) < TOL_STEP, nm
+
+
+def test_two_launch_iteration_is_chosen_by_size_and_refused_where_it_does_not_apply(hip):
+    big = orc.synthetic_triples(400_000, 30_000, 6_000, 5, seed=2)
+    with hip.HipEM(big, 10, 10) as em:
+        assert em.get_option("fused") == 0.0             # beyond 300k ratings: four launches (option still available)
+        em.set_option("fused", 1)
+    small = orc.synthetic_triples(5_000, 500, 200, 5, seed=2)
+    with hip.HipEM(small, 50, 50) as em:                 # tile beyond the scalar cache: not this kernel
+        assert em.get_option("fused") == 0.0
+        with pytest.raises(Exception, match="fused"):
+            em.set_option("fused", 1)
+    with hip.HipEM(small, 28, 8) as em:                  # rows of more than 24 groups
+        assert em.get_option("fused") == 0.0
+    rng = np.random.default_rng(0)                       # one very busy user: its segment is cut into work items
+    n = 9_000
+    skew = np.stack([np.where(rng.random(n) < 0.3, 3, rng.integers(0, 900, n)), rng.integers(0, 400, n),
+                     rng.integers(0, 5, n)], axis=1).astype(np.int64)
+    with hip.HipEM(skew, 10, 10) as em:
+        assert em.get_option("items_users") > 0 and em.get_option("fused") == 0.0
+
+
 def test_cv_fit_matches_reference(hip):
     """The reference's cv_fit test case (tests/test_mmsbm.py:30-34,57-61): folds=2, accuracies 0.125, 0.16."""
     import pandas as pd
