@@ -20,7 +20,7 @@ constexpr int kRedThreads = kRedCols * kRedRows, kRedBatch = 5;  // 64 x 5 = 320
 // ROWS = rows of the reduction pattern (which fixes the association order of the sum over slabs); NTY = rows of
 // threads that carry it out, ROWS / NTY pattern rows each.  eta_p_kernel: 64 / 64.  tail_fused_kernel
 // (fused_small.hpp) has 256 threads: 64 / 16 -- the same sums in the same order, four rounds of loads per thread.
-template <int ROWS, int NTY = ROWS>
+template <int ROWS, int NTY = ROWS, int BATCH = kRedBatch>
 __device__ __forceinline__ void p_update_block(
     double (*red)[ROWS][kRedCols], int block, const double *__restrict__ partial,
     const int32_t *__restrict__ chunk_off, const double *__restrict__ p_old,
@@ -48,28 +48,38 @@ __device__ __forceinline__ void p_update_block(
       longest = max(longest, c1[j] - c0[j]);
       s[j] = 0.0;
     }
-    for (int vty = ty; vty < ROWS; vty += NTY) {  // (one trip when every pattern row has its own thread row)
+    // (a pattern row adds its slabs c0 + vty, + ROWS, + 2 ROWS, ... one after the other: BATCH only says how many
+    // of those loads are in flight together, it does not touch the order of the sum)
+    constexpr int VR = ROWS / NTY;  // pattern rows per thread row: their loads share a round too
+    double sv[VR][kRedGroup];
 #pragma unroll
-      for (int j = 0; j < kRedGroup; ++j) s[j] = 0.0;
-      if (ok) {
-        for (int off = vty; off < longest; off += ROWS * kRedBatch) {
-          double v[kRedGroup][kRedBatch];
+    for (int m = 0; m < VR; ++m)
+#pragma unroll
+      for (int j = 0; j < kRedGroup; ++j) sv[m][j] = 0.0;
+    if (ok) {
+      for (int off = 0; off < longest; off += ROWS * BATCH) {
+        double v[VR][kRedGroup][BATCH];
+#pragma unroll
+        for (int m = 0; m < VR; ++m)
 #pragma unroll
           for (int j = 0; j < kRedGroup; ++j)
 #pragma unroll
-            for (int i = 0; i < kRedBatch; ++i) {  // every rating's slab loads issued together
-              const int c = c0[j] + off + i * ROWS;
-              v[j][i] = (c < c1[j]) ? partial[static_cast<size_t>(c) * kl + col] : 0.0;
+            for (int i = 0; i < BATCH; ++i) {  // every rating's slab loads issued together
+              const int c = c0[j] + off + (ty + m * NTY) + i * ROWS;
+              v[m][j][i] = (c < c1[j]) ? partial[static_cast<size_t>(c) * kl + col] : 0.0;
             }
 #pragma unroll
+        for (int m = 0; m < VR; ++m)
+#pragma unroll
           for (int j = 0; j < kRedGroup; ++j)
 #pragma unroll
-            for (int i = 0; i < kRedBatch; ++i) s[j] += v[j][i];
-        }
+            for (int i = 0; i < BATCH; ++i) sv[m][j] += v[m][j][i];
       }
-#pragma unroll
-      for (int j = 0; j < kRedGroup; ++j) red[j][vty][tx] = s[j];
     }
+#pragma unroll
+    for (int m = 0; m < VR; ++m)
+#pragma unroll
+      for (int j = 0; j < kRedGroup; ++j) red[j][ty + m * NTY][tx] = sv[m][j];
     __syncthreads();
     if (ty < 8) {  // ROWS rows -> 8 partial sums (fixed order)
 #pragma unroll

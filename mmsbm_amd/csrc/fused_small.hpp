@@ -57,6 +57,7 @@ __global__ __launch_bounds__(kBlock) void pairs_fused_kernel(FusedPairArgs fa) {
   double *es = etaT + static_cast<size_t>(lp) * CS;         // [64][lp]  the same rows, row-major (S); later the T rows
   double *aout = es + static_cast<size_t>(kUnitPairs) * lp; // [64][kp]  A rows of the unit
   double *cT = aout + static_cast<size_t>(kUnitPairs) * kp; // [kp][CS]  C rows, transposed
+  STAMP(0);
   const mmsbm::Chunk ch = fa.chunks[blockIdx.x];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int q0 = ch.q_begin, np = ch.q_end - ch.q_begin;  // (np <= 64; 0 for the padding of the unit lists)
@@ -64,45 +65,67 @@ __global__ __launch_bounds__(kBlock) void pairs_fused_kernel(FusedPairArgs fa) {
   const const_tile_ptr gpt = (const_tile_ptr)(reinterpret_cast<uintptr_t>(pt_tiles + static_cast<size_t>(ch.rating) * lp * kp));
   const const_tile_ptr gp = (const_tile_ptr)(reinterpret_cast<uintptr_t>(p_tiles + static_cast<size_t>(ch.rating) * kp * lp));
 
-  // ---- the pair segments' first indices and offsets: asked for now, used after the A mat-vec ----
+  // ---- everything the unit needs from memory, asked for in dependency LEVELS (the vector-memory wait counter is
+  // in order: what is asked for first must arrive first, so independent loads of one level go out together and
+  // nothing waits on a younger load): offsets + item ids -> first indices + eta rows -> first theta rows of round 0,
+  // which then travel while A is multiplied ----
   constexpr int NGRP = kBlock / G, ROUNDS = (kUnitPairs + NGRP - 1) / NGRP;
   const int grp = tid / G, gl = tid % G;
-  constexpr int CH = (G < 16) ? 2 * G : G;
-  int beg[ROUNDS], end[ROUNDS], mine0[ROUNDS], mine1[ROUNDS];
+  constexpr int CH = B;       // triples per step of a segment = row gathers in flight per group
+  constexpr int IPL = CH / G;  // indices a lane holds per step (G = 4: two, G = 8: one)
+  static_assert(IPL == 1 || IPL == 2, "groups of 4 or 8 lanes");
+  constexpr int NE = 4;  // eta loads per thread: 64 pairs x <= 32 entries / 2 per load / 256 threads
+  const int tot = np * lp;
+  int beg[ROUNDS], end[ROUNDS], mine0[ROUNDS], mine1[ROUNDS], next0[ROUNDS], next1[ROUNDS];
+  int pr[NE], d[NE], ids[NE];
 #pragma unroll
-  for (int r = 0; r < ROUNDS; ++r) {
-    const int pr = grp + r * NGRP;
-    const bool on = pr < np;
-    beg[r] = on ? fa.pair_off[q0 + pr] : 0;
-    end[r] = on ? fa.pair_off[q0 + pr + 1] : 0;
+  for (int r = 0; r < ROUNDS; ++r) {  // level 1
+    const int p0 = grp + r * NGRP;
+    const bool on = p0 < np;
+    beg[r] = on ? fa.pair_off[q0 + p0] : 0;
+    end[r] = on ? fa.pair_off[q0 + p0 + 1] : 0;
   }
 #pragma unroll
-  for (int r = 0; r < ROUNDS; ++r) {
-    const int cnt = min(CH, end[r] - beg[r]);
-    mine0[r] = cnt > 0 ? fa.pair_user[beg[r] + min(gl, cnt - 1)] : 0;
-    mine1[r] = (CH > G && cnt > 0) ? fa.pair_user[beg[r] + min(G + gl, cnt - 1)] : 0;
+  for (int j = 0; j < NE; ++j) {
+    const int t = min(tid * 2 + j * kBlock * 2, max(tot - 2, 0));
+    pr[j] = t / lp;
+    d[j] = t - pr[j] * lp;
+    ids[j] = tot > 0 ? fa.pair_item[q0 + pr[j]] : 0;
   }
-
-  // ---- eta rows of the unit's pairs -> etaT (transposed) and es (row-major) ----
-  {
-    const int tot = np * lp;
-    for (int t0 = tid * 2; t0 < tot; t0 += kBlock * 4) {
-      double2 v[2];
-      int pr[2], d[2];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int t = min(t0 + j * kBlock * 2, max(tot - 2, 0));
-        pr[j] = t / lp;
-        d[j] = t - pr[j] * lp;
-        v[j] = *reinterpret_cast<const double2 *>(eta + static_cast<size_t>(fa.pair_item[q0 + pr[j]]) * lp + d[j]);
-      }
+  for (int r = 0; r < ROUNDS; ++r) {  // level 2: the indices of a segment's first two steps
+    const int len = end[r] - beg[r];
+    const int last = max(len - 1, 0);
+    mine0[r] = len > 0 ? fa.pair_user[beg[r] + min(gl, last)] : 0;
+    mine1[r] = (IPL > 1 && len > 0) ? fa.pair_user[beg[r] + min(G + gl, last)] : 0;
+    next0[r] = len > CH ? fa.pair_user[beg[r] + min(CH + gl, last)] : 0;
+    next1[r] = (IPL > 1 && len > CH) ? fa.pair_user[beg[r] + min(CH + G + gl, last)] : 0;
+  }
+  double2 ev[NE];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        if (t0 + j * kBlock * 2 < tot) {
-          etaT[d[j] * CS + pr[j]] = v[j].x;
-          etaT[(d[j] + 1) * CS + pr[j]] = v[j].y;
-          *reinterpret_cast<double2 *>(es + pr[j] * lp + d[j]) = v[j];
-        }
+  for (int j = 0; j < NE; ++j) ev[j] = *reinterpret_cast<const double2 *>(eta + static_cast<size_t>(ids[j]) * lp + d[j]);
+  __builtin_amdgcn_sched_barrier(0);  // (the compiler moved one of these behind the gathers below, and with it the wait)
+  const bool act = gl * VEC < kp;
+  const int lane_off = act ? gl * VEC : 0;
+  const bool g_main = lane_off < theta.mw;
+  const double *gbase = g_main ? theta.main + lane_off : theta.tail + (lane_off - theta.mw);
+  const size_t gstride = g_main ? theta.rs_m : theta.rs_t;
+  double gpre[B][VEC];
+  {  // level 3
+#pragma unroll
+    for (int b = 0; b < B; ++b) {  // (entries past the segment's end repeat its last triple -- or row 0 -- and are not used)
+      const int id = __shfl((IPL > 1 && b >= G) ? mine1[0] : mine0[0], b % G, G);
+      load_vec<VEC>(gbase + static_cast<size_t>(id) * gstride, gpre[b]);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  {  // eta rows -> etaT (transposed) and es (row-major)
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+      if (tid * 2 + j * kBlock * 2 < tot) {
+        etaT[d[j] * CS + pr[j]] = ev[j].x;
+        etaT[(d[j] + 1) * CS + pr[j]] = ev[j].y;
+        *reinterpret_cast<double2 *>(es + pr[j] * lp + d[j]) = ev[j];
       }
     }
     if (np < kUnitPairs) {  // ragged tail of a rating: the missing pairs are zero columns / zero rows
@@ -112,7 +135,9 @@ __global__ __launch_bounds__(kBlock) void pairs_fused_kernel(FusedPairArgs fa) {
       }
     }
   }
+  STAMP(1);
   __syncthreads();
+  STAMP(2);
   // ---- A[q,:] = pT_r eta_q: lane = pair, wave = chunk of 4 outputs (pair_block's A mode) ----
   for (int c = __builtin_amdgcn_readfirstlane(wave); c < (kp >> 2); c += kBlock / 64) {
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
@@ -140,6 +165,7 @@ __global__ __launch_bounds__(kBlock) void pairs_fused_kernel(FusedPairArgs fa) {
     *reinterpret_cast<double2 *>(aout + lane * kp + c * 4 + 2) = w1;
   }
   __syncthreads();
+  STAMP(3);
   // the unit's A rows go to memory for launch 2 (the user pass gathers them)
   for (int t = tid * 2; t < np * kp; t += kBlock * 2) {
     const int pr = t / kp, j = t - pr * kp;
@@ -148,11 +174,6 @@ __global__ __launch_bounds__(kBlock) void pairs_fused_kernel(FusedPairArgs fa) {
   }
   // ---- the pair segments (seg_body's arithmetic): a group of G lanes per pair, C row into cT ----
   {
-    const bool act = gl * VEC < kp;
-    const int lane_off = act ? gl * VEC : 0;
-    const bool g_main = lane_off < theta.mw;
-    const double *gbase = g_main ? theta.main + lane_off : theta.tail + (lane_off - theta.mw);
-    const size_t gstride = g_main ? theta.rs_m : theta.rs_t;
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
       const int pr = grp + r * NGRP;
@@ -163,34 +184,59 @@ __global__ __launch_bounds__(kBlock) void pairs_fused_kernel(FusedPairArgs fa) {
         acc[v] = 0.0;
         f[v] = act ? aout[pr * kp + lane_off + v] : 0.0;
       }
+      // One step = CH = 8 triples.  The rows of step n + 1 are asked for before step n is added up, with indices
+      // that were fetched a step earlier still (the first two steps' at the very top of the kernel): a long
+      // segment pays one round trip per step instead of two, a segment of up to 16 triples none beyond the first.
+      double g[B][VEC];
+      if (r == 0) {
+#pragma unroll
+        for (int b = 0; b < B; ++b)
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) g[b][v] = gpre[b][v];
+      } else {
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+          const int id = __shfl((IPL > 1 && b >= G) ? mine1[r] : mine0[r], b % G, G);
+          load_vec<VEC>(gbase + static_cast<size_t>(id) * gstride, g[b]);
+        }
+      }
+      int n0 = next0[r], n1 = next1[r];
       for (int c0 = beg[r]; c0 < end[r]; c0 += CH) {
         const int cnt = min(CH, end[r] - c0);
-        int m0 = mine0[r], m1 = mine1[r];
-        if (c0 != beg[r]) {  // (segments longer than the first batch of indices: rare here)
-          m0 = fa.pair_user[c0 + min(gl, cnt - 1)];
-          m1 = (CH > G) ? fa.pair_user[c0 + min(G + gl, cnt - 1)] : 0;
-        }
-        for (int n = 0; n < cnt; n += B) {
-          double g[B][VEC];
+        double gn[B][VEC];
+        int nn0 = 0, nn1 = 0;
+        if (c0 + CH < end[r]) {  // (whole groups)
 #pragma unroll
           for (int b = 0; b < B; ++b) {
-            const int jj = min(n + b, cnt - 1);
-            const int id = __shfl((CH > G && jj >= G) ? m1 : m0, jj, G);
-            load_vec<VEC>(gbase + static_cast<size_t>(id) * gstride, g[b]);
+            const int id = __shfl((IPL > 1 && b >= G) ? n1 : n0, b % G, G);
+            load_vec<VEC>(gbase + static_cast<size_t>(id) * gstride, gn[b]);
           }
-#pragma unroll
-          for (int b = 0; b < B; ++b) {
-            if (n + b < cnt) {
-              double pt = 0.0;
-#pragma unroll
-              for (int v = 0; v < VEC; ++v) pt = fma(g[b][v], f[v], pt);
-              const double s = group_sum<G>(pt);
-              const double w = 1.0 / fmax(s, kEps);
-#pragma unroll
-              for (int v = 0; v < VEC; ++v) acc[v] = fma(g[b][v], w, acc[v]);
-            }
+          if (c0 + 2 * CH < end[r]) {
+            const int last = end[r] - 1;
+            nn0 = fa.pair_user[min(c0 + 2 * CH + gl, last)];
+            nn1 = IPL > 1 ? fa.pair_user[min(c0 + 2 * CH + G + gl, last)] : 0;
           }
         }
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+          if (b < cnt) {  // (weights of 0 for the empty slots instead of this branch: 2.36 vs 1.98 us for the phase)
+            double pt = 0.0;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) pt = fma(g[b][v], f[v], pt);
+            const double s = group_sum<G>(pt);
+            const double w = 1.0 / fmax(s, kEps);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) acc[v] = fma(g[b][v], w, acc[v]);
+          }
+        }
+        if (c0 + CH < end[r]) {
+#pragma unroll
+          for (int b = 0; b < B; ++b)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) g[b][v] = gn[b][v];
+        }
+        n0 = nn0;
+        n1 = nn1;
       }
       if (act) {
 #pragma unroll
@@ -199,6 +245,7 @@ __global__ __launch_bounds__(kBlock) void pairs_fused_kernel(FusedPairArgs fa) {
     }
   }
   __syncthreads();
+  STAMP(4);
   // ---- S: thread = (k, 4 l) slot of a KT x 4 register tile, copies split the unit's pairs (pair_block) ----
   const int nch = lp >> 2;
   const int nslot = (kp / KT) * nch, spb = fa.spb, nsub = fa.nsub;
@@ -227,6 +274,7 @@ __global__ __launch_bounds__(kBlock) void pairs_fused_kernel(FusedPairArgs fa) {
     }
   }
   __syncthreads();  // es is dead: its space takes the T rows
+  STAMP(5);
   double *tout = es;
   // ---- T[q,:] = p_r^T C_q: lane = pair, wave = chunk of 4 outputs ----
   for (int c = __builtin_amdgcn_readfirstlane(wave); c < nch; c += kBlock / 64) {
@@ -255,6 +303,7 @@ __global__ __launch_bounds__(kBlock) void pairs_fused_kernel(FusedPairArgs fa) {
     *reinterpret_cast<double2 *>(tout + lane * lp + c * 4 + 2) = w1;
   }
   __syncthreads();
+  STAMP(6);
   {  // the unit's T rows are contiguous in memory
     double *dst = t_out + static_cast<size_t>(q0) * lp;
     for (int t = tid * 2; t < np * lp; t += kBlock * 2)
@@ -284,6 +333,12 @@ __global__ __launch_bounds__(kBlock) void pairs_fused_kernel(FusedPairArgs fa) {
       *reinterpret_cast<double2 *>(cell + h * lp + 2) = y;
     }
   }
+#ifdef MMSBM_STAMPS
+  STAMP(7);
+  __syncthreads();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  STAMP(8);
+#endif
 }
 
 // launch 2: blocks [0, bu) user segments, [bu, bu + nb_p) p_update, the rest item_sum
@@ -295,7 +350,7 @@ __global__ __launch_bounds__(kBlock) void tail_fused_kernel(SegArgs su, EtaPArgs
   if (bx < bu) {
     seg_body<G, VEC, 8, 1>(su, bx * (kBlock / G) + threadIdx.x / G, dp, 1);
   } else if (bx < bu + a.nb_p) {
-    p_update_block<kRedRows, kBlock / kRedCols>(red, bx - bu, a.partial + slot * a.bs_partial, a.chunk_off,
+    p_update_block<kRedRows, kBlock / kRedCols, 2>(red, bx - bu, a.partial + slot * a.bs_partial, a.chunk_off,
                                       a.p_old + slot * a.bs_p, a.p_new + slot * a.bs_p, a.pt_new + slot * a.bs_p,
                                       a.npr + slot * a.bs_p, a.n_ratings, a.kp, a.lp, a.normalize);
   } else {

@@ -1,0 +1,31 @@
+"""Where the workgroups of pairs_fused_kernel spend their time (diagnostic build with -DMMSBM_STAMPS, see
+scripts/phase_stamps.py).
+
+    hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared -DMMSBM_STAMPS -o /tmp/libstamps.so mmsbm_amd/csrc/mmsbm_hip.hip
+    MMSBM_HIP_LIBRARY=/tmp/libstamps.so python scripts/phase_stamps_fused.py c2
+"""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from mmsbm_amd import MMSBM, _lib
+from mmsbm_amd.synthetic import CONFIGS, synthetic_triples
+n, u, i, r, k, l = CONFIGS[sys.argv[1] if len(sys.argv) > 1 else "c2"]
+train = synthetic_triples(n, u, i, r, 0)
+mm = MMSBM(k, l, iterations=1, seed=0); mm._prepare_objects(train)
+ctx = mm._ctx(0); ctx.init_params(mm.child_states[0]); ctx.set_option("fused", 1); ctx.iterate(3)
+lib = _lib.load()
+lib.mmsbm_hip_debug_stamps.argtypes = [C.POINTER(C.c_uint64), C.c_int]
+names = ["ids, offsets, eta rows, theta prefetch -> LDS", "barrier", "A mat-vec + barrier", "A rows out + pair segments + barrier",
+         "S + barrier", "T mat-vec + barrier", "T rows out + slab hand-over + slab store", "drain"]
+for rep in range(3):
+    ctx.time_stage(4, 1)   # stage 4 = pairs_fused_kernel: 3 warm launches + 1
+    buf = np.zeros(8192 * 16, dtype=np.uint64)
+    assert lib.mmsbm_hip_debug_stamps(buf.ctypes.data_as(C.POINTER(C.c_uint64)), buf.size) == 0
+    st = buf.reshape(8192, 16).astype(np.int64)
+    st = st[st[:, 0] > 0][:, :9]
+    rel = (st - st[:, 0].min()) / 100.0   # microseconds
+    print(f"-- {len(st)} workgroups; last start {rel[:, 0].max():.2f}, first end {rel[:, 8].min():.2f}, last end {rel[:, 8].max():.2f} us")
+    d = np.diff(rel, axis=1)
+    for j in range(8):
+        print(f"   {names[j]:52s} mean {d[:, j].mean():6.2f}  p10 {np.percentile(d[:, j], 10):6.2f}  p90 {np.percentile(d[:, j], 90):6.2f} us")
+    print(f"   workgroup lifetime mean {(rel[:, 8] - rel[:, 0]).mean():.2f} us")
