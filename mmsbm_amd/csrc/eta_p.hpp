@@ -150,7 +150,9 @@ __device__ __forceinline__ void item_sum_block(
     const int32_t *__restrict__ item_pairs, const int32_t *__restrict__ item_deg,
     const double *__restrict__ eta, double *__restrict__ eta_new, int n_items, int lp,
     int normalize, const int32_t *__restrict__ item_grid, int n_ratings) {
-  constexpr int B = 8;
+  // T rows in flight per group: 8 while a row piece is 4 doubles per lane; wide rows (8 or 16 doubles per lane) would
+  // need 128 - 256 registers for that and spill (eta_p at L = 520: 780 us, most of it scratch traffic)
+  constexpr int B = VEC <= 4 ? 8 : (VEC == 8 ? 4 : 2);
   const int it = block * (static_cast<int>(blockDim.x) / G) + threadIdx.x / G;
   const int gl = threadIdx.x % G;
   if (it >= n_items || gl * VEC >= lp) return;

@@ -23,9 +23,8 @@ namespace {
 // log omega = log theta_k + (log eta_l + log p_kl) from the logarithm tables of likelihood_fast_kernel; omega
 // is associated as theta_k (eta_l p_kl).  Both differ from the reference's (theta eta) p in the last bit
 // only (and w, w log w are continuous at the clamp): agreement ~1e-15 relative, the formula is unchanged.
-// Lanes beyond L (and columns beyond L in the last 64-block) and the zero-padded rows K .. Kp - 1 run on omega = 0,
-// log omega = -inf: each of their elements is exactly eps (log eps - ls), which is taken off again in closed
-// form -- so the loops have no bounds checks and no divergence.
+// Lanes beyond L (and columns beyond L in the last 64-block) run on omega = 0, log omega = -inf: each of their
+// elements is exactly eps (log eps - ls), which is taken off again in closed form -- no bounds checks, no divergence.
 // ======================================================================================
 constexpr int kLikWaveThreads = 512;  // eight waves share a staged tile: 3 workgroups = 24 waves per CU at K = L = 50
 
@@ -46,54 +45,107 @@ __global__ __launch_bounds__(kBlock) void theta_log_pairs_kernel(RowTab in, doub
   tl[e] = o;
 }
 
-// TB triples (nt <= TB of them real) of one pair: s_t, then the K x L elements of each, two tile rows per step.
+template <int G>
+__device__ __forceinline__ double group_max(double x) {  // like group_sum (common.hpp), with max
+  if (G >= 2) x = fmax(x, dpp_move<0xB1>(x));
+  if (G >= 4) x = fmax(x, dpp_move<0x4E>(x));
+  if (G >= 8) x = fmax(x, dpp_move<0x141>(x));
+  if (G >= 16) x = fmax(x, dpp_move<0x140>(x));
+  if (G >= 32) x = fmax(x, __shfl_xor(x, 16, 64));
+  if (G >= 64) x = fmax(x, __shfl_xor(x, 32, 64));
+  return x;
+}
+
+// TB triples (nt <= TB of them real) of one pair: s_t, then the elements of each, two tile rows per step.
+// Rows that are dead for the whole chunk are not visited: row k is dead when max_t theta[u_t, k] * (max eta_i *
+// max_l p[k, l]) < eps -- by monotonicity of rounding every omega of the row is then below eps too, so each of
+// its real elements is exactly eps (log eps - ls_t) and goes in as a count.  Early in a run no row is dead;
+// late, memberships are concentrated (BASELINE's config 5 after 400 iterations: 83 % of the theta entries are
+// below eps) and about half of the rows of a chunk of four triples drop out.  `bk`: this lane's rows' bounds
+// max eta_i * max_l p[k, l] (rows lane, lane + 64, ...).
 template <int LW, int TB>
 __device__ __forceinline__ double lik_wave_chunk(const double2 *__restrict__ tl, const size_t (&u)[4], int nt, int lane,
-                                                 const double (&av)[3], int na, const double *tile,
+                                                 const double (&av)[3], const double (&bk)[3], int na, const double *tile,
                                                  const double *ltile, const double (&e)[LW], const double (&le)[LW],
-                                                 const int (&cc)[LW], int kp, int lp, double fake, double log_eps) {
+                                                 const int (&cc)[LW], int k_groups, int kp, int lp, int n_inv, double log_eps) {
   double ls[TB], cl[TB], acc[TB];
+  double sp[TB], vmax[3];
 #pragma unroll
-  for (int t = 0; t < TB; ++t) {  // s_t = theta_t . A[q]: a coalesced row product + a wave sum
-    double sp = 0.0;
+  for (int m = 0; m < 3; ++m) vmax[m] = 0.0;
 #pragma unroll
-    for (int m = 0; m < 3; ++m)
-      if (m < na) sp = fma(tl[u[t] * kp + min(lane + 64 * m, kp - 1)].x, av[m], sp);
-    const double s = group_sum<64>(sp);
+  for (int t = 0; t < TB; ++t) sp[t] = 0.0;
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {
+    if (m < na) {
+#pragma unroll
+      for (int t = 0; t < TB; ++t) {  // s_t = theta_t . A[q]: a coalesced row product + a wave sum
+        const double th = tl[u[t] * kp + min(lane + 64 * m, kp - 1)].x;
+        sp[t] = fma(th, av[m], sp[t]);
+        vmax[m] = fmax(vmax[m], th);
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < TB; ++t) {
+    const double s = group_sum<64>(sp[t]);
     ls[t] = log(fmax(s, kEps));
     cl[t] = log_eps - ls[t];
     acc[t] = 0.0;
   }
-  for (int k0 = 0; k0 < kp; k0 += 2) {  // (kp is even; no bounds checks inside: see `fake`)
-    double tq[TB][4];  // theta, log theta of rows k0, k0 + 1: scalar registers
+  int n_proc = 0;
 #pragma unroll
-    for (int t = 0; t < TB; ++t) {
-      const const_f64_ptr tp = (const_f64_ptr)(reinterpret_cast<uintptr_t>(tl + u[t] * kp + k0));
+  for (int m = 0; m < 3; ++m) {
+    if (m >= na) break;
+    // rows 64 m .. 64 m + 63 that are not dead (rows >= K hold theta = 0: never live)
+    unsigned long long rows = __ballot(lane + 64 * m < kp && vmax[m] * bk[m] >= kEps);
+    n_proc += __builtin_popcountll(rows);
+    while (rows) {  // (uniform)
+      const int ka = 64 * m + __builtin_ctzll(rows);
+      rows &= rows - 1;
+      const bool two = rows != 0;
+      const int kb = two ? 64 * m + __builtin_ctzll(rows) : ka;
+      rows &= rows - 1;  // (0 stays 0)
+      double tq[TB][4];  // theta, log theta of rows ka, kb: scalar registers
 #pragma unroll
-      for (int i = 0; i < 4; ++i) tq[t][i] = tp[i];
-    }
-    double pv[2][LW], lpv[2][LW];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
+      for (int t = 0; t < TB; ++t) {
+        const const_f64_ptr pa = (const_f64_ptr)(reinterpret_cast<uintptr_t>(tl + u[t] * kp + ka));
+        const const_f64_ptr pb = (const_f64_ptr)(reinterpret_cast<uintptr_t>(tl + u[t] * kp + kb));
+        tq[t][0] = pa[0]; tq[t][1] = pa[1];
+        tq[t][2] = pb[0]; tq[t][3] = pb[1];
+      }
+      double pv[2][LW], lpv[2][LW];
 #pragma unroll
       for (int j = 0; j < LW; ++j) {
-        pv[i][j] = tile[(k0 + i) * lp + cc[j]];
-        lpv[i][j] = ltile[(k0 + i) * lp + cc[j]];
+        pv[0][j] = tile[ka * lp + cc[j]];
+        lpv[0][j] = ltile[ka * lp + cc[j]];
+        pv[1][j] = tile[kb * lp + cc[j]];
+        lpv[1][j] = ltile[kb * lp + cc[j]];
       }
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
       for (int j = 0; j < LW; ++j) {
-        const double ep = e[j] * pv[i][j], lep = le[j] + lpv[i][j];
+        const double ep = e[j] * pv[0][j], lep = le[j] + lpv[0][j];
 #pragma unroll
         for (int t = 0; t < TB; ++t)
-          acc[t] = fma(fmax(tq[t][2 * i] * ep, kEps), fmax((tq[t][2 * i + 1] - ls[t]) + lep, cl[t]), acc[t]);
+          acc[t] = fma(fmax(tq[t][0] * ep, kEps), fmax((tq[t][1] - ls[t]) + lep, cl[t]), acc[t]);
       }
+      if (two) {
+#pragma unroll
+        for (int j = 0; j < LW; ++j) {
+          const double ep = e[j] * pv[1][j], lep = le[j] + lpv[1][j];
+#pragma unroll
+          for (int t = 0; t < TB; ++t)
+            acc[t] = fma(fmax(tq[t][2] * ep, kEps), fmax((tq[t][3] - ls[t]) + lep, cl[t]), acc[t]);
+        }
+      }
+    }
   }
+  // this lane's columns: LW - n_inv real ones; a visited row's other columns each added exactly eps (log eps - ls)
+  // -- eta = 0, log eta = -inf -- and come off again, a dead row's real columns each go in with the same amount
+  const double count = static_cast<double>((k_groups - n_proc) * (LW - n_inv) - n_proc * n_inv);
   double tot = 0.0;
 #pragma unroll
   for (int t = 0; t < TB; ++t)
-    if (t < nt) tot += acc[t] - fake * (kEps * cl[t]);
+    if (t < nt) tot += acc[t] + count * (kEps * cl[t]);
   return tot;
 }
 
@@ -104,7 +156,7 @@ __global__ __launch_bounds__(kLikWaveThreads) void lik_wave_kernel(
     RowTab a_tab, const double *__restrict__ eta, const double *__restrict__ leta, const double *__restrict__ p,
     const double *__restrict__ logp, double *__restrict__ block_out, int k_groups, int l_groups, int kp, int lp) {
   constexpr int NW = kLikWaveThreads / 64;
-  extern __shared__ double lds[];  // [kp*lp] tile, [kp*lp] its logarithms
+  extern __shared__ double lds[];  // [kp*lp] tile, [kp*lp] its logarithms, [kp] the tile's row maxima
   __shared__ int32_t poff[kUnitPairs + 4];
   __shared__ double red[NW];
   const mmsbm::Chunk ch = units[blockIdx.x];
@@ -121,6 +173,13 @@ __global__ __launch_bounds__(kLikWaveThreads) void lik_wave_kernel(
     }
   }
   __syncthreads();
+  double *prmax = ltile + static_cast<size_t>(kp) * lp;
+  for (int k = tid; k < kp; k += kLikWaveThreads) {
+    double mx = 0.0;
+    for (int l = 0; l < l_groups; ++l) mx = fmax(mx, tile[k * lp + l]);
+    prmax[k] = mx;
+  }
+  __syncthreads();
   const const_i32_ptr users = (const_i32_ptr)(reinterpret_cast<uintptr_t>(pair_user));
   const double log_eps = log(kEps);
   int cc[LW], n_inv = 0;
@@ -130,27 +189,28 @@ __global__ __launch_bounds__(kLikWaveThreads) void lik_wave_kernel(
     cc[j] = min(col, lp - 1);
     n_inv += col >= l_groups ? 1 : 0;
   }
-  // what this lane's LW columns x kp rows hold beyond the real K x (its real columns): each such element is
-  // exactly eps (log eps - ls) -- zero padding of theta / tile rows, -inf logarithms -- and is taken off again
-  const double fake = static_cast<double>(kp * LW - k_groups * (LW - n_inv));
   const int na = (kp + 63) / 64;  // (<= 3: the host sends wider rows elsewhere)
   double total = 0.0;
   for (int pq = wave; pq < npairs; pq += NW) {
     const int q = ch.q_begin + pq;
     const int t0 = __builtin_amdgcn_readfirstlane(poff[pq]), t1 = __builtin_amdgcn_readfirstlane(poff[pq + 1]);
     const size_t irow = static_cast<size_t>(__builtin_amdgcn_readfirstlane(pair_item[q]));
-    double e[LW], le[LW], av[3];
+    double e[LW], le[LW], av[3], bk[3], emax = 0.0;
 #pragma unroll
     for (int j = 0; j < LW; ++j) {
       const bool ok = lane + 64 * j < l_groups;
       const double ev = eta[irow * lp + cc[j]], lv = leta[irow * lp + cc[j]];
       e[j] = ok ? ev : 0.0;
       le[j] = ok ? lv : -INFINITY;
+      emax = fmax(emax, e[j]);
     }
+    emax = group_max<64>(emax);
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
       const int kk = lane + 64 * m;
-      av[m] = (m < na && kk < kp) ? *rowtab_ptr(a_tab, static_cast<size_t>(q), kk) : 0.0;
+      const bool on = m < na && kk < kp;
+      av[m] = on ? *rowtab_ptr(a_tab, static_cast<size_t>(q), kk) : 0.0;
+      bk[m] = on ? emax * prmax[kk] : 0.0;
     }
     for (int c0 = t0; c0 < t1; c0 += 4) {
       const int nt = min(4, t1 - c0);
@@ -158,9 +218,9 @@ __global__ __launch_bounds__(kLikWaveThreads) void lik_wave_kernel(
 #pragma unroll
       for (int t = 0; t < 4; ++t) u[t] = static_cast<size_t>(users[c0 + min(t, nt - 1)]);
       // (a pair's last one or two triples run the narrower instantiations: no work for slots that hold nothing)
-      if (nt > 2) total += lik_wave_chunk<LW, 4>(tl, u, nt, lane, av, na, tile, ltile, e, le, cc, kp, lp, fake, log_eps);
-      else if (nt == 2) total += lik_wave_chunk<LW, 2>(tl, u, nt, lane, av, na, tile, ltile, e, le, cc, kp, lp, fake, log_eps);
-      else total += lik_wave_chunk<LW, 1>(tl, u, nt, lane, av, na, tile, ltile, e, le, cc, kp, lp, fake, log_eps);
+      if (nt > 2) total += lik_wave_chunk<LW, 4>(tl, u, nt, lane, av, bk, na, tile, ltile, e, le, cc, k_groups, kp, lp, n_inv, log_eps);
+      else if (nt == 2) total += lik_wave_chunk<LW, 2>(tl, u, nt, lane, av, bk, na, tile, ltile, e, le, cc, k_groups, kp, lp, n_inv, log_eps);
+      else total += lik_wave_chunk<LW, 1>(tl, u, nt, lane, av, bk, na, tile, ltile, e, le, cc, k_groups, kp, lp, n_inv, log_eps);
     }
   }
   total = group_sum<64>(total);

@@ -265,10 +265,14 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
     c->lds_ma = pair_mfma_lds(c->lp, c->kp, false);
     c->mfma = mfma_possible(c.get()) && c->kp * c->lp > 1024 && std::getenv("MMSBM_HIP_NO_MFMA") == nullptr;
     // K or L beyond 64: the blocked matrix-core kernels take over from the lane-per-pair stage with its tile in
-    // scalar loads and from the wide-row kernels (skinny shapes -- a side below 16 -- keep those: one
-    // 16 x 16 tile would be mostly padding)
-    c->mfma_big = !c->mfma && c->kp * c->lp > 1024 && std::min(c->kp, c->lp) >= 16 &&
-                  std::getenv("MMSBM_HIP_NO_MFMA") == nullptr;
+    // scalar loads and from the wide-row kernels
+    // Skinny tiles too (a side below 16 groups, e.g. 600 x 5 or 3 x 1,024): three quarters of a 16-wide tile are
+    // padding there, and it is still several times faster than the alternatives -- the wide-row kernels have one
+    // thread per output column (8 of 256 threads busy at L = 5), the lane-per-pair stage streams a 38 KB tile
+    // through the scalar cache.  1M ratings, T+S / A launch: 600 x 5 2,336 / 124 -> 380 / 115 us, 1,024 x 3
+    // 5,822 / 152 -> 621 / 171, 8 x 520 471 / 927 -> 247 / 191, 3 x 1,024 470 / 3,219 -> 430 / 346, 300 x 8
+    // 310 / 91 -> 197 / 53 (scripts/skinny_time.py, round 3).
+    c->mfma_big = !c->mfma && c->kp * c->lp > 1024 && std::getenv("MMSBM_HIP_NO_MFMA") == nullptr;
     int big_chunk = 4 * mmsbm::kMvChunkPairs;
     if (c->mfma && c->lay.n_pairs >= 2 * big_chunk * 4 * c->n_cus) big_chunk *= 2;
     if (const char *e = std::getenv("MMSBM_HIP_MFMA_CHUNK")) big_chunk = std::min(std::max(std::atoi(e) / 64 * 64, 64), kMfmaChunkPairs);  // (tuning)
@@ -660,7 +664,7 @@ namespace {
 // are shared by four triples at a time).  Returns the number of partial sums.
 bool lik_pairs_usable(const mmsbm_hip_ctx *c) {
   return c->lik_mode == 2 && c->lp > 32 && c->lp <= 192 && c->kp <= 192 && c->n_lik_units > 0 && c->n_pairs > 0 &&
-         2 * static_cast<size_t>(c->kp) * c->lp * sizeof(double) <= kLdsMax - 4096 &&
+         (2 * static_cast<size_t>(c->kp) * c->lp + c->kp) * sizeof(double) <= kLdsMax - 4096 &&
          c->n_obs * 2 >= static_cast<int64_t>(c->n_pairs) * 5;
 }
 int likelihood_pairs(mmsbm_hip_ctx *c) {
@@ -681,7 +685,7 @@ int likelihood_pairs(mmsbm_hip_ctx *c) {
   log_table_kernel<<<blocks(np), kBlock, 0, st>>>(p, c->lg_p.ptr, np);
   const int nb = c->n_lik_units;
   if (c->lik_part.count < static_cast<size_t>(nb)) c->lik_part.alloc(static_cast<size_t>(nb));
-  const size_t lds = 2 * static_cast<size_t>(c->kp) * c->lp * sizeof(double);
+  const size_t lds = (2 * static_cast<size_t>(c->kp) * c->lp + c->kp) * sizeof(double);
 #define WAVE_GO(LW_)                                                                                 \
   do {                                                                                               \
     allow_big_lds(lik_wave_kernel<LW_>, lds);                                                        \
@@ -1097,6 +1101,8 @@ int mmsbm_hip_time_stage(mmsbm_hip_ctx *ctx, int stage, int reps, float *mean_us
     struct Reset { mmsbm_hip_ctx *c; ~Reset() { c->ablate = 0; } } reset{ctx};
     if (!mean_us || reps <= 0 || stage < 0 || stage >= K_COUNT)
       throw std::invalid_argument("bad argument");
+    if ((stage == K_FUSED_PAIRS || stage == K_FUSED_TAIL) && !fused_possible(ctx))
+      throw std::invalid_argument("time_stage: the two-launch kernels do not apply to this shape / data");
     use_device(ctx);
     ensure_a(ctx);
     auto one = [&] {

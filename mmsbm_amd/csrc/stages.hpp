@@ -177,7 +177,8 @@ void stage_seg(mmsbm_hip_ctx *c, bool commit, bool with_pairs, bool with_users, 
   const int bu = (with_users && sw == 1) ? (su.nseg + per - 1) / per : 0;
   if (bp + bu > 0) {  // one slot per workgroup (blockIdx.y = slot)
 #define SEG_GO(G, V, B) LAUNCH_IN(ls, (seg_pass_kernel<G, V, B>), slot_grid(c, bp + bu), kBlock, 0, st, sp, su, bp, c->kp)
-    if (c->seg_batch == 8) {  // (eight row gathers in flight per group: small problems)
+    if (c->seg_batch == 8 && c->code_k <= 4) {  // (eight row gathers in flight per group: small problems; not with
+                                                  // 8 or 16 doubles per lane and row: that is 128 - 256 registers)
 #define CALL(G, V) SEG_GO(G, V, 8)
       DISPATCH_GV(c->code_k, CALL);
 #undef CALL

@@ -33,7 +33,7 @@ for opts in ({"mfma": 0}, {"mfma": 1, "mfma_threads": 512}, {"mfma": 1, "mfma_th
     ctx.iterate(10)
     reps = 30
     it = min(ctx.time_iterations(reps) for _ in range(3)) * 1000 / reps
-    st = [min(ctx.time_stage(s, 10) for _ in range(2)) for s in range(lib.mmsbm_hip_kernel_count())]
+    st = [min(ctx.time_stage(s, 10) for _ in range(2)) for s in range(4)]
     print(f"{opts}: iteration {it:8.2f} us   stages " + "  ".join(f"{x:7.2f}" for x in st), flush=True)
 err = [max(float(np.max(np.abs(a - b) / np.maximum(np.abs(a), 1e-300))) for a, b in zip(outs[0], o)) for o in outs[1:]]
 print("max relative difference to the lane-per-pair kernels after 3 iterations:", err)

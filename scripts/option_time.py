@@ -28,6 +28,6 @@ for v in values:
     ctx.iterate(30)
     reps = 300 if n <= 1_000_000 else 30
     it = min(ctx.time_iterations(reps) for _ in range(3)) * 1000 / reps
-    st = [ctx.time_stage(s, 100 if n <= 1_000_000 else 10) for s in range(lib.mmsbm_hip_kernel_count())]
+    st = [ctx.time_stage(s, 100 if n <= 1_000_000 else 10) for s in range(4)]
     print(f"{opt}={v:g}: iteration {it:8.2f} us   stages " + "  ".join(f"{x:7.2f}" for x in st), flush=True)
 print("bitwise identical to the first:", [all(np.array_equal(a, b) for a, b in zip(outs[0], o)) for o in outs[1:]])

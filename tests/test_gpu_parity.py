@@ -1171,11 +1171,13 @@ def test_pair_stage_on_the_matrix_cores(hip, k, l, forced):
 
 
 @pytest.mark.parametrize("k,l,mode", [(80, 80, 1), (100, 100, 1), (130, 70, 1), (65, 16, 1), (200, 200, 1), (300, 24, 1),
+                                      (600, 5, 1), (8, 520, 1), (1024, 3, 1), (3, 1024, 1), (300, 8, 1), (200, 12, 1), (5, 260, 1),
                                       (20, 20, 2), (50, 50, 2), (7, 64, 2), (64, 64, 2)])
 def test_pair_stage_on_the_matrix_cores_blocked(hip, k, l, mode):
     """K or L beyond 64: mfma_rows_kernel + mfma_slab_kernel (64 x 64 blocks), the library's own choice
-    where both sides have at least 16 groups; forced (option mfma = 2) on shapes the one-block kernel or
-    the vector kernels would take.  Ragged chunks, restart slots, either orientation; against the oracle
+    for every K x L > 1,024 the one-block kernel does not take -- skinny tiles included (one side of 3 .. 12
+    groups: most of a 16-wide tile is padding there, round 3); forced (option mfma = 2) on shapes the one-block
+    kernel or the vector kernels would take.  Ragged chunks, restart slots, either orientation; against the oracle
     and against the vector-ALU kernels (lane-per-pair stage or wide rows) of the same context."""
     rng = np.random.default_rng(1000 * k + l)
     n_u, n_i, n_r = 200, 150, 3
@@ -1216,11 +1218,11 @@ def test_pair_stage_on_the_matrix_cores_blocked(hip, k, l, mode):
 
 
 @pytest.mark.parametrize("k,l,family", [(32, 32, 0.0), (31, 32, 0.0), (31, 33, 1.0), (32, 36, 1.0), (36, 29, 1.0), (64, 64, 1.0), (61, 64, 1.0),
-                                        (64, 65, 2.0), (68, 16, 2.0), (13, 100, 2.0), (12, 100, 0.0), (9, 130, 0.0)])
+                                        (64, 65, 2.0), (68, 16, 2.0), (13, 100, 2.0), (12, 100, 2.0), (9, 130, 2.0), (8, 128, 0.0), (3, 300, 0.0), (4, 260, 2.0)])
 def test_pair_stage_families_at_their_borders(hip, k, l, family):
     """Which kernels take the pair stage is decided from (K, L): vector ALUs while the padded tile is at most
-    1,024 entries or a side has fewer than 16 (padded) groups, the one-block matrix-core kernel up to 64 per
-    side, the blocked kernels beyond.  Shapes on both sides of every border, against the oracle."""
+    1,024 entries, the one-block matrix-core kernel up to 64 per side, the blocked kernels beyond -- skinny
+    tiles included (round 3).  Shapes on both sides of every border, against the oracle."""
     rng = np.random.default_rng(k * 131 + l)
     n_u, n_i, n_r, n = 90, 70, 3, 1500
     data = np.stack([rng.integers(0, n_u, n), rng.integers(0, n_i, n), rng.integers(0, n_r, n)], axis=1).astype(np.int64)
