@@ -25,6 +25,7 @@ int group_code(int dp) {
   if (dp <= 512) return 5;  // G=64 VEC=8
   return 6;                 // G=64 VEC=16 (up to 1,024 groups)
 }
+constexpr int kMaxGroupRow = 1024;  // columns the widest (G, VEC) covers; wider rows: seg_wide_kernel / block loops
 int group_lanes(int code) {
   static const int g[7] = {4, 8, 16, 32, 64, 64, 64};
   return g[code];

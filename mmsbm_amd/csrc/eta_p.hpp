@@ -155,8 +155,9 @@ __device__ __forceinline__ void item_sum_block(
   constexpr int B = VEC <= 4 ? 8 : (VEC == 8 ? 4 : 2);
   const int it = block * (static_cast<int>(blockDim.x) / G) + threadIdx.x / G;
   const int gl = threadIdx.x % G;
-  if (it >= n_items || gl * VEC >= lp) return;
-  const int lane_off = gl * VEC;
+  if (it >= n_items) return;
+  // (rows of more than G x VEC = 1,024 groups: one more trip per 1,024 columns -- every column is its own sum)
+  for (int lane_off = gl * VEC; lane_off < lp; lane_off += G * VEC) {
   double acc[VEC], e[VEC];
 #pragma unroll
   for (int v = 0; v < VEC; ++v) acc[v] = 0.0;
@@ -202,6 +203,7 @@ __device__ __forceinline__ void item_sum_block(
 #pragma unroll
   for (int v = 0; v < VEC; ++v) e[v] = normalize ? (e[v] * acc[v]) / d : e[v] * acc[v];
   store_vec<VEC>(eta_new + static_cast<size_t>(it) * lp + lane_off, e);
+  }
 }
 
 // eta_p -- the two independent updates that follow the T / slab stage share ONE launch:

@@ -138,8 +138,8 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
     if (!out) throw std::invalid_argument("null out");
     *out = nullptr;
     if (k_groups <= 0 || l_groups <= 0) throw std::invalid_argument("K and L must be positive");
-    if (k_groups > 1024 || l_groups > 1024)
-      throw ApiError(MMSBM_E_UNSUPPORTED, "K and L are limited to 1024 groups (64 lanes x 16 doubles per row)");
+    if (static_cast<int64_t>(k_groups) * l_groups > (int64_t(1) << 26))
+      throw ApiError(MMSBM_E_UNSUPPORTED, "K x L beyond 2^26 entries per rating tile");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
       throw ApiError(MMSBM_E_NODEVICE, "no HIP device available (this library has no CPU path)");
@@ -203,8 +203,6 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
     // dependent gathers per segment, and eight rows in flight per group beat four (C1 16.8 -> 16.1 us, C2 29.7 ->
     // 29.1 us per iteration); at C3 four are better (95.3 vs 97.3 us)
     c->seg_batch = n_obs <= 300000 ? 8 : 4;
-    if (n_ratings > 65535)
-      throw ApiError(MMSBM_E_UNSUPPORTED, "more than 65535 distinct ratings are not supported");
 
     lap("checks");
     // The sorts: on the host for small inputs (14 ms at 1M ratings), on the device beyond
@@ -293,7 +291,10 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
     c->n_chunks = static_cast<int>(c->lay.mv_chunks.size());
     // dense data: XCD-local work lists (layout.hpp) -- every segment cut at fixed borders of the
     // gathered index, each range's work on one XCD, whose L2 then holds that slice of the table
-    if (std::getenv("MMSBM_HIP_NO_RANGES") == nullptr) {
+    if (c->kp > kMaxGroupRow) {  // rows beyond the widest group-of-lanes instantiation: seg_wide_kernel, whole segments
+      c->lay.pair_work = mmsbm::WorkList();
+      c->lay.user_work = mmsbm::WorkList();
+    } else if (std::getenv("MMSBM_HIP_NO_RANGES") == nullptr) {
       const int per = kBlock / group_lanes(c->code_k);
       const size_t row_bytes = static_cast<size_t>(c->kp) * sizeof(double);
       const int64_t mean_p = c->n_pairs > 0 ? n_obs / c->n_pairs : 0, mean_u = n_obs / std::max(c->n_users, 1);

@@ -424,6 +424,14 @@ __global__ __launch_bounds__(kBlock) void predict_rows_kernel(
           double pt = 0.0;
 #pragma unroll
           for (int v = 0; v < VEC; ++v) pt = fma(g[b][v], f[v], pt);
+          // (rows of more than G x VEC = 1,024 groups: the remaining columns, 1,024 at a time)
+          for (int cb = G * VEC + gl * VEC; cb < dp; cb += G * VEC) {
+            double f2[VEC], g2[VEC];
+            load_vec<VEC>(rowtab_ptr(theta, static_cast<size_t>(pu[m]), cb), f2);
+            load_vec<VEC>(btab + static_cast<size_t>(pi[m]) * dp + static_cast<size_t>(r) * rating_stride + cb, g2);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) pt = fma(g2[v], f2[v], pt);
+          }
           const double v = group_sum<G>(pt);
           if (MODE == 0) {
             if (gl == 0) srow[r] = v;

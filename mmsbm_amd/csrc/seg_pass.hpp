@@ -167,6 +167,87 @@ __global__ __launch_bounds__(kBlock) void seg_pass_slots_kernel(SegArgs sa, SegA
   seg_body<G, VEC, B, SW>(first ? sa : sb, blk * (kBlock / (G * SW)) + threadIdx.x / (G * SW), dp, n_slots);
 }
 
+// Rows of more than 1,024 groups (the widest instantiation above is 64 lanes x 16 doubles).  The reference has no
+// size limit (src/kernels_numpy.py:21-79), so these run too -- in a plain form: one WAVE per segment, the row walked in
+// blocks of 64 x 16 doubles.  A triple's weight needs the dot product over the WHOLE row before any column can be
+// added up, so a chunk of up to 64 triples is handled in two sweeps: first every triple's weight (lane j keeps the
+// weight of triple j), then, block by block, acc[block] += row[block] * weight over the chunk's triples -- the rows
+// are read twice (the second time from L2).  Between the chunks of a long segment the raw sums wait in the output row.
+// Same sums as seg_body in the same order per column; only the dot product is associated per block.
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void seg_wide_kernel(SegArgs sa, SegArgs sb, int blocks_a, int dp) {
+  constexpr int G = 64, BW = G * VEC;  // columns per block
+  const bool first = static_cast<int>(blockIdx.x) < blocks_a;
+  const SegArgs &a = first ? sa : sb;
+  const int blk = first ? blockIdx.x : blockIdx.x - blocks_a;
+  const int lane = threadIdx.x % G, unit = blk * (kBlock / G) + threadIdx.x / G;
+  if (unit >= a.nseg) return;  // whole waves
+  const size_t slot = blockIdx.y;
+  const RowTab fixed = slot_tab(a.fixed, slot), gath = slot_tab(a.gath, slot), outt = slot_tab(a.out, slot);
+  const int seg = unit, beg = a.off[unit], end = a.off[unit + 1];  // (no work lists for these shapes)
+  const int nblk = (dp + BW - 1) / BW;
+  for (int c0 = beg; c0 < end; c0 += G) {
+    const int cnt = min(G, end - c0);
+    const int myidx = a.idx[c0 + min(lane, cnt - 1)];
+    double myw = 0.0;
+    for (int j = 0; j < cnt; ++j) {
+      const size_t id = static_cast<size_t>(__shfl(myidx, j, G));
+      double pt = 0.0;
+      for (int b = 0; b < nblk; ++b) {
+        const int off = b * BW + lane * VEC;
+        if (off < dp) {
+          double g[VEC], f[VEC];
+          load_vec<VEC>(rowtab_ptr(gath, id, off), g);
+          load_vec<VEC>(rowtab_ptr(fixed, static_cast<size_t>(seg), off), f);
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) pt = fma(g[v], f[v], pt);
+        }
+      }
+      const double w = 1.0 / fmax(group_sum<G>(pt), kEps);
+      if (lane == j) myw = w;
+    }
+    for (int b = 0; b < nblk; ++b) {
+      const int off = b * BW + lane * VEC;
+      if (off >= dp) continue;  // (no cross-lane operation below: each lane owns its columns)
+      double acc[VEC];
+      if (c0 == beg) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] = 0.0;
+      } else {
+        load_vec<VEC>(rowtab_ptr(outt, static_cast<size_t>(seg), off), acc);
+      }
+      for (int j = 0; j < cnt; ++j) {
+        // (shuffles by every lane of the wave that is still here: lanes past the row's end left together above)
+        const size_t id = static_cast<size_t>(__builtin_amdgcn_readlane(myidx, j));
+        const double w = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(myw), j),
+                                          __builtin_amdgcn_readlane(__double2loint(myw), j));
+        double g[VEC];
+        load_vec<VEC>(rowtab_ptr(gath, id, off), g);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] = fma(g[v], w, acc[v]);
+      }
+      if (c0 + G >= end && a.mode != 0) {  // the segment is complete: its epilogue
+        double f[VEC];
+        load_vec<VEC>(rowtab_ptr(fixed, static_cast<size_t>(seg), off), f);
+        const double d = static_cast<double>(max(end - beg, 1));
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] = a.mode == 1 ? (f[v] * acc[v]) / d : f[v] * acc[v];
+      }
+      store_vec<VEC>(rowtab_ptr(outt, static_cast<size_t>(seg), off), acc);
+    }
+  }
+  if (beg == end) {  // an id that never occurs: a zero row (what the loop-free epilogue of seg_body gives)
+    for (int b = 0; b < nblk; ++b) {
+      const int off = b * BW + lane * VEC;
+      if (off >= dp) continue;
+      double z[VEC];
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) z[v] = 0.0;
+      store_vec<VEC>(rowtab_ptr(outt, static_cast<size_t>(seg), off), z);
+    }
+  }
+}
+
 // Long segments: add the pieces' partial rows in piece order and apply the epilogue.
 struct CombineArgs {
   const mmsbm::SplitSeg *splits;

@@ -139,6 +139,13 @@ EtaPArgs eta_p_args(const mmsbm_hip_ctx *c, bool commit, int cols_per_block) {
 void stage_seg(mmsbm_hip_ctx *c, bool commit, bool with_pairs, bool with_users, hipStream_t st) {
   const SegArgs sp = seg_pairs_args(c), su = seg_users_args(c, commit, c->n_users);
   const int per = kBlock / group_lanes(c->code_k);
+  if (c->kp > kMaxGroupRow) {  // rows of more than 1,024 groups: a wave per segment, the row in blocks (no work lists)
+    LaunchScope ls(c, K_SEG, st == c->stream);
+    const int bp = with_pairs ? (sp.nseg + per - 1) / per : 0, bu = with_users ? (su.nseg + per - 1) / per : 0;
+    if (bp + bu > 0) LAUNCH_IN(ls, (seg_wide_kernel<16>), slot_grid(c, bp + bu), kBlock, 0, st, sp, su, bp, c->kp);
+    ls.done();
+    return;
+  }
   // several restart slots: a super-group of SW x G lanes per segment (seg_pass_slots_kernel)
   int sw = 1;
   if (c->launch_slots > 1 && c->slot_waves) {

@@ -19,7 +19,9 @@ def short(name):
                     ("pair_block_kernel<true", "pair_block_kernel(A)"), ("pair_quad_a_kernel", "pair_block_kernel(A)"),
                     # (K x L > 1024: the same two launches run pair_mfma_kernel; full_name keeps the kernel's own name)
                     ("pair_mfma_kernel<false", "pair_block_kernel(T+S)"), ("pair_mfma_kernel<true", "pair_block_kernel(A)"),
-                    ("eta_p_kernel", "eta_p_kernel"), ("seg_combine_small_kernel", "seg_combine_small_kernel"),
+                    ("eta_p_kernel", "eta_p_kernel"), ("pairs_fused_kernel", "pairs_fused_kernel"), ("tail_fused_kernel", "tail_fused_kernel"),
+                    ("lik_wave_kernel", "lik_wave_kernel"), ("theta_log_pairs_kernel", "theta_log_pairs_kernel"),
+                    ("seg_combine_small_kernel", "seg_combine_small_kernel"),
                     ("seg_combine_kernel", "seg_combine_kernel"), ("likelihood_fast_kernel", "likelihood_fast_kernel"), ("log_table_kernel", "log_table_kernel"),
                     ("init_rows_kernel", "init_rows_kernel"), ("likelihood_units_kernel", "likelihood_units_kernel"),
                     ("likelihood_kernel", "likelihood_kernel"), ("prod_dist_kernel", "prod_dist_kernel")):
@@ -55,12 +57,9 @@ with open(os.path.join(dst, f"{tag}_pmc.csv"), "w", newline="") as fh:
             v = agg[nm][cn]; w.writerow([nm, cn, f"{sum(v) / len(v):.1f}", len(v)])
 
 def kernel_source_sha16():  # the same identity bench.py computes: a profile is only valid for these sources
-    h = hashlib.sha256()
-    csrc = os.path.join(root, "mmsbm_amd", "csrc")
-    for name in sorted(f for f in os.listdir(csrc) if f.endswith((".hip", ".hpp"))):
-        with open(os.path.join(csrc, name), "rb") as fh:
-            h.update(name.encode() + b"\0" + fh.read())
-    return h.hexdigest()[:16]
+    sys.path.insert(0, root)
+    from mmsbm_amd.build import source_id
+    return source_id()
 
 summary_path = os.path.join(dst, "pmc_summary.json")
 summary = json.load(open(summary_path)) if os.path.exists(summary_path) else {}

@@ -466,8 +466,10 @@ def test_c_abi_error_paths(hip):
         HipEM(np.array([[0, 0, 0], [7, 0, 0]]), 2, 2, n_users=2, n_items=1, n_ratings=1)
     assert e.value.code == _lib.E_INVALID and "out of range" in e.value.message
     with pytest.raises(_lib.HipLibraryError) as e:
-        HipEM(good, 1025, 2)                                # 64 lanes x 16 doubles per row is the widest form
-    assert e.value.code == _lib.E_UNSUPPORTED and "1024" in e.value.message
+        HipEM(good, 9000, 9000)                             # a rating tile of more than 2^26 entries
+    assert e.value.code == _lib.E_UNSUPPORTED and "2^26" in e.value.message
+    with HipEM(good, 1025, 2) as em:                        # beyond 64 lanes x 16 doubles per row: runs since round 3
+        assert em.n_pairs == 3
     with HipEM(good, 200, 200) as em:                       # beyond the 64-pair LDS stage: wide-row kernels,
         assert em.get_option("wide") == 1.0                 # no longer refused
     with pytest.raises(_lib.HipLibraryError) as e:
@@ -1063,6 +1065,67 @@ def test_wide_group_counts_beyond_the_lds_tile(hip, k, l):
                 assert rel_err(got, w) < 1e-11, nm
             assert em.likelihood() == pytest.approx(float(orc.compute_likelihood(data, t, e, p)), rel=1e-11)
             assert np.allclose(em.prod_dist(data[:50]), orc.prod_dist(data[:50], t, e, p), rtol=1e-11, atol=1e-300)
+
+
+@pytest.mark.parametrize("k,l,n", [(1500, 3, 700), (3, 1500, 700), (1100, 20, 500), (2100, 2, 400), (1040, 1030, 60)])
+def test_more_than_1024_groups_per_side(hip, k, l, n):
+    """The reference's numpy backend has no size limit (src/kernels_numpy.py:21-79).  Rows beyond the widest
+    group-of-lanes instantiation (64 lanes x 16 doubles = 1,024 groups) run since round 3: the triple passes as
+    seg_wide_kernel (a wave per segment, the row in blocks of 1,024 columns, weights first, then the columns),
+    item_sum and the prediction rows with one more trip per 1,024 columns, the pair stage on the blocked
+    matrix-core kernels.  Segments longer than a wave's 64 triples (a busy user / a popular pair) included; same
+    checks as every other shape, either side paired with the rating, two restart slots."""
+    rng = np.random.default_rng(k * 7 + l)
+    n_u, n_i, n_r = 30, 12, 3
+    u_col = np.where(rng.random(n) < 0.3, 4, rng.integers(0, n_u, n))      # user 4: ~ n / 3 triples (> 64)
+    i_col = np.where(rng.random(n) < 0.3, 2, rng.integers(0, n_i, n))      # item 2 likewise
+    data = np.stack([u_col, i_col, rng.integers(0, n_r, n)], axis=1).astype(np.int64)
+    d_u, d_i = orc.degrees(data, n_u, n_i)
+    theta, eta, pr = orc.init_params(5, n_u, n_i, n_r, k, l, d_u, d_i)
+    want = orc.update_coefficients(data, theta, eta, pr)
+    t, e, p = theta, eta, pr
+    for _ in range(2):
+        t, e, p = orc.em_step(data, t, e, p, d_u, d_i)
+    for swap in (0, 1):
+        with hip.HipEM(data, k, l, n_u, n_i, n_r, slots=2, swap_sides=swap) as em:
+            em.select(1).set_params(theta * 0.5, eta, pr)
+            em.select(0).set_params(theta, eta, pr)
+            for got, w, nm in zip(em.update_coefficients(), want, ("n_theta", "n_eta", "n_pr")):
+                assert rel_err(got, w) < TOL_STEP, (nm, rel_err(got, w))
+                assert_elementwise(got, w, nm, rtol=1e-11)
+            em.iterate(2)
+            for got, w, nm in zip(em.get_params(), (t, e, p), ("theta", "eta", "pr")):
+                assert rel_err(got, w) < 1e-11, nm
+            assert em.likelihood() == pytest.approx(float(orc.compute_likelihood(data, t, e, p)), rel=1e-11)
+            assert np.allclose(em.prod_dist(data[:50]), orc.prod_dist(data[:50], t, e, p), rtol=1e-11, atol=1e-300)
+            st = em.select(1).get_params()
+            seen = np.bincount(data[:, 0], minlength=n_u) > 0
+            assert np.all(np.isfinite(st[0])) and np.allclose(st[0].sum(1)[seen], 1.0, atol=1e-12)
+
+
+def test_more_than_65535_rating_values(hip):
+    """R = 70,000 distinct rating values (most (item, rating) pairs hold one triple): no limit on R either.
+    Checked against the factorised checker (pinned to the dense oracle in tests/test_oracle_golden.py): the dense
+    oracle restates the reference's per-rating mask loop, which is O(R N)."""
+    from oracle import mmsbm_factorised as fac
+    rng = np.random.default_rng(5)
+    n, n_u, n_i, n_r = 80_000, 500, 300, 70_000
+    r_col = np.concatenate([np.arange(n_r), rng.integers(0, n_r, n - n_r)])
+    data = np.stack([rng.integers(0, n_u, n), rng.integers(0, n_i, n), r_col], axis=1).astype(np.int64)
+    d_u, d_i = orc.degrees(data, n_u, n_i)
+    theta, eta, pr = orc.init_params(5, n_u, n_i, n_r, 2, 3, d_u, d_i)
+    pairs = fac.Pairs(data, n_u, n_i, n_r)
+    want = fac.update_coefficients(data, theta, eta, pr, pairs)
+    with make_ctx(hip, data, theta, eta, pr) as em:
+        for got, w, nm in zip(em.update_coefficients(), want, ("n_theta", "n_eta", "n_pr")):
+            assert rel_err(got, w) < TOL_STEP, nm
+        em.iterate(2)
+        t, e, p = theta, eta, pr
+        for _ in range(2):
+            t, e, p = fac.em_step(data, t, e, p, d_u, d_i, pairs)
+        for got, w, nm in zip(em.get_params(), (t, e, p), ("theta", "eta", "pr")):
+            assert rel_err(got, w) < 1e-11, nm
+        assert em.likelihood() == pytest.approx(float(fac.compute_likelihood(data, t, e, p, pairs)), rel=1e-11)
 
 
 @pytest.mark.parametrize("k,l,n", [(200, 200, 3000), (170, 160, 1500), (300, 24, 1500), (8, 520, 1200), (600, 5, 900),
