@@ -1157,6 +1157,7 @@ int mmsbm_hip_set_option(mmsbm_hip_ctx *ctx, const char *name, double value) {
     } else if (key == "fused") {  // two launches per iteration (small tiles, unsplit segments); any problem size
       if (value != 0.0 && !fused_possible(ctx)) throw std::invalid_argument("fused: not available for this shape / data");
       ctx->fused = value != 0.0;
+      ctx->fused_forced = value != 0.0;
     } else if (key == "seg_batch") {
       if (value != 4 && value != 8) throw std::invalid_argument("seg_batch: 4 or 8");
       ctx->seg_batch = static_cast<int>(value);

@@ -438,8 +438,15 @@ void mark_a(mmsbm_hip_ctx *c, bool ok) {
   for (int s = c->base_slot; s < c->base_slot + c->launch_slots; ++s) c->a_ok[static_cast<size_t>(s)] = ok ? 1 : 0;
 }
 
+// Two launches while the launches' work is small: ratings x restart slots of the launch <= 300,000 (measured, 100k
+// ratings at K = L = 10 per restart-iteration, two / four launches: 1 slot 20.9 / 29.3 us, 2 slots 15.0 / 16.3, 4 slots
+// 12.6 / 10.7, 8 slots 10.9 / 8.2 -- with several slots the four-launch form shares the index stream among them)
+bool use_fused(const mmsbm_hip_ctx *c) {
+  return c->fused && (c->fused_forced || c->n_obs * c->launch_slots <= 300000);
+}
+
 void launch_iteration(mmsbm_hip_ctx *c, bool commit) {
-  if (c->fused) {
+  if (use_fused(c)) {
     stage_fused_pairs(c);  // (writes A of the current parameters on its way)
     stage_fused_tail(c, commit);
     if (commit) c->cur ^= 1;
@@ -463,7 +470,7 @@ void run_iterations(mmsbm_hip_ctx *c, int n) {
     while (n >= 2) {
       const int slot = c->cur;
       if (!c->graph_exec[slot]) {
-        if (!c->fused) ensure_a(c);  // (outside the capture: a replay must not repeat it)
+        if (!use_fused(c)) ensure_a(c);  // (outside the capture: a replay must not repeat it)
         hipGraph_t graph = nullptr;
         HIP_CHECK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
         try {

@@ -28,10 +28,14 @@ for tag in sys.argv[1:] or ["c1", "c2", "c3"]:
         for s in range(slots):
             em.select(s).set_params(*mm.init_params(mm.child_states[s], d_u, d_i))
         iters = 200 if tag == "c3" else 1000
-        em.iterate(20)
-        ms = min(em.time_iterations(iters) for _ in range(3))
-        us = ms * 1000 / iters
-        base = base or us
-        print(f"{tag} slots={slots:2d}  {us:9.2f} us/iteration  {us / slots:8.2f} us per restart-iteration"
-              f"  x{base / (us / slots):5.2f}", flush=True)
+        line = f"{tag} slots={slots:2d}"
+        for fused in ((1, 0) if em.get_option("fused") else (0,)):   # small problems: two launches, and four for comparison
+            em.set_option("fused", fused)
+            em.iterate(20)
+            ms = min(em.time_iterations(iters) for _ in range(3))
+            us = ms * 1000 / iters
+            base = base or us
+            line += (f"  [{'two' if fused else 'four'} launches] {us:9.2f} us/iteration  {us / slots:8.2f} us per restart-iteration"
+                     f"  x{base / (us / slots):5.2f}")
+        print(line, flush=True)
         em.close()
