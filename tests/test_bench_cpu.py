@@ -45,8 +45,9 @@ def test_roofline_object_follows_survey_8d_and_reads_the_committed_profile():
     else:   # mid-development: rerun scripts/profile_round.sh + summarize_profile.py before the round ends
         assert rf["traffic"] is None and "stale" in rf["traffic_source"]
     assert rf["rocprof_avg_us"] == pmc["c3"]["seg_pass_kernel"]["avg_us"]
-    for cfg in ("c2", "c5"):   # every bench config has its summary, with the LDS-pipe counters
-        ent = pmc[cfg]["pair_block_kernel(T+S)"]
+    # every bench config has its summary, with the LDS-pipe counters (C2 runs the two-launch iteration)
+    for cfg, kern in (("c2", "pairs_fused_kernel"), ("c2", "tail_fused_kernel"), ("c5", "pair_block_kernel(T+S)")):
+        ent = pmc[cfg][kern]
         assert ent["avg_us"] > 0 and "SQ_WAIT_INST_LDS" in ent and "SQ_LDS_BANK_CONFLICT" in ent
 
 
