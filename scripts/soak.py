@@ -50,11 +50,11 @@ for j in range(300):
             print(f"create/destroy {j}: free {free_mb() - base:+.1f} MiB vs start", flush=True)
 print(f"after 300 contexts: free {free_mb() - base:+.1f} MiB vs start  [{time.time() - t0:.1f}s]")
 big = synthetic_triples(400_000, 40_000, 5_000, 6, 2)
-for j, (kk, ll) in enumerate([(50, 50), (100, 80), (200, 200), (300, 8)] * 5):      # every pair-stage family
+for j, (kk, ll) in enumerate([(50, 50), (100, 80), (200, 200), (300, 8), (600, 5), (3, 1024), (1500, 3), (4, 1100)] * 3):  # every pair-stage family
     with HipEM(big, kk, ll, slots=1 + j % 2) as em:
         for s in range(em.slots):
             em.select(s).init_params(j + s)
         em.iterate(2)
         em.select(0).prod_dist(big[:50_000])
         assert np.isfinite(em.select(0).likelihood())
-print(f"after 20 contexts with big tiles (matrix-core one-block / blocked, wide rows): free {free_mb() - base:+.1f} MiB vs start  [{time.time() - t0:.1f}s]")
+print(f"after 24 contexts with big tiles (matrix-core one-block / blocked, skinny, rows beyond 1,024 groups): free {free_mb() - base:+.1f} MiB vs start  [{time.time() - t0:.1f}s]")
