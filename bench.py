@@ -88,14 +88,24 @@ def kernel_source_sha16():
     return source_id()
 
 
-def gather_ranks(mine, world):
-    """[per-rank record] on every rank, in rank order (one all_gather_object; a list of one without a group)."""
+def gather_ranks(mine, world, device=None):
+    """[per-rank record] on every rank, in rank order: ONE all_gather of a fixed-size byte tensor (the record as
+    JSON, padded) on the device the backend wants -- plain tensor collectives only, the path RCCL is built for; a
+    list of one without a process group."""
+    import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or world == 1:
         return [mine]
-    parts = [None] * world
-    dist.all_gather_object(parts, mine)
-    return parts
+    width = 2048
+    raw = json.dumps(mine).encode()
+    if len(raw) > width:
+        raise ValueError("per-rank record too long")
+    buf = torch.zeros(width, dtype=torch.uint8)
+    buf[:len(raw)] = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
+    buf = buf.to(device if device is not None else "cpu")
+    parts = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(parts, buf)
+    return [json.loads(bytes(p.cpu().numpy().tobytes()).rstrip(b"\0").decode()) for p in parts]
 
 
 def cpu_baseline(cfg, sample_rows, iters):
@@ -299,7 +309,8 @@ def main():
                           "pci_bus_id": ident["pci_bus_id"], "compute_units": ident["compute_units"],
                           "hostname": socket.gethostname(), "pid": os.getpid(), "restart": rank,
                           "ms_per_step": 1000.0 * elapsed / args.steps,
-                          "steady_ms_per_step": steady_ms, "likelihood": float(lik), "build_id": build_id}, world)
+                          "steady_ms_per_step": steady_ms, "likelihood": float(lik), "build_id": build_id}, world,
+                         restarts._collective_device(device))
 
     out = None
     if rank == 0:

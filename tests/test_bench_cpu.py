@@ -87,3 +87,40 @@ def test_argument_defaults(monkeypatch):
     monkeypatch.setattr(sys, "argv", ["bench.py"])
     a = bench.parse_args()
     assert (a.gpus, a.config, a.no_cpu_baseline, a.batched_restarts) == (1, "c3", False, 0) and a.steps >= 100
+
+
+GATHER_WORKER = """
+import os, sys
+sys.path.insert(0, {root!r})
+import torch, torch.distributed as dist
+import bench
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+mine = {{"rank": rank, "device_name": "AMD (gfx950:sramecc+:xnack-)", "pci_bus_id": "0000:%02x:00.0" % (5 + rank),
+        "ms_per_step": 0.1 + rank, "steady_ms_per_step": None, "likelihood": -1.5 * rank}}
+out = bench.gather_ranks(mine, world, torch.device("cpu"))
+assert [r["rank"] for r in out] == [0, 1] and out[rank] == mine and out[1]["pci_bus_id"] == "0000:06:00.0", out
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_per_rank_records_travel_as_one_tensor_all_gather(tmp_path):
+    """bench.gather_ranks: every rank's record (device identity, its own time, its likelihood) reaches every rank in
+    rank order through ONE plain tensor all_gather -- two gloo ranks here, RCCL on the GPUs."""
+    import socket
+    import subprocess
+    script = tmp_path / "gather_worker.py"
+    script.write_text(GATHER_WORKER.format(root=ROOT))
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    for rank, p in enumerate(procs):
+        out = p.communicate(timeout=240)[0]
+        assert p.returncode == 0 and f"rank {rank} ok" in out, out[-2000:]
