@@ -101,3 +101,26 @@ def test_pcg64_stream_matches_numpy_at_any_offset():
         bg = np.random.PCG64(seed)
         bg.advance(big)
         assert np.array_equal(pcg64_doubles(seed, big, 64), np.random.Generator(bg).random(64))
+
+
+def test_build_id_is_the_hash_of_the_sources_and_staleness_goes_by_content(tmp_path, monkeypatch):
+    """bench.py and the tests must never measure a binary built from other sources than the tree
+    holds.  The library carries mmsbm_hip_build_id() = the hash mmsbm_amd.build.source_id() computes over csrc/;
+    is_stale() compares CONTENT (a sidecar with that hash next to the .so), not time stamps -- a copy of the tree
+    does not keep those."""
+    from mmsbm_amd import build
+    assert _lib.build_id() == build.source_id() == build.built_id()
+    assert not build.is_stale()
+    # another set of sources (one byte more in a copy of csrc/): a different id, and the library counts as stale
+    import shutil
+    copy = tmp_path / "csrc"
+    shutil.copytree(build.CSRC, copy)
+    with open(copy / "common.hpp", "a") as fh:
+        fh.write("\n")
+    monkeypatch.setattr(build, "CSRC", str(copy))
+    assert build.source_id() != _lib.build_id()
+    assert build.is_stale()
+    # touching a file without changing it does NOT make the library stale
+    monkeypatch.undo()
+    os.utime(os.path.join(build.CSRC, "common.hpp"))
+    assert not build.is_stale()
