@@ -347,6 +347,7 @@ __global__ __launch_bounds__(kBlock) void tail_fused_kernel(SegArgs su, EtaPArgs
   __shared__ double red[kRedGroup][kRedRows][kRedCols];  // (eta_p_kernel's pattern: the same sums in the same order)
   const int bx = static_cast<int>(blockIdx.x);
   const size_t slot = blockIdx.y;
+  STAMP(0);
   if (bx < bu) {
     seg_body<G, VEC, 8, 1>(su, bx * (kBlock / G) + threadIdx.x / G, dp, 1);
   } else if (bx < bu + a.nb_p) {
@@ -358,6 +359,11 @@ __global__ __launch_bounds__(kBlock) void tail_fused_kernel(SegArgs su, EtaPArgs
                              a.eta + slot * a.bs_eta, a.eta_new + slot * a.bs_eta, a.n_items, a.lp, a.normalize,
                              a.item_grid, a.n_ratings);
   }
+#ifdef MMSBM_STAMPS
+  __syncthreads();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  STAMP(8);
+#endif
 }
 
 }  // namespace

@@ -29,3 +29,21 @@ for rep in range(3):
     for j in range(8):
         print(f"   {names[j]:52s} mean {d[:, j].mean():6.2f}  p10 {np.percentile(d[:, j], 10):6.2f}  p90 {np.percentile(d[:, j], 90):6.2f} us")
     print(f"   workgroup lifetime mean {(rel[:, 8] - rel[:, 0]).mean():.2f} us")
+
+# the three roles of tail_fused_kernel (stage 5): lifetimes per role (blocks [0, bu) users, then p_update, then item_sum)
+per_u = 256 // (4 if k <= 16 else 8)
+bu = -(-(ctx.n_users if not ctx.swapped else ctx.n_items) // per_u)
+nb_p = -(-(-(-k // 4) * 4 * (-(-l // 4) * 4)) // 16)
+for rep in range(2):
+    ctx.time_stage(5, 1)
+    buf = np.zeros(8192 * 16, dtype=np.uint64)
+    assert lib.mmsbm_hip_debug_stamps(buf.ctypes.data_as(C.POINTER(C.c_uint64)), buf.size) == 0
+    st = buf.reshape(8192, 16).astype(np.int64)
+    t0 = st[:bu, 0].min()
+    life = (st[:, 8] - st[:, 0]) / 100.0
+    end = (st[:, 8] - t0) / 100.0
+    per_i = 256 // (4 if l <= 16 else 8)
+    n_blocks = bu + nb_p + -(-(ctx.n_items if not ctx.swapped else ctx.n_users) // per_i)   # (stale stamps of launch 1 lie beyond)
+    for nm, a, b in (("user segments", 0, bu), ("p_update", bu, bu + nb_p), ("item_sum", bu + nb_p, n_blocks)):
+        if b > a:
+            print(f"   tail role {nm:14s} {b - a:4d} blocks: lifetime mean {life[a:b].mean():5.2f} max {life[a:b].max():5.2f} us, last end {end[a:b].max():5.2f} us")
