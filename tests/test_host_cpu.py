@@ -232,6 +232,28 @@ def test_two_rank_gloo_predict_without_gathering_parameters(tmp_path, gather):
         assert f"rank {rank} ok" in out
 
 
+def test_four_rank_gloo_more_ranks_than_restarts(tmp_path):
+    """sampling = 3 on four ranks: rank 3 runs nothing and only takes part in the collectives (the likelihood
+    all-reduce, the (M, R) all-reduce of predict_distributed, the broadcast of the best restart); the result is the
+    one-process result."""
+    script = tmp_path / "predict_worker4.py"
+    text = PREDICT_WORKER.format(root=ROOT, gather=False)
+    text = text.replace("assert [r for r in model._restart_ids] == ([0, 2] if rank == 0 else [1])",
+                        "assert [r for r in model._restart_ids] == [[0], [1], [2], []][rank]")
+    script.write_text(text)
+    port = _free_port()
+    procs = []
+    for rank in range(4):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="4", LOCAL_RANK="0",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, out[-3000:]
+        assert f"rank {rank} ok" in out
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
