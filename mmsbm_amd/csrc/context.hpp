@@ -10,7 +10,8 @@ namespace {
 int pad_dim(int d) {  // multiples of 4: 32-byte row granules, whole chunks of 4 outputs
   if (d <= 256) return (d + 3) / 4 * 4;
   if (d <= 512) return (d + 7) / 8 * 8;
-  return (d + 15) / 16 * 16;
+  if (d <= 1024) return (d + 15) / 16 * 16;
+  return (d + 31) / 32 * 32;  // (whole lanes of the 64 x 32 instantiation of the triple passes)
 }
 
 // (G, VEC) instantiation for a padded row length: code 0..6

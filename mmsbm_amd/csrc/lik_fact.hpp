@@ -17,8 +17,8 @@ namespace {
 //     and walks the pair's triples four at a time: per tile row one product and one sum per lane serve four
 //     elements;
 //   * theta through the scalar unit.  With the whole wave on one pair, theta[u_t, k] and its logarithm are the
-//     same for every lane: they arrive as scalar loads (two rows' values and logarithms per load) and cost no
-//     vector instruction, no LDS staging and no cross-lane traffic.  s_t = theta_t . A[q] is one coalesced row
+//     same for every lane: they arrive as scalar loads (a row's value and logarithm in one s_load_dwordx4 per
+//     triple) and cost no vector instruction, no LDS staging and no cross-lane traffic.  s_t = theta_t . A[q] is one coalesced row
 //     product + a wave sum.
 // log omega = log theta_k + (log eta_l + log p_kl) from the logarithm tables of likelihood_fast_kernel; omega
 // is associated as theta_k (eta_l p_kl).  Both differ from the reference's (theta eta) p in the last bit
@@ -26,14 +26,14 @@ namespace {
 // Lanes beyond L (and columns beyond L in the last 64-block) run on omega = 0, log omega = -inf: each of their
 // elements is exactly eps (log eps - ls), which is taken off again in closed form -- no bounds checks, no divergence.
 // ======================================================================================
-constexpr int kLikWaveThreads = 512;  // eight waves share a staged tile: 3 workgroups = 24 waves per CU at K = L = 50
+constexpr int kLikWaveThreads = 512;  // eight waves share a staged tile (43 KB at K = L = 50); 2 workgroups = 16 waves per CU
 
 typedef const double __attribute__((address_space(4))) * const_f64_ptr;
 typedef const int32_t __attribute__((address_space(4))) * const_i32_ptr;
 
 // tl[u][k] = (theta[u, k], log theta[u, k]) as one 16-byte pair, plain rows of kp pairs: ONE base address per
-// triple for the scalar loads (theta and its logarithm of two rows arrive as one s_load_dwordx8), and the
-// vector loads of the s_t row product pull a triple's whole row into L2 before the scalar loads ask for it.
+// triple for the scalar loads (theta and its logarithm of a row arrive as one s_load_dwordx4), and the vector
+// loads of the s_t row product pull a triple's whole row into L2 before the scalar loads ask for it.
 __global__ __launch_bounds__(kBlock) void theta_log_pairs_kernel(RowTab in, double2 *__restrict__ tl, size_t rows, int dp) {
   const size_t e = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
   if (e >= rows * dp) return;

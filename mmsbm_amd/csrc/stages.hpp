@@ -139,10 +139,15 @@ EtaPArgs eta_p_args(const mmsbm_hip_ctx *c, bool commit, int cols_per_block) {
 void stage_seg(mmsbm_hip_ctx *c, bool commit, bool with_pairs, bool with_users, hipStream_t st) {
   const SegArgs sp = seg_pairs_args(c), su = seg_users_args(c, commit, c->n_users);
   const int per = kBlock / group_lanes(c->code_k);
-  if (c->kp > kMaxGroupRow) {  // rows of more than 1,024 groups: a wave per segment, the row in blocks (no work lists)
+  if (c->kp > kMaxGroupRow) {  // rows of more than 1,024 groups: a wave per segment, whole segments (no work lists)
     LaunchScope ls(c, K_SEG, st == c->stream);
     const int bp = with_pairs ? (sp.nseg + per - 1) / per : 0, bu = with_users ? (su.nseg + per - 1) / per : 0;
-    if (bp + bu > 0) LAUNCH_IN(ls, (seg_wide_kernel<16>), slot_grid(c, bp + bu), kBlock, 0, st, sp, su, bp, c->kp);
+    if (bp + bu > 0) {
+      // up to 2,048: the group-of-lanes kernel once more, 32 doubles per lane, one row in flight per wave (the row,
+      // the fixed row and the sums are 192 registers); beyond: seg_wide_kernel, the row in blocks of 1,024 columns
+      if (c->kp <= 2 * kMaxGroupRow) LAUNCH_IN(ls, (seg_pass_kernel<64, 32, 1>), slot_grid(c, bp + bu), kBlock, 0, st, sp, su, bp, c->kp);
+      else LAUNCH_IN(ls, (seg_wide_kernel<16>), slot_grid(c, bp + bu), kBlock, 0, st, sp, su, bp, c->kp);
+    }
     ls.done();
     return;
   }

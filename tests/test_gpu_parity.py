@@ -1067,11 +1067,13 @@ def test_wide_group_counts_beyond_the_lds_tile(hip, k, l):
             assert np.allclose(em.prod_dist(data[:50]), orc.prod_dist(data[:50], t, e, p), rtol=1e-11, atol=1e-300)
 
 
-@pytest.mark.parametrize("k,l,n", [(1500, 3, 700), (3, 1500, 700), (1100, 20, 500), (2100, 2, 400), (1040, 1030, 60)])
+@pytest.mark.parametrize("k,l,n", [(1500, 3, 700), (3, 1500, 700), (1100, 20, 500), (2100, 2, 400), (2, 2500, 400),
+                                   (1040, 1030, 60), (2048, 3, 300)])
 def test_more_than_1024_groups_per_side(hip, k, l, n):
     """The reference's numpy backend has no size limit (src/kernels_numpy.py:21-79).  Rows beyond the widest
-    group-of-lanes instantiation (64 lanes x 16 doubles = 1,024 groups) run since round 3: the triple passes as
-    seg_wide_kernel (a wave per segment, the row in blocks of 1,024 columns, weights first, then the columns),
+    group-of-lanes instantiation (64 lanes x 16 doubles = 1,024 groups) run since round 3: the triple passes with 32
+    doubles per lane up to 2,048 groups and as seg_wide_kernel beyond (a wave per segment, the row in blocks of
+    1,024 columns, weights first, then the columns),
     item_sum and the prediction rows with one more trip per 1,024 columns, the pair stage on the blocked
     matrix-core kernels.  Segments longer than a wave's 64 triples (a busy user / a popular pair) included; same
     checks as every other shape, either side paired with the rating, two restart slots."""
