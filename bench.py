@@ -333,7 +333,7 @@ def main():
                                    f"(sampling={world}), uniform generator seed 0, model seed 0",
                        "launch": "hipGraph replay" if args.graph else "eager",
                        "pairs": ctx.n_pairs,
-                       "launches_per_iteration": 2 if ctx.get_option("fused") else 4,
+                       "launches_per_iteration": int(ctx.get_option("launches")),
                        "pair_stage": {0.0: "vector ALUs (pair_block_kernel)", 1.0: "matrix cores (pair_mfma_kernel)",
                                       2.0: "matrix cores, blocked (mfma_rows_kernel + mfma_slab_kernel)"}[ctx.get_option("mfma")]},
             "collective": coll,

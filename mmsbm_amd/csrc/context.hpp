@@ -164,7 +164,7 @@ struct mmsbm_hip_ctx {
   bool predict_fast = true;
   int seg_batch = 4;  // row gathers a group of seg_pass keeps in flight (4, or 8)
   bool fused = false;          // small problems: two launches per iteration (fused_small.hpp)
-  bool fused_forced = false;   // option "fused" = 1: whatever the size (else: while ratings x restart slots <= 300,000)
+  bool fused_forced = false;   // option "fused" = 1: whatever the size (else: while ratings x restart slots x (K + L) <= 14M)
   std::vector<char> a_ok;      // per slot: atab[cur] holds A of the CURRENT parameters (the fused form computes A at
                                // the start of an iteration, so after a committed fused iteration it does not)
   bool mfma = false;    // both pair-stage launches run pair_mfma_kernel (tiles beyond the scalar cache, K, L <= 64)

@@ -48,6 +48,7 @@ __device__ __forceinline__ void p_update_block(
       longest = max(longest, c1[j] - c0[j]);
       s[j] = 0.0;
     }
+    if (longest >= 0) STAMP(1);  // (diagnostic builds: the slab ranges have arrived)
     // (a pattern row adds its slabs c0 + vty, + ROWS, + 2 ROWS, ... one after the other: BATCH only says how many
     // of those loads are in flight together, it does not touch the order of the sum)
     constexpr int VR = ROWS / NTY;  // pattern rows per thread row: their loads share a round too
@@ -80,7 +81,9 @@ __device__ __forceinline__ void p_update_block(
     for (int m = 0; m < VR; ++m)
 #pragma unroll
       for (int j = 0; j < kRedGroup; ++j) red[j][ty + m * NTY][tx] = sv[m][j];
+    STAMP(2);
     __syncthreads();
+    STAMP(3);
     if (ty < 8) {  // ROWS rows -> 8 partial sums (fixed order)
 #pragma unroll
       for (int j = 0; j < kRedGroup; ++j) {
@@ -111,7 +114,9 @@ __device__ __forceinline__ void p_update_block(
         }
       }
     }
+    STAMP(4);
     __syncthreads();
+    STAMP(5);
     if (n_ratings <= kRedGroup) {  // common case: normalise straight from registers
       if (ty == 0 && ok && normalize) {
         const double den = (tot_all == 0.0) ? 1.0 : tot_all;

@@ -58,6 +58,7 @@ __global__ __launch_bounds__(kBlock) void pairs_fused_kernel(FusedPairArgs fa) {
   double *aout = es + static_cast<size_t>(kUnitPairs) * lp; // [64][kp]  A rows of the unit
   double *cT = aout + static_cast<size_t>(kUnitPairs) * kp; // [kp][CS]  C rows, transposed
   STAMP(0);
+  STAMP_WHERE(9);
   const mmsbm::Chunk ch = fa.chunks[blockIdx.x];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int q0 = ch.q_begin, np = ch.q_end - ch.q_begin;  // (np <= 64; 0 for the padding of the unit lists)
@@ -71,12 +72,16 @@ __global__ __launch_bounds__(kBlock) void pairs_fused_kernel(FusedPairArgs fa) {
   // which then travel while A is multiplied ----
   constexpr int NGRP = kBlock / G, ROUNDS = (kUnitPairs + NGRP - 1) / NGRP;
   const int grp = tid / G, gl = tid % G;
-  constexpr int CH = B;       // triples per step of a segment = row gathers in flight per group
-  constexpr int IPL = CH / G;  // indices a lane holds per step (G = 4: two, G = 8: one)
-  static_assert(IPL == 1 || IPL == 2, "groups of 4 or 8 lanes");
+#ifdef MMSBM_FUSED_CH  // (tuning aid, scripts/ab_fused.sh)
+  constexpr int CH = MMSBM_FUSED_CH > G ? MMSBM_FUSED_CH : G;
+#else
+  constexpr int CH = B;        // triples per step of a segment = row gathers in flight per group
+#endif
+  constexpr int IPL = CH / G;  // indices a lane holds per step (G = 4: four, G = 8: two)
+  static_assert(IPL == 1 || IPL == 2 || IPL == 4, "groups of 4 or 8 lanes");
   constexpr int NE = 4;  // eta loads per thread: 64 pairs x <= 32 entries / 2 per load / 256 threads
   const int tot = np * lp;
-  int beg[ROUNDS], end[ROUNDS], mine0[ROUNDS], mine1[ROUNDS], next0[ROUNDS], next1[ROUNDS];
+  int beg[ROUNDS], end[ROUNDS], mine[ROUNDS][IPL], nxt[ROUNDS][IPL];
   int pr[NE], d[NE], ids[NE];
 #pragma unroll
   for (int r = 0; r < ROUNDS; ++r) {  // level 1
@@ -96,10 +101,11 @@ __global__ __launch_bounds__(kBlock) void pairs_fused_kernel(FusedPairArgs fa) {
   for (int r = 0; r < ROUNDS; ++r) {  // level 2: the indices of a segment's first two steps
     const int len = end[r] - beg[r];
     const int last = max(len - 1, 0);
-    mine0[r] = len > 0 ? fa.pair_user[beg[r] + min(gl, last)] : 0;
-    mine1[r] = (IPL > 1 && len > 0) ? fa.pair_user[beg[r] + min(G + gl, last)] : 0;
-    next0[r] = len > CH ? fa.pair_user[beg[r] + min(CH + gl, last)] : 0;
-    next1[r] = (IPL > 1 && len > CH) ? fa.pair_user[beg[r] + min(CH + G + gl, last)] : 0;
+#pragma unroll
+    for (int i = 0; i < IPL; ++i) {
+      mine[r][i] = len > i * G ? fa.pair_user[beg[r] + min(i * G + gl, last)] : 0;
+      nxt[r][i] = len > CH + i * G ? fa.pair_user[beg[r] + min(CH + i * G + gl, last)] : 0;
+    }
   }
   double2 ev[NE];
 #pragma unroll
@@ -110,12 +116,13 @@ __global__ __launch_bounds__(kBlock) void pairs_fused_kernel(FusedPairArgs fa) {
   const bool g_main = lane_off < theta.mw;
   const double *gbase = g_main ? theta.main + lane_off : theta.tail + (lane_off - theta.mw);
   const size_t gstride = g_main ? theta.rs_m : theta.rs_t;
-  double gpre[B][VEC];
-  {  // level 3
+  double gpre[CH][VEC];
+  {  // level 3: the rows of round 0's first step (only those the segment has: a group that is done asks for nothing)
+    const int len0 = end[0] - beg[0];
 #pragma unroll
-    for (int b = 0; b < B; ++b) {  // (entries past the segment's end repeat its last triple -- or row 0 -- and are not used)
-      const int id = __shfl((IPL > 1 && b >= G) ? mine1[0] : mine0[0], b % G, G);
-      load_vec<VEC>(gbase + static_cast<size_t>(id) * gstride, gpre[b]);
+    for (int b = 0; b < CH; ++b) {
+      const int id = __shfl(mine[0][b / G], b % G, G);
+      if (b < len0) load_vec<VEC>(gbase + static_cast<size_t>(id) * gstride, gpre[b]);
     }
   }
   __builtin_amdgcn_sched_barrier(0);
@@ -184,41 +191,39 @@ __global__ __launch_bounds__(kBlock) void pairs_fused_kernel(FusedPairArgs fa) {
         acc[v] = 0.0;
         f[v] = act ? aout[pr * kp + lane_off + v] : 0.0;
       }
-      // One step = CH = 8 triples.  The rows of step n + 1 are asked for before step n is added up, with indices
-      // that were fetched a step earlier still (the first two steps' at the very top of the kernel): a long
-      // segment pays one round trip per step instead of two, a segment of up to 16 triples none beyond the first.
-      double g[B][VEC];
+      // One step = CH = 16 triples, all of its rows in flight together.  The rows of round 0's first step were asked
+      // for at the very top of the kernel and travelled while A was multiplied: a segment of up to 16 triples -- all
+      // but a handful at the sizes this kernel serves -- waits for nothing here.  Longer ones: the next step's
+      // indices are in registers a step ahead, its rows are asked for when the current step has been added up.
+      double g[CH][VEC];
       if (r == 0) {
 #pragma unroll
-        for (int b = 0; b < B; ++b)
+        for (int b = 0; b < CH; ++b)
 #pragma unroll
           for (int v = 0; v < VEC; ++v) g[b][v] = gpre[b][v];
       } else {
+        const int len = end[r] - beg[r];
 #pragma unroll
-        for (int b = 0; b < B; ++b) {
-          const int id = __shfl((IPL > 1 && b >= G) ? mine1[r] : mine0[r], b % G, G);
-          load_vec<VEC>(gbase + static_cast<size_t>(id) * gstride, g[b]);
+        for (int b = 0; b < CH; ++b) {
+          const int id = __shfl(mine[r][b / G], b % G, G);
+          if (b < len) load_vec<VEC>(gbase + static_cast<size_t>(id) * gstride, g[b]);
         }
       }
-      int n0 = next0[r], n1 = next1[r];
+      int n[IPL];
+#pragma unroll
+      for (int i = 0; i < IPL; ++i) n[i] = nxt[r][i];
       for (int c0 = beg[r]; c0 < end[r]; c0 += CH) {
         const int cnt = min(CH, end[r] - c0);
-        double gn[B][VEC];
-        int nn0 = 0, nn1 = 0;
-        if (c0 + CH < end[r]) {  // (whole groups)
+        int nn[IPL];
 #pragma unroll
-          for (int b = 0; b < B; ++b) {
-            const int id = __shfl((IPL > 1 && b >= G) ? n1 : n0, b % G, G);
-            load_vec<VEC>(gbase + static_cast<size_t>(id) * gstride, gn[b]);
-          }
-          if (c0 + 2 * CH < end[r]) {
-            const int last = end[r] - 1;
-            nn0 = fa.pair_user[min(c0 + 2 * CH + gl, last)];
-            nn1 = IPL > 1 ? fa.pair_user[min(c0 + 2 * CH + G + gl, last)] : 0;
-          }
+        for (int i = 0; i < IPL; ++i) nn[i] = 0;
+        if (c0 + 2 * CH < end[r]) {  // (whole groups)
+          const int last = end[r] - 1;
+#pragma unroll
+          for (int i = 0; i < IPL; ++i) nn[i] = fa.pair_user[min(c0 + 2 * CH + i * G + gl, last)];
         }
 #pragma unroll
-        for (int b = 0; b < B; ++b) {
+        for (int b = 0; b < CH; ++b) {
           if (b < cnt) {  // (weights of 0 for the empty slots instead of this branch: 2.36 vs 1.98 us for the phase)
             double pt = 0.0;
 #pragma unroll
@@ -230,13 +235,15 @@ __global__ __launch_bounds__(kBlock) void pairs_fused_kernel(FusedPairArgs fa) {
           }
         }
         if (c0 + CH < end[r]) {
+          const int left = end[r] - c0 - CH;
 #pragma unroll
-          for (int b = 0; b < B; ++b)
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) g[b][v] = gn[b][v];
+          for (int b = 0; b < CH; ++b) {
+            const int id = __shfl(n[b / G], b % G, G);
+            if (b < left) load_vec<VEC>(gbase + static_cast<size_t>(id) * gstride, g[b]);
+          }
         }
-        n0 = nn0;
-        n1 = nn1;
+#pragma unroll
+        for (int i = 0; i < IPL; ++i) n[i] = nn[i];
       }
       if (act) {
 #pragma unroll
@@ -309,21 +316,26 @@ __global__ __launch_bounds__(kBlock) void pairs_fused_kernel(FusedPairArgs fa) {
     for (int t = tid * 2; t < np * lp; t += kBlock * 2)
       *reinterpret_cast<double2 *>(dst + t) = *reinterpret_cast<const double2 *>(tout + t);
   }
-  // ---- the slab: the copies hand their sums over through LDS, added in copy order ----
+  // ---- the slab: the copies hand their sums over through LDS; one thread per CELL of the slab then adds the copies
+  // in copy order (the order of the four-launch form, where copy 0's threads do it for their 8 cells each) and the
+  // slab goes out as one contiguous piece ----
   if (nsub > 1) {
     __syncthreads();
-    if (s_active && sub > 0 && slot0 < nslot) {
+    if (s_active && slot0 < nslot) {
 #pragma unroll
-      for (int j = 0; j < TV; ++j) lds[(j * (nsub - 1) + sub - 1) * nslot + slot0] = sacc[j];
+      for (int j = 0; j < TV; ++j) lds[(j * nsub + sub) * nslot + slot0] = sacc[j];
     }
     __syncthreads();
-    if (sub == 0 && slot0 < nslot) {
-      for (int oo = 1; oo < nsub; ++oo)
-#pragma unroll
-        for (int j = 0; j < TV; ++j) sacc[j] += lds[(j * (nsub - 1) + oo - 1) * nslot + slot0];
+    double *slab = partial + static_cast<size_t>(blockIdx.x) * kp * lp;
+    for (int t = tid; t < kp * lp; t += kBlock) {
+      const int k = t / lp, l = t - k * lp;
+      const int sl = (k / KT) * nch + (l >> 2), j = (k % KT) * 4 + (l & 3);
+      const double *src = lds + static_cast<size_t>(j) * nsub * nslot + sl;
+      double v = src[0];
+      for (int oo = 1; oo < nsub; ++oo) v += src[oo * nslot];
+      slab[t] = v;
     }
-  }
-  if (sub == 0 && slot0 < nslot) {
+  } else if (sub == 0 && slot0 < nslot) {
     double *cell = partial + static_cast<size_t>(blockIdx.x) * kp * lp + (o / nch) * KT * lp + eoff;
 #pragma unroll
     for (int h = 0; h < KT; ++h) {
@@ -341,19 +353,111 @@ __global__ __launch_bounds__(kBlock) void pairs_fused_kernel(FusedPairArgs fa) {
 #endif
 }
 
-// launch 2: blocks [0, bu) user segments, [bu, bu + nb_p) p_update, the rest item_sum
-template <int G, int VEC, int GL, int VECL>
+// seg_body (seg_pass.hpp) for the sizes of this file: the same sums in the same order (one triple after the other), but
+// the indices of a segment's first CH triples in ONE load level and all CH rows in flight together -- a user with up
+// to CH ratings costs offsets -> indices -> rows instead of an index and a row round trip per 8 triples; the next
+// step's indices travel a step ahead.  (Rows a segment does not have are not asked for.)  Occupancy does not matter
+// here -- the launch has fewer workgroups than the chip has CUs.
+template <int G, int VEC, int CH>
+__device__ __forceinline__ void seg_body_small(const SegArgs &a, int unit, int dp) {
+  constexpr int IPL = CH / G;
+  static_assert(IPL >= 1 && CH % G == 0, "groups of up to 16 lanes");
+  const int gl = threadIdx.x % G;
+  const size_t sidx = blockIdx.y;
+  if (unit >= a.nseg) return;  // whole groups leave together
+  const RowTab fixed = slot_tab(a.fixed, sidx), gath = slot_tab(a.gath, sidx), outt = slot_tab(a.out, sidx);
+  int seg = unit, beg, end, part = -1;
+  if (a.items) {
+    const mmsbm::WorkItem it = a.items[unit];
+    seg = it.seg; beg = it.begin; end = it.end; part = it.part;
+    if (seg < 0) return;  // padding of an XCD-local work list
+  } else {
+    beg = a.off[unit];
+    end = a.off[unit + 1];
+  }
+  const bool act = gl * VEC < dp;
+  const int lane_off = act ? gl * VEC : 0;
+  double f[VEC], acc[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) acc[v] = 0.0;
+  load_vec<VEC>(rowtab_ptr(fixed, seg, lane_off), f);
+  if (!act) {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) f[v] = 0.0;
+  }
+  const bool g_main = lane_off < gath.mw;
+  const double *gbase = g_main ? gath.main + lane_off : gath.tail + (lane_off - gath.mw);
+  const size_t gstride = g_main ? gath.rs_m : gath.rs_t;
+  if (end >= beg) STAMP(1);  // (diagnostic builds: the segment's range has arrived)
+  const int last = max(end - 1, beg);
+  int n[IPL];
+#pragma unroll
+  for (int i = 0; i < IPL; ++i) n[i] = end - beg > i * G ? a.idx[min(beg + i * G + gl, last)] : 0;
+  for (int c0 = beg; c0 < end; c0 += CH) {
+    const int cnt = min(CH, end - c0);
+    double g[CH][VEC];
+#pragma unroll
+    for (int b = 0; b < CH; ++b) {
+      const int id = __shfl(n[b / G], b % G, G);
+      if (b < cnt) load_vec<VEC>(gbase + static_cast<size_t>(id) * gstride, g[b]);
+    }
+    if (n[0] >= 0) STAMP(2);  // (the indices have arrived, the rows are asked for)
+    if (c0 + CH < end) {
+#pragma unroll
+      for (int i = 0; i < IPL; ++i) n[i] = a.idx[min(c0 + CH + i * G + gl, last)];
+    }
+#pragma unroll
+    for (int b = 0; b < CH; ++b) {
+      if (b < cnt) {
+        double pt = 0.0;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) pt = fma(g[b][v], f[v], pt);
+        const double s = group_sum<G>(pt);
+        const double w = 1.0 / fmax(s, kEps);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] = fma(g[b][v], w, acc[v]);
+      }
+    }
+  }
+  if (acc[0] >= 0.0) STAMP(3);  // (rows arrived and added up)
+  if (!act) return;
+  if (part >= 0) {  // (a piece of a long segment: not at the sizes that take this path, kept for completeness)
+    store_vec<VEC>(a.parts + sidx * a.bs_parts + static_cast<size_t>(part) * dp + lane_off, acc);
+    return;
+  }
+  double o[VEC];
+  if (a.mode == 0) {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) o[v] = acc[v];
+  } else if (a.mode == 1) {
+    const double d = static_cast<double>(max(end - beg, 1));
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) o[v] = (f[v] * acc[v]) / d;
+  } else {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) o[v] = f[v] * acc[v];
+  }
+  store_vec<VEC>(rowtab_ptr(outt, seg, lane_off), o);
+}
+
+// Rows in flight per user segment (UCH): 32 while the launch is ONE round of workgroups at one workgroup per CU (32 rows
+// of 4 doubles per lane are 256 registers); 16 beyond.  Measured at BASELINE's config 1 on one box, per iteration:
+// 8 (seg_body) 20.8 us, 16 20.4, 24 20.6, 32 19.8, 48 20.7; with the 157 user workgroups split into 314 smaller ones
+// (a second round at 32) 23.5.
+// launch 2: blocks [0, nb_p) p_update, [nb_p, nb_p + bu) user segments, the rest item_sum
+template <int G, int VEC, int GL, int VECL, int UCH>
 __global__ __launch_bounds__(kBlock) void tail_fused_kernel(SegArgs su, EtaPArgs a, int bu, int dp) {
   __shared__ double red[kRedGroup][kRedRows][kRedCols];  // (eta_p_kernel's pattern: the same sums in the same order)
   const int bx = static_cast<int>(blockIdx.x);
   const size_t slot = blockIdx.y;
   STAMP(0);
-  if (bx < bu) {
-    seg_body<G, VEC, 8, 1>(su, bx * (kBlock / G) + threadIdx.x / G, dp, 1);
-  } else if (bx < bu + a.nb_p) {
-    p_update_block<kRedRows, kBlock / kRedCols, 2>(red, bx - bu, a.partial + slot * a.bs_partial, a.chunk_off,
+  STAMP_WHERE(9);
+  if (bx < a.nb_p) {  // (the longest chain of the three first)
+    p_update_block<kRedRows, kBlock / kRedCols, 2>(red, bx, a.partial + slot * a.bs_partial, a.chunk_off,
                                       a.p_old + slot * a.bs_p, a.p_new + slot * a.bs_p, a.pt_new + slot * a.bs_p,
                                       a.npr + slot * a.bs_p, a.n_ratings, a.kp, a.lp, a.normalize);
+  } else if (bx < a.nb_p + bu) {
+    seg_body_small<G, VEC, UCH>(su, (bx - a.nb_p) * (kBlock / G) + threadIdx.x / G, dp);
   } else {
     item_sum_block<GL, VECL>(bx - bu - a.nb_p, a.ttab + slot * a.bs_t, a.item_off, a.item_pairs, a.item_deg,
                              a.eta + slot * a.bs_eta, a.eta_new + slot * a.bs_eta, a.n_items, a.lp, a.normalize,

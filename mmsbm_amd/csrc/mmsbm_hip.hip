@@ -330,7 +330,7 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
     }
     lap("xcd-local work lists");
     // small problems (where eight rows in flight pay, above): two launches per iteration instead of four
-    c->fused = n_obs <= 300000 && fused_possible(c.get()) && std::getenv("MMSBM_HIP_NO_FUSED") == nullptr;
+    c->fused = n_obs <= kFusedRatingsMax && fused_possible(c.get()) && std::getenv("MMSBM_HIP_NO_FUSED") == nullptr;
 
     hipStream_t s = c->stream;
     c->pair_off.upload(c->lay.pair_off, s);
@@ -1189,6 +1189,7 @@ int mmsbm_hip_get_option(const mmsbm_hip_ctx *ctx, const char *name, double *val
     else if (key == "predict_fast") *value = ctx->predict_fast;
     else if (key == "seg_batch") *value = ctx->seg_batch;
     else if (key == "fused") *value = ctx->fused;
+    else if (key == "launches") *value = use_fused(ctx) ? 2 : 4;  // read-only: launches per iteration at the current slot count
     else if (key == "wide") *value = ctx->wide;
     else if (key == "slot_waves") *value = ctx->slot_waves;
     else if (key == "lik_fast") *value = ctx->lik_mode;

@@ -419,12 +419,20 @@ void stage_fused_tail(mmsbm_hip_ctx *c, bool commit) {
   const int per_u = kBlock / group_lanes(c->code_k), per_i = kBlock / group_lanes(c->code_l);
   const int bu = (su.nseg + per_u - 1) / per_u, nb_i = (c->n_items + per_i - 1) / per_i;
   const dim3 grid = slot_grid(c, bu + a.nb_p + nb_i);
+  // (32 rows in flight per user segment leave one workgroup per CU: only while that is a single round)
+  const bool deep = static_cast<long long>(grid.x) * grid.y <= c->n_cus;
+#define TAIL(G, V, GL, VL)                                                                                        \
+  do {                                                                                                            \
+    if (deep) LAUNCH_IN(ls, (tail_fused_kernel<G, V, GL, VL, 32>), grid, kBlock, 0, c->stream, su, a, bu, c->kp); \
+    else LAUNCH_IN(ls, (tail_fused_kernel<G, V, GL, VL, 16>), grid, kBlock, 0, c->stream, su, a, bu, c->kp);      \
+  } while (0)
   switch (c->code_k * 2 + c->code_l) {
-    case 0: LAUNCH_IN(ls, (tail_fused_kernel<4, 4, 4, 4>), grid, kBlock, 0, c->stream, su, a, bu, c->kp); break;
-    case 1: LAUNCH_IN(ls, (tail_fused_kernel<4, 4, 8, 4>), grid, kBlock, 0, c->stream, su, a, bu, c->kp); break;
-    case 2: LAUNCH_IN(ls, (tail_fused_kernel<8, 4, 4, 4>), grid, kBlock, 0, c->stream, su, a, bu, c->kp); break;
-    default: LAUNCH_IN(ls, (tail_fused_kernel<8, 4, 8, 4>), grid, kBlock, 0, c->stream, su, a, bu, c->kp); break;
+    case 0: TAIL(4, 4, 4, 4); break;
+    case 1: TAIL(4, 4, 8, 4); break;
+    case 2: TAIL(8, 4, 4, 4); break;
+    default: TAIL(8, 4, 8, 4); break;
   }
+#undef TAIL
   ls.done();
 }
 
@@ -443,11 +451,14 @@ void mark_a(mmsbm_hip_ctx *c, bool ok) {
   for (int s = c->base_slot; s < c->base_slot + c->launch_slots; ++s) c->a_ok[static_cast<size_t>(s)] = ok ? 1 : 0;
 }
 
-// Two launches while the launches' work is small: ratings x restart slots of the launch <= 300,000 (measured, 100k
-// ratings at K = L = 10 per restart-iteration, two / four launches: 1 slot 20.9 / 29.3 us, 2 slots 15.0 / 16.3, 4 slots
-// 12.6 / 10.7, 8 slots 10.9 / 8.2 -- with several slots the four-launch form shares the index stream among them)
+// Two launches while the launches' work is small: ratings x restart slots x (K + L, padded) <= 14M (measured per
+// iteration, two / four launches.  One slot, K = L = 10: 100k ratings 20.2 / 29.3 us, 300k 28.7 / 37.0, 500k 37.8 /
+// 43.5; K = L = 16: 400k 36.0 / 41.7; K = L = 20: 100k 28.4 / 37.6, 300k 50.1 / 50.1, 600k 69.4 / 67.5, 1M 105.0 / 95.6.  100k ratings at K = L = 10
+// with 2 / 4 / 8 / 16 slots: 26.5 / 32.4, 40.9 / 42.8, 68.0 / 64.9, 119.9 / 115.9 -- with several slots the four-launch
+// form shares the index stream among them)
+constexpr long long kFusedWorkMax = 14000000, kFusedRatingsMax = 1500000;
 bool use_fused(const mmsbm_hip_ctx *c) {
-  return c->fused && (c->fused_forced || c->n_obs * c->launch_slots <= 300000);
+  return c->fused && (c->fused_forced || c->n_obs * c->launch_slots * (c->kp + c->lp) <= kFusedWorkMax);
 }
 
 void launch_iteration(mmsbm_hip_ctx *c, bool commit) {

@@ -1,0 +1,20 @@
+#!/usr/bin/env bash
+# A/B of build variants of the two-launch path on ONE box (box-to-box spread is larger than the differences looked for):
+#   scripts/ab_fused.sh "<flags A>" "<flags B>" ...     AB_CONFIGS="c2 c1" picks the problems
+set -u
+i=0
+for flags in "$@"; do
+  hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared $flags -o /tmp/libab$i.so mmsbm_amd/csrc/mmsbm_hip.hip &
+  i=$((i+1))
+  [ $((i % 6)) -eq 0 ] && wait
+done
+wait
+for rep in 1 2 3; do
+  i=0
+  for flags in "$@"; do
+    [ -f /tmp/libab$i.so ] || { echo "variant $i did not build"; exit 1; }
+    echo "== variant $i [$flags] rep $rep"
+    MMSBM_HIP_LIBRARY=/tmp/libab$i.so python scripts/slots_time.py ${AB_CONFIGS:-c2} 2>&1 | grep "slots= 1 "
+    i=$((i+1))
+  done
+done

@@ -427,9 +427,14 @@ def test_two_launch_iteration_is_bitwise_the_four_launch_one(hip, shape):
 
 def test_two_launch_iteration_is_chosen_by_size_and_refused_where_it_does_not_apply(hip):
     big = orc.synthetic_triples(400_000, 30_000, 6_000, 5, seed=2)
-    with hip.HipEM(big, 10, 10) as em:
-        assert em.get_option("fused") == 0.0             # beyond 300k ratings: four launches (option still available)
-        em.set_option("fused", 1)
+    with hip.HipEM(big, 20, 20) as em:                   # ratings x slots x (K + L) beyond 14M: four launches ...
+        assert em.get_option("fused") == 1.0 and em.get_option("launches") == 4.0
+        em.set_option("fused", 1)                        # ... unless asked for
+        assert em.get_option("launches") == 2.0
+    with hip.HipEM(big, 10, 10, slots=2) as em:          # the size that counts is that of the launch: all its slots
+        assert em.get_option("launches") == 4.0
+        em.set_slots(1)
+        assert em.get_option("launches") == 2.0
     small = orc.synthetic_triples(5_000, 500, 200, 5, seed=2)
     with hip.HipEM(small, 50, 50) as em:                 # tile beyond the scalar cache: not this kernel
         assert em.get_option("fused") == 0.0
