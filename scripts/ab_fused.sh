@@ -14,7 +14,7 @@ for rep in 1 2 3; do
   for flags in "$@"; do
     [ -f /tmp/libab$i.so ] || { echo "variant $i did not build"; exit 1; }
     echo "== variant $i [$flags] rep $rep"
-    MMSBM_HIP_LIBRARY=/tmp/libab$i.so python scripts/slots_time.py ${AB_CONFIGS:-c2} 2>&1 | grep "slots= 1 "
+    MMSBM_HIP_LIBRARY=/tmp/libab$i.so python scripts/slots_time.py ${AB_CONFIGS:-c2} 2>&1 | grep "slots= 1 " | sed "s/us per restart-iteration//g"
     i=$((i+1))
   done
 done

@@ -360,7 +360,7 @@ def test_launch_modes_give_identical_results(hip, slots):
             assert np.array_equal(a, b)
 
 
-@pytest.mark.parametrize("shape", ["c1", "g4", "k20", "k12x24", "ragged", "c2"])
+@pytest.mark.parametrize("shape", ["c1", "g4", "k20", "k12x24", "ragged", "busy", "c2"])
 def test_two_launch_iteration_is_bitwise_the_four_launch_one(hip, shape):
     """fused_small.hpp: for small problems an iteration is pairs_fused_kernel (A, the pair pass and T + S
     of a 64-pair unit in one workgroup, C never leaving LDS) + tail_fused_kernel (user pass || p_update ||
@@ -383,6 +383,10 @@ def test_two_launch_iteration_is_bitwise_the_four_launch_one(hip, shape):
             i_col = rng.integers(0, 400, n) * 3 % 401
             u_col = rng.integers(0, 900, n) * 2
             data, k, l = np.stack([u_col, i_col, r_col], axis=1).astype(np.int64), 7, 13
+        elif shape == "busy":     # 20 users with 50 ratings each among 780 with ~11: segments of two steps of rows in flight
+            u_col = np.concatenate([np.repeat(np.arange(20), 50), rng.integers(20, 800, 8_600)])
+            data = np.stack([u_col, rng.integers(0, 300, u_col.size), rng.integers(0, 4, u_col.size)], axis=1).astype(np.int64)
+            k, l = 9, 11
         else:
             data = orc.synthetic_triples(20_000, 2_000, 500, 4, seed=9)
             k, l = (20, 20) if shape == "k20" else (12, 24)
