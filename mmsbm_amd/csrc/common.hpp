@@ -92,5 +92,27 @@ __device__ __forceinline__ void store_vec(double *__restrict__ p, const double (
   }
 }
 
+// Output rows that the NEXT launch reads and this one never touches again (T, A, theta') can go out as non-temporal
+// stores: their lines do not wait in an L2 for the end-of-kernel write-back.  `nt` is uniform (a kernel argument).
+typedef double nt_dbl2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void store_out2(double *p, const double2 v, bool nt) {
+  if (nt) {
+    nt_dbl2 t;
+    t.x = v.x; t.y = v.y;
+    __builtin_nontemporal_store(t, reinterpret_cast<nt_dbl2 *>(p));
+  } else {
+    *reinterpret_cast<double2 *>(p) = v;
+  }
+}
+template <int VEC>
+__device__ __forceinline__ void store_vec_out(double *__restrict__ p, const double (&v)[VEC], bool nt) {
+#pragma unroll
+  for (int j = 0; j < VEC; j += 2) {
+    double2 t;
+    t.x = v[j];
+    t.y = v[j + 1];
+    store_out2(p + j, t, nt);
+  }
+}
 
 }  // namespace

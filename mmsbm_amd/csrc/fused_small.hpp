@@ -32,7 +32,7 @@ struct FusedPairArgs {
   const mmsbm::Chunk *chunks;
   double *t_out;           // T [Q][lp]
   double *partial;         // one K x L slab per workgroup
-  int kp, lp, spb, nsub;
+  int kp, lp, spb, nsub, nt;  // nt: A and T rows as non-temporal stores
   size_t bs_tiles, bs_eta, bs_t, bs_partial;  // restart slots (blockIdx.y): strides of the streamed tables
 };
 
@@ -176,8 +176,7 @@ __global__ __launch_bounds__(kBlock) void pairs_fused_kernel(FusedPairArgs fa) {
   // the unit's A rows go to memory for launch 2 (the user pass gathers them)
   for (int t = tid * 2; t < np * kp; t += kBlock * 2) {
     const int pr = t / kp, j = t - pr * kp;
-    *reinterpret_cast<double2 *>(rowtab_ptr(a_out, static_cast<size_t>(q0 + pr), j)) =
-        *reinterpret_cast<const double2 *>(aout + t);
+    store_out2(rowtab_ptr(a_out, static_cast<size_t>(q0 + pr), j), *reinterpret_cast<const double2 *>(aout + t), fa.nt != 0);
   }
   // ---- the pair segments (seg_body's arithmetic): a group of G lanes per pair, C row into cT ----
   {
@@ -314,7 +313,7 @@ __global__ __launch_bounds__(kBlock) void pairs_fused_kernel(FusedPairArgs fa) {
   {  // the unit's T rows are contiguous in memory
     double *dst = t_out + static_cast<size_t>(q0) * lp;
     for (int t = tid * 2; t < np * lp; t += kBlock * 2)
-      *reinterpret_cast<double2 *>(dst + t) = *reinterpret_cast<const double2 *>(tout + t);
+      store_out2(dst + t, *reinterpret_cast<const double2 *>(tout + t), fa.nt != 0);
   }
   // ---- the slab: the copies hand their sums over through LDS; one thread per CELL of the slab then adds the copies
   // in copy order (the order of the four-launch form, where copy 0's threads do it for their 8 cells each) and the
@@ -437,7 +436,7 @@ __device__ __forceinline__ void seg_body_small(const SegArgs &a, int unit, int d
 #pragma unroll
     for (int v = 0; v < VEC; ++v) o[v] = f[v] * acc[v];
   }
-  store_vec<VEC>(rowtab_ptr(outt, seg, lane_off), o);
+  store_vec_out<VEC>(rowtab_ptr(outt, seg, lane_off), o, a.nt_out != 0 && a.mode != 0);
 }
 
 // Rows in flight per user segment (UCH): 32 while the launch is ONE round of workgroups at one workgroup per CU (32 rows

@@ -1158,6 +1158,8 @@ int mmsbm_hip_set_option(mmsbm_hip_ctx *ctx, const char *name, double value) {
       if (value != 0.0 && !fused_possible(ctx)) throw std::invalid_argument("fused: not available for this shape / data");
       ctx->fused = value != 0.0;
       ctx->fused_forced = value != 0.0;
+    } else if (key == "nt_out") {  // 0: plain stores for every output row
+      ctx->nt_out = value != 0.0;
     } else if (key == "seg_batch") {
       if (value != 4 && value != 8) throw std::invalid_argument("seg_batch: 4 or 8");
       ctx->seg_batch = static_cast<int>(value);
@@ -1189,6 +1191,7 @@ int mmsbm_hip_get_option(const mmsbm_hip_ctx *ctx, const char *name, double *val
     else if (key == "predict_fast") *value = ctx->predict_fast;
     else if (key == "seg_batch") *value = ctx->seg_batch;
     else if (key == "fused") *value = ctx->fused;
+    else if (key == "nt_out") *value = nt_on(ctx);
     else if (key == "launches") *value = use_fused(ctx) ? 2 : 4;  // read-only: launches per iteration at the current slot count
     else if (key == "wide") *value = ctx->wide;
     else if (key == "slot_waves") *value = ctx->slot_waves;

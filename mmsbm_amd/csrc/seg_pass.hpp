@@ -46,6 +46,7 @@ struct SegArgs {
   const mmsbm::WorkItem *items;  // null: unit w is segment w.  Else unit w is a piece of a segment
   double *parts;                 // [n_parts][dp] partial rows of the split segments
   size_t bs_parts;               // restart slots: distance in doubles between the slots' partial rows
+  int32_t nt_out = 0;            // finished rows (mode != 0: theta') as non-temporal stores
 };
 __device__ __forceinline__ RowTab slot_tab(RowTab t, size_t slot) {
   t.main += slot * t.so_m;
@@ -147,7 +148,7 @@ __device__ __forceinline__ void seg_body(const SegArgs &a, int unit, int dp, int
 #pragma unroll
     for (int v = 0; v < VEC; ++v) o[v] = f[v] * acc[v];
   }
-  store_vec<VEC>(rowtab_ptr(outt, seg, lane_off), o);
+  store_vec_out<VEC>(rowtab_ptr(outt, seg, lane_off), o, a.nt_out != 0 && a.mode != 0);
 }
 
 // blocks [0, blocks_a) work on segment set `sa`, the rest on `sb`

@@ -74,6 +74,13 @@ struct OneSlot {
   ~OneSlot() { c->base_slot = b; c->launch_slots = n; }
 };
 
+// Non-temporal stores for the rows the next launch gathers (T, A, theta'): one restart per launch and rows of up to
+// 32 groups.  Measured per iteration, plain -> non-temporal (scripts/ab_fused.sh, variants side by side on one box): C1
+// 11.3 -> 11.2 us, C2 20.3 -> 19.5, 600k ratings at K = L = 20 67.2 -> 66.0, C3 95.3 -> 93.8, 3M 302.3 -> 297.2, 10M
+// 886 -> 880; with restart slots nothing or a loss (C3 x 2 165.8 -> 166.9, C3 x 8 591 -> 597), theta' at K = L = 50
+// +0.3 %.  C rows, eta' and the slabs the same way: +0.3, +0.3 and +1.0 us at C3 -- they stay plain stores.
+bool nt_on(const mmsbm_hip_ctx *c) { return c->nt_out && c->launch_slots == 1 && c->kp <= 32 && c->lp <= 32; }
+
 SegArgs seg_pairs_args(const mmsbm_hip_ctx *c) {  // C = sum over a pair's triples
   const bool it = !c->lay.pair_work.items.empty();
   return SegArgs{a_tab(c, c->cur), theta_tab(c, c->cur), c->pair_off.ptr, c->pair_user.ptr,
@@ -87,7 +94,8 @@ SegArgs seg_users_args(const mmsbm_hip_ctx *c, bool commit, int seg_end) {  // t
                  theta_tab(c, c->cur ^ 1),
                  it ? static_cast<int32_t>(c->lay.user_work.items.size()) : seg_end,
                  commit ? 1 : 2,
-                 it ? c->user_items.ptr : nullptr, c->user_parts.at(c->base_slot), c->user_parts.stride};
+                 it ? c->user_items.ptr : nullptr, c->user_parts.at(c->base_slot), c->user_parts.stride,
+                 nt_on(c) ? 1 : 0};
 }
 PairBlockArgs pair_block_t_args(const mmsbm_hip_ctx *c) {
   const int s = c->base_slot;
@@ -96,6 +104,7 @@ PairBlockArgs pair_block_t_args(const mmsbm_hip_ctx *c) {
   pa.pair_item = c->pair_item.ptr; pa.chunks = c->mv_chunks.ptr;
   pa.out = c->ttab.at(s); pa.partial = c->partial.at(s);
   pa.din = c->k; pa.dinp = c->kp; pa.doutp = c->lp; pa.spb = c->pb_spb; pa.nsub = c->pb_nsub; pa.abl = c->ablate;
+  pa.nt = nt_on(c) ? 1 : 0;
   pa.out_mw = c->lp; pa.out_rs_m = c->lp; pa.out_rs_t = 0; pa.out_tail = c->ttab.at(s);
   pa.bs_tiles = c->p[0].stride; pa.bs_in = c->ctab.stride; pa.bs_e = c->eta[0].stride;
   pa.bs_out = c->ttab.stride; pa.bs_out_t = 0; pa.bs_partial = c->partial.stride;
@@ -109,6 +118,7 @@ PairBlockArgs pair_block_a_args(const mmsbm_hip_ctx *c, int param_slot, int a_sl
   pa.pair_item = c->pair_item.ptr; pa.chunks = c->mv_chunks.ptr;
   pa.out = at.main; pa.partial = nullptr;
   pa.din = c->l; pa.dinp = c->lp; pa.doutp = c->kp; pa.spb = kBlock; pa.nsub = 1; pa.abl = c->ablate;
+  pa.nt = nt_on(c) ? 1 : 0;
   pa.out_mw = at.mw; pa.out_rs_m = at.rs_m; pa.out_rs_t = at.rs_t; pa.out_tail = at.tail;
   pa.bs_tiles = c->pt[0].stride; pa.bs_in = c->eta[0].stride; pa.bs_e = 0;
   pa.bs_out = at.so_m; pa.bs_out_t = at.so_t; pa.bs_partial = 0;
@@ -404,7 +414,7 @@ void stage_fused_pairs(mmsbm_hip_ctx *c) {
   fa.theta = theta_tab(c, cur); fa.a_out = a_tab(c, cur);
   fa.pair_off = c->pair_off.ptr; fa.pair_user = c->pair_user.ptr; fa.pair_item = c->pair_item.ptr;
   fa.chunks = c->mv_chunks.ptr; fa.t_out = c->ttab.at(s); fa.partial = c->partial.at(s);
-  fa.kp = c->kp; fa.lp = c->lp; fa.spb = c->pb_spb; fa.nsub = c->pb_nsub;
+  fa.kp = c->kp; fa.lp = c->lp; fa.spb = c->pb_spb; fa.nsub = c->pb_nsub; fa.nt = nt_on(c) ? 1 : 0;
   fa.bs_tiles = c->p[0].stride; fa.bs_eta = c->eta[0].stride; fa.bs_t = c->ttab.stride; fa.bs_partial = c->partial.stride;
   const size_t lds = pairs_fused_lds(c->kp, c->lp);
   const dim3 grid = slot_grid(c, c->n_chunks);

@@ -454,6 +454,29 @@ def test_two_launch_iteration_is_chosen_by_size_and_refused_where_it_does_not_ap
         assert em.get_option("items_users") > 0 and em.get_option("fused") == 0.0
 
 
+def test_non_temporal_output_rows_change_nothing_but_the_cache_policy(hip):
+    """T, A and theta' rows go out as non-temporal stores for one restart per launch and rows of up to 32 groups
+    (stages.hpp: nt_on): the same bits as with plain stores, in the four-launch and in the two-launch form."""
+    data = orc.synthetic_triples(30_000, 3_000, 700, 5, seed=3)
+    for k, l, fused in ((20, 20, 0), (20, 20, 1), (10, 7, 1), (32, 9, 0)):
+        runs = []
+        for nt in (1, 0):
+            with hip.HipEM(data, k, l) as em:
+                assert em.get_option("nt_out") == 1.0
+                em.set_option("nt_out", nt)
+                assert em.get_option("nt_out") == float(nt)
+                em.set_option("fused", fused)
+                em.init_params(11)
+                em.iterate(6)
+                runs.append(em.get_params() + (em.likelihood(),))
+        for a, b in zip(*runs):
+            assert np.array_equal(np.asarray(a), np.asarray(b))
+    with hip.HipEM(data, 20, 20, slots=2) as em:     # several restarts per launch, or long rows: plain stores
+        assert em.get_option("nt_out") == 0.0
+    with hip.HipEM(data[:3000], 40, 8) as em:
+        assert em.get_option("nt_out") == 0.0
+
+
 def test_cv_fit_matches_reference(hip):
     """The reference's cv_fit test case (tests/test_mmsbm.py:30-34,57-61): folds=2, accuracies 0.125, 0.16."""
     import pandas as pd
