@@ -114,5 +114,21 @@ __device__ __forceinline__ void store_vec_out(double *__restrict__ p, const doub
     store_out2(p + j, t, nt);
   }
 }
+// ... and a row that is read once (the segment's own row) can come in as a non-temporal load
+template <int VEC>
+__device__ __forceinline__ void load_vec_in(const double *__restrict__ p, double (&v)[VEC], bool nt) {
+#pragma unroll
+  for (int j = 0; j < VEC; j += 2) {
+    if (nt) {
+      const nt_dbl2 t = __builtin_nontemporal_load(reinterpret_cast<const nt_dbl2 *>(p + j));
+      v[j] = t.x;
+      v[j + 1] = t.y;
+    } else {
+      const double2 t = *reinterpret_cast<const double2 *>(p + j);
+      v[j] = t.x;
+      v[j + 1] = t.y;
+    }
+  }
+}
 
 }  // namespace

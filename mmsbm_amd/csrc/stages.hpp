@@ -78,7 +78,9 @@ struct OneSlot {
 // 32 groups.  Measured per iteration, plain -> non-temporal (scripts/ab_fused.sh, variants side by side on one box): C1
 // 11.3 -> 11.2 us, C2 20.3 -> 19.5, 600k ratings at K = L = 20 67.2 -> 66.0, C3 95.3 -> 93.8, 3M 302.3 -> 297.2, 10M
 // 886 -> 880; with restart slots nothing or a loss (C3 x 2 165.8 -> 166.9, C3 x 8 591 -> 597), theta' at K = L = 50
-// +0.3 %.  C rows, eta' and the slabs the same way: +0.3, +0.3 and +1.0 us at C3 -- they stay plain stores.
+// +0.3 %.  C rows, eta' and the slabs the same way: +0.3, +0.3 and +1.0 us at C3 -- they stay plain stores.  Loads:
+// the segments' own rows in seg_pass as non-temporal loads C3 94.1 -> 93.5 (kept, same condition); the T rows in
+// item_sum +1.6 us, the index stream +0.3, C rows in T + S and the slabs in p_update nothing.
 bool nt_on(const mmsbm_hip_ctx *c) { return c->nt_out && c->launch_slots == 1 && c->kp <= 32 && c->lp <= 32; }
 
 SegArgs seg_pairs_args(const mmsbm_hip_ctx *c) {  // C = sum over a pair's triples
@@ -86,7 +88,8 @@ SegArgs seg_pairs_args(const mmsbm_hip_ctx *c) {  // C = sum over a pair's tripl
   return SegArgs{a_tab(c, c->cur), theta_tab(c, c->cur), c->pair_off.ptr, c->pair_user.ptr,
                  plain_tab(c->ctab.at(c->base_slot), c->kp, c->ctab.stride),
                  it ? static_cast<int32_t>(c->lay.pair_work.items.size()) : c->n_pairs, 0,
-                 it ? c->pair_items.ptr : nullptr, c->pair_parts.at(c->base_slot), c->pair_parts.stride};
+                 it ? c->pair_items.ptr : nullptr, c->pair_parts.at(c->base_slot), c->pair_parts.stride,
+                 nt_on(c) ? 1 : 0};
 }
 SegArgs seg_users_args(const mmsbm_hip_ctx *c, bool commit, int seg_end) {  // theta_new
   const bool it = !c->lay.user_work.items.empty();
