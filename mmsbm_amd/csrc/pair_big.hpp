@@ -331,7 +331,11 @@ __global__ __launch_bounds__(NT, NT == 512 ? MMSBM_MFMA_WPE : 2) void pair_mfma_
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int r = trow0 + lk + 4 * g;
-          if (r < np) *pair_out_ptr(pa, out, out_tail, static_cast<size_t>(q0 + r), col) = acc_t[n][g];
+          if (r < np) {
+            double *dst = pair_out_ptr(pa, out, out_tail, static_cast<size_t>(q0 + r), col);
+            if (GATHER && (pa.nt & 2)) __builtin_nontemporal_store(acc_t[n][g], dst);  // (A rows: stages.hpp, nt_on)
+            else *dst = acc_t[n][g];
+          }
         }
       }
     }

@@ -47,7 +47,7 @@ __device__ unsigned long long g_stamps[kStampBlocks * kStampSlots];
 struct PairBlockArgs {
   const double *tiles; const double *in_tab; const double *e_tab; const int32_t *pair_item;
   const mmsbm::Chunk *chunks; double *out; double *partial;
-  int din, dinp, doutp, spb, nsub, abl, nt;  // nt: output rows as non-temporal stores
+  int din, dinp, doutp, spb, nsub, abl, nt;  // nt: output rows as non-temporal stores (bit 0: here, bit 1: pair_mfma_kernel's A rows)
   // output rows: `out` is a plain [rows][doutp] table (T: out_mw == doutp, out_rs == doutp) or the
   // main part of a RowTab whose tail part starts at out_tail (A)
   int out_mw, out_rs_m, out_rs_t;
@@ -254,11 +254,11 @@ __device__ __forceinline__ void pair_block_body(const PairBlockArgs &pa,
       if (pa.out_mw == doutp && pa.out_rs_m == doutp) {  // plain table: the unit's rows are one block
         double *dst = out + static_cast<size_t>(q0) * doutp;
         for (int t = tid * 2; t < total; t += nthr * 2)
-          store_out2(dst + t, *reinterpret_cast<const double2 *>(tout + t), pa.nt != 0);
+          store_out2(dst + t, *reinterpret_cast<const double2 *>(tout + t), (pa.nt & 1) != 0);
       } else {  // RowTab output (A): row by row, main part and tail part
         for (int t = tid * 2; t < total; t += nthr * 2) {
           const int pr = t / doutp, j = t - pr * doutp;
-          store_out2(pair_out_ptr(pa, out, out_tail, static_cast<size_t>(q0 + pr), j), *reinterpret_cast<const double2 *>(tout + t), pa.nt != 0);
+          store_out2(pair_out_ptr(pa, out, out_tail, static_cast<size_t>(q0 + pr), j), *reinterpret_cast<const double2 *>(tout + t), (pa.nt & 1) != 0);
         }
       }
     }
