@@ -172,7 +172,7 @@ struct mmsbm_hip_ctx {
   int mfma_threads = kPairBlockMax;  // T+S launch: 512 (eight waves) or 256
   bool mfma_big = false;  // K or L beyond 64: the blocked forms (mfma_rows_kernel + mfma_slab_kernel)
   bool wide = false;    // K, L beyond the LDS stage: wide_matvec / wide_slab kernels (any size)
-  bool nt_out = true;      // option "nt_out": T, A and theta' rows as non-temporal stores where that pays (nt_on, stages.hpp)
+  int nt_out = 7;          // option "nt_out" (bits: 1 T and A rows, 2 theta' rows as non-temporal stores, 4 the segments' own rows as non-temporal loads) where that pays (nt_on, stages.hpp)
   bool slot_waves = true;  // several slots: one super-group of lanes walks a segment for all of them
   int ranges_pairs = 1, ranges_users = 1;  // XCD-local work lists: ranges the gathered table is cut into
   int n_cus = 256;

@@ -436,7 +436,7 @@ __device__ __forceinline__ void seg_body_small(const SegArgs &a, int unit, int d
 #pragma unroll
     for (int v = 0; v < VEC; ++v) o[v] = f[v] * acc[v];
   }
-  store_vec_out<VEC>(rowtab_ptr(outt, seg, lane_off), o, a.nt_out != 0 && a.mode != 0);
+  store_vec_out<VEC>(rowtab_ptr(outt, seg, lane_off), o, (a.nt_out & 1) != 0 && a.mode != 0);
 }
 
 // Rows in flight per user segment (UCH): 32 while the launch is ONE round of workgroups at one workgroup per CU (32 rows

@@ -1158,8 +1158,9 @@ int mmsbm_hip_set_option(mmsbm_hip_ctx *ctx, const char *name, double value) {
       if (value != 0.0 && !fused_possible(ctx)) throw std::invalid_argument("fused: not available for this shape / data");
       ctx->fused = value != 0.0;
       ctx->fused_forced = value != 0.0;
-    } else if (key == "nt_out") {  // 0: plain stores for every output row
-      ctx->nt_out = value != 0.0;
+    } else if (key == "nt_out") {  // 0: plain stores for every output row; bits: 1 T and A rows, 2 theta' rows, 4 own-row loads
+      if (value < 0 || value > 15) throw std::invalid_argument("nt_out: 0 .. 15");
+      ctx->nt_out = static_cast<int>(value);
     } else if (key == "seg_batch") {
       if (value != 4 && value != 8) throw std::invalid_argument("seg_batch: 4 or 8");
       ctx->seg_batch = static_cast<int>(value);

@@ -46,7 +46,7 @@ struct SegArgs {
   const mmsbm::WorkItem *items;  // null: unit w is segment w.  Else unit w is a piece of a segment
   double *parts;                 // [n_parts][dp] partial rows of the split segments
   size_t bs_parts;               // restart slots: distance in doubles between the slots' partial rows
-  int32_t nt_out = 0;            // the segment's own row as a non-temporal load, finished rows (mode != 0: theta') as non-temporal stores
+  int32_t nt_out = 0;            // bit 0: finished rows (mode != 0: theta') as non-temporal stores, bit 1: the segment's own row as a non-temporal load
 };
 __device__ __forceinline__ RowTab slot_tab(RowTab t, size_t slot) {
   t.main += slot * t.so_m;
@@ -90,7 +90,7 @@ __device__ __forceinline__ void seg_body(const SegArgs &a, int unit, int dp, int
   double f[VEC], acc[VEC];
 #pragma unroll
   for (int v = 0; v < VEC; ++v) acc[v] = 0.0;
-  load_vec_in<VEC>(rowtab_ptr(fixed, seg, lane_off), f, a.nt_out != 0);
+  load_vec_in<VEC>(rowtab_ptr(fixed, seg, lane_off), f, (a.nt_out & 2) != 0);
   if (!act) {
 #pragma unroll
     for (int v = 0; v < VEC; ++v) f[v] = 0.0;
@@ -148,7 +148,7 @@ __device__ __forceinline__ void seg_body(const SegArgs &a, int unit, int dp, int
 #pragma unroll
     for (int v = 0; v < VEC; ++v) o[v] = f[v] * acc[v];
   }
-  store_vec_out<VEC>(rowtab_ptr(outt, seg, lane_off), o, a.nt_out != 0 && a.mode != 0);
+  store_vec_out<VEC>(rowtab_ptr(outt, seg, lane_off), o, (a.nt_out & 1) != 0 && a.mode != 0);
 }
 
 // blocks [0, blocks_a) work on segment set `sa`, the rest on `sb`

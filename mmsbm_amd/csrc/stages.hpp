@@ -81,7 +81,15 @@ struct OneSlot {
 // +0.3 %.  C rows, eta' and the slabs the same way: +0.3, +0.3 and +1.0 us at C3 -- they stay plain stores.  Loads:
 // the segments' own rows in seg_pass as non-temporal loads C3 94.1 -> 93.5 (kept, same condition); the T rows in
 // item_sum +1.6 us, the index stream +0.3, C rows in T + S and the slabs in p_update nothing.
-bool nt_on(const mmsbm_hip_ctx *c) { return c->nt_out && c->launch_slots == 1 && c->kp <= 32 && c->lp <= 32; }
+// Only for data whose segments are all short and alike (no work lists on either side): with heavy-tailed degrees the
+// rows of busy users and popular items are gathered again and again and a long segment's own row is read by every one
+// of its pieces -- there every one of these hints costs (1M ratings, K = L = 20, per iteration, none / T and A rows /
+// theta' rows / own-row loads / all: log-normal degrees 90.2 / 90.6 / 91.5 / 95.9 / 96.8 us, Zipf(1.2) 93.9 / 95.5 /
+// 99.2 / 103.6 / 104.7; 100k ratings of 943 users: 28.2 / 29.2 / 28.2 / 28.4 / 29.4; scripts/nt_time.py).
+int nt_on(const mmsbm_hip_ctx *c) {
+  const bool plain_data = (c->lay.pair_work.items.empty() && c->lay.user_work.items.empty()) || (c->nt_out & 8);  // (8: tuning, whatever the data)
+  return (plain_data && c->launch_slots == 1 && c->kp <= 32 && c->lp <= 32) ? (c->nt_out & 7) : 0;
+}
 
 SegArgs seg_pairs_args(const mmsbm_hip_ctx *c) {  // C = sum over a pair's triples
   const bool it = !c->lay.pair_work.items.empty();
@@ -89,7 +97,7 @@ SegArgs seg_pairs_args(const mmsbm_hip_ctx *c) {  // C = sum over a pair's tripl
                  plain_tab(c->ctab.at(c->base_slot), c->kp, c->ctab.stride),
                  it ? static_cast<int32_t>(c->lay.pair_work.items.size()) : c->n_pairs, 0,
                  it ? c->pair_items.ptr : nullptr, c->pair_parts.at(c->base_slot), c->pair_parts.stride,
-                 nt_on(c) ? 1 : 0};
+                 nt_on(c) >> 1};
 }
 SegArgs seg_users_args(const mmsbm_hip_ctx *c, bool commit, int seg_end) {  // theta_new
   const bool it = !c->lay.user_work.items.empty();
@@ -98,7 +106,7 @@ SegArgs seg_users_args(const mmsbm_hip_ctx *c, bool commit, int seg_end) {  // t
                  it ? static_cast<int32_t>(c->lay.user_work.items.size()) : seg_end,
                  commit ? 1 : 2,
                  it ? c->user_items.ptr : nullptr, c->user_parts.at(c->base_slot), c->user_parts.stride,
-                 nt_on(c) ? 1 : 0};
+                 nt_on(c) >> 1};
 }
 PairBlockArgs pair_block_t_args(const mmsbm_hip_ctx *c) {
   const int s = c->base_slot;
@@ -107,7 +115,7 @@ PairBlockArgs pair_block_t_args(const mmsbm_hip_ctx *c) {
   pa.pair_item = c->pair_item.ptr; pa.chunks = c->mv_chunks.ptr;
   pa.out = c->ttab.at(s); pa.partial = c->partial.at(s);
   pa.din = c->k; pa.dinp = c->kp; pa.doutp = c->lp; pa.spb = c->pb_spb; pa.nsub = c->pb_nsub; pa.abl = c->ablate;
-  pa.nt = nt_on(c) ? 1 : 0;
+  pa.nt = nt_on(c) & 1;
   pa.out_mw = c->lp; pa.out_rs_m = c->lp; pa.out_rs_t = 0; pa.out_tail = c->ttab.at(s);
   pa.bs_tiles = c->p[0].stride; pa.bs_in = c->ctab.stride; pa.bs_e = c->eta[0].stride;
   pa.bs_out = c->ttab.stride; pa.bs_out_t = 0; pa.bs_partial = c->partial.stride;
@@ -121,7 +129,7 @@ PairBlockArgs pair_block_a_args(const mmsbm_hip_ctx *c, int param_slot, int a_sl
   pa.pair_item = c->pair_item.ptr; pa.chunks = c->mv_chunks.ptr;
   pa.out = at.main; pa.partial = nullptr;
   pa.din = c->l; pa.dinp = c->lp; pa.doutp = c->kp; pa.spb = kBlock; pa.nsub = 1; pa.abl = c->ablate;
-  pa.nt = (nt_on(c) ? 1 : 0) | ((c->nt_out && c->launch_slots == 1) ? 2 : 0);  // bit 1: the matrix-core A rows (C5 2,236 -> 2,215 us; T rows there: nothing)
+  pa.nt = (nt_on(c) & 1) | (((c->nt_out & 1) && c->launch_slots == 1 && c->lay.pair_work.items.empty() && c->lay.user_work.items.empty()) ? 2 : 0);  // bit 1: the matrix-core A rows (C5 2,236 -> 2,215 us; T rows there: nothing)
   pa.out_mw = at.mw; pa.out_rs_m = at.rs_m; pa.out_rs_t = at.rs_t; pa.out_tail = at.tail;
   pa.bs_tiles = c->pt[0].stride; pa.bs_in = c->eta[0].stride; pa.bs_e = 0;
   pa.bs_out = at.so_m; pa.bs_out_t = at.so_t; pa.bs_partial = 0;
@@ -417,7 +425,7 @@ void stage_fused_pairs(mmsbm_hip_ctx *c) {
   fa.theta = theta_tab(c, cur); fa.a_out = a_tab(c, cur);
   fa.pair_off = c->pair_off.ptr; fa.pair_user = c->pair_user.ptr; fa.pair_item = c->pair_item.ptr;
   fa.chunks = c->mv_chunks.ptr; fa.t_out = c->ttab.at(s); fa.partial = c->partial.at(s);
-  fa.kp = c->kp; fa.lp = c->lp; fa.spb = c->pb_spb; fa.nsub = c->pb_nsub; fa.nt = nt_on(c) ? 1 : 0;
+  fa.kp = c->kp; fa.lp = c->lp; fa.spb = c->pb_spb; fa.nsub = c->pb_nsub; fa.nt = nt_on(c) & 1;
   fa.bs_tiles = c->p[0].stride; fa.bs_eta = c->eta[0].stride; fa.bs_t = c->ttab.stride; fa.bs_partial = c->partial.stride;
   const size_t lds = pairs_fused_lds(c->kp, c->lp);
   const dim3 grid = slot_grid(c, c->n_chunks);

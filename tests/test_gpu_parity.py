@@ -462,9 +462,9 @@ def test_non_temporal_output_rows_change_nothing_but_the_cache_policy(hip):
         runs = []
         for nt in (1, 0):
             with hip.HipEM(data, k, l) as em:
-                assert em.get_option("nt_out") == 1.0
-                em.set_option("nt_out", nt)
-                assert em.get_option("nt_out") == float(nt)
+                assert em.get_option("nt_out") == 7.0    # T and A rows, theta' rows, own-row loads
+                em.set_option("nt_out", 7 * nt)
+                assert em.get_option("nt_out") == 7.0 * nt
                 em.set_option("fused", fused)
                 em.init_params(11)
                 em.iterate(6)
@@ -475,6 +475,11 @@ def test_non_temporal_output_rows_change_nothing_but_the_cache_policy(hip):
         assert em.get_option("nt_out") == 0.0
     with hip.HipEM(data[:3000], 40, 8) as em:
         assert em.get_option("nt_out") == 0.0
+    rng = np.random.default_rng(1)                   # heavy-tailed degrees (work lists): rows are re-used, plain stores
+    skew = np.stack([(rng.zipf(1.3, 20_000) - 1) % 2_000, (rng.zipf(1.3, 20_000) - 1) % 500, rng.integers(0, 5, 20_000)],
+                    axis=1).astype(np.int64)
+    with hip.HipEM(skew, 20, 20) as em:
+        assert em.get_option("items_users") > 0 and em.get_option("nt_out") == 0.0
 
 
 def test_cv_fit_matches_reference(hip):
