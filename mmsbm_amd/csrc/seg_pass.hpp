@@ -262,13 +262,12 @@ struct CombineArgs {
 // One workgroup per split segment: its kBlock/G groups add the pieces j = g, g + NG, ... (four
 // loads in flight), the per-group sums meet in LDS and are added in group order.
 template <int G, int VEC>
-__global__ __launch_bounds__(kBlock) void seg_combine_kernel(CombineArgs ca, CombineArgs cb,
-                                                             int blocks_a, int dp) {
+__device__ __forceinline__ void seg_combine_big(const CombineArgs &ca, const CombineArgs &cb, int block, int blocks_a, int dp) {
   extern __shared__ double lds[];  // [kBlock / G][dp]
   constexpr int NG = kBlock / G;
-  const bool first = static_cast<int>(blockIdx.x) < blocks_a;
+  const bool first = block < blocks_a;
   const CombineArgs &a = first ? ca : cb;
-  const int w = first ? blockIdx.x : blockIdx.x - blocks_a;
+  const int w = first ? block : block - blocks_a;
   const int grp = threadIdx.x / G, gl = threadIdx.x % G;
   const bool act = gl * VEC < dp;
   const int lane_off = act ? gl * VEC : 0;
@@ -311,11 +310,10 @@ __global__ __launch_bounds__(kBlock) void seg_combine_kernel(CombineArgs ca, Com
 // Split segments with few pieces (the usual case when MANY segments are cut: dense data): one group
 // of lanes per split segment adds its pieces in piece order, four loads in flight.
 template <int G, int VEC>
-__global__ __launch_bounds__(kBlock) void seg_combine_small_kernel(CombineArgs ca, CombineArgs cb,
-                                                                   int blocks_a, int dp) {
-  const bool first = static_cast<int>(blockIdx.x) < blocks_a;
+__device__ __forceinline__ void seg_combine_small(const CombineArgs &ca, const CombineArgs &cb, int block, int blocks_a, int dp) {
+  const bool first = block < blocks_a;
   const CombineArgs &a = first ? ca : cb;
-  const int blk = first ? blockIdx.x : blockIdx.x - blocks_a;
+  const int blk = first ? block : block - blocks_a;
   const int w = blk * (kBlock / G) + threadIdx.x / G, gl = threadIdx.x % G;
   if (w >= a.n_splits || gl * VEC >= dp) return;
   const int lane_off = gl * VEC;
@@ -344,5 +342,22 @@ __global__ __launch_bounds__(kBlock) void seg_combine_small_kernel(CombineArgs c
   store_vec<VEC>(rowtab_ptr(slot_tab(a.out, blockIdx.y), sp.seg, lane_off), o);
 }
 
+template <int G, int VEC>
+__global__ __launch_bounds__(kBlock) void seg_combine_kernel(CombineArgs ca, CombineArgs cb, int blocks_a, int dp) {
+  seg_combine_big<G, VEC>(ca, cb, static_cast<int>(blockIdx.x), blocks_a, dp);
+}
+template <int G, int VEC>
+__global__ __launch_bounds__(kBlock) void seg_combine_small_kernel(CombineArgs ca, CombineArgs cb, int blocks_a, int dp) {
+  seg_combine_small<G, VEC>(ca, cb, static_cast<int>(blockIdx.x), blocks_a, dp);
+}
+// Both kinds in one launch (small problems, where a launch costs more than what it does): blocks [0, n_small) take the
+// splits of few pieces, a group of lanes each; the rest take one split of many pieces each.
+template <int G, int VEC>
+__global__ __launch_bounds__(kBlock) void seg_combine_both_kernel(CombineArgs sa, CombineArgs sb, int small_a, int n_small,
+                                                                  CombineArgs ba, CombineArgs bb, int big_a, int dp) {
+  const int bx = static_cast<int>(blockIdx.x);
+  if (bx < n_small) seg_combine_small<G, VEC>(sa, sb, bx, small_a, dp);
+  else seg_combine_big<G, VEC>(ba, bb, bx - n_small, big_a, dp);
+}
 
 }  // namespace

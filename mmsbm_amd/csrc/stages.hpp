@@ -229,25 +229,25 @@ void stage_seg(mmsbm_hip_ctx *c, bool commit, bool with_pairs, bool with_users, 
   const int nsp_b = with_pairs ? static_cast<int>(wp.splits.size()) - wp.n_small : 0;
   const int nsu_s = with_users ? wu.n_small : 0;
   const int nsu_b = with_users ? static_cast<int>(wu.splits.size()) - wu.n_small : 0;
-  if (nsp_s + nsu_s > 0) {
-    const CombineArgs cp{c->pair_splits.ptr, sp.parts, c->pair_off.ptr, sp.fixed, sp.out, nsp_s,
-                         sp.mode, sp.bs_parts};
-    const CombineArgs cu{c->user_splits.ptr, su.parts, c->user_off.ptr, su.fixed, su.out, nsu_s,
-                         su.mode, su.bs_parts};
-    const int ba = (nsp_s + per - 1) / per, bb = (nsu_s + per - 1) / per;
+  const CombineArgs cps{c->pair_splits.ptr, sp.parts, c->pair_off.ptr, sp.fixed, sp.out, nsp_s, sp.mode, sp.bs_parts};
+  const CombineArgs cus{c->user_splits.ptr, su.parts, c->user_off.ptr, su.fixed, su.out, nsu_s, su.mode, su.bs_parts};
+  const CombineArgs cpb{c->pair_splits.ptr + wp.n_small, sp.parts, c->pair_off.ptr, sp.fixed, sp.out, nsp_b, sp.mode, sp.bs_parts};
+  const CombineArgs cub{c->user_splits.ptr + wu.n_small, su.parts, c->user_off.ptr, su.fixed, su.out, nsu_b, su.mode, su.bs_parts};
+  const int ba = (nsp_s + per - 1) / per, bb = (nsu_s + per - 1) / per;
+  const size_t lds = static_cast<size_t>(per) * c->kp * sizeof(double);
+  if (nsp_s + nsu_s > 0 && nsp_b + nsu_b > 0) {  // both kinds: one launch
 #define CALL(G, V) \
-  seg_combine_small_kernel<G, V><<<slot_grid(c, ba + bb), kBlock, 0, st>>>(cp, cu, ba, c->kp)
+  seg_combine_both_kernel<G, V><<<slot_grid(c, ba + bb + nsp_b + nsu_b), kBlock, lds, st>>>(cps, cus, ba, ba + bb, cpb, cub, nsp_b, c->kp)
     DISPATCH_GV(c->code_k, CALL);
 #undef CALL
-  }
-  if (nsp_b + nsu_b > 0) {
-    const CombineArgs cp{c->pair_splits.ptr + wp.n_small, sp.parts, c->pair_off.ptr, sp.fixed, sp.out, nsp_b,
-                         sp.mode, sp.bs_parts};
-    const CombineArgs cu{c->user_splits.ptr + wu.n_small, su.parts, c->user_off.ptr, su.fixed, su.out, nsu_b,
-                         su.mode, su.bs_parts};
-    const size_t lds = static_cast<size_t>(per) * c->kp * sizeof(double);
+  } else if (nsp_s + nsu_s > 0) {
 #define CALL(G, V) \
-  seg_combine_kernel<G, V><<<slot_grid(c, nsp_b + nsu_b), kBlock, lds, st>>>(cp, cu, nsp_b, c->kp)
+  seg_combine_small_kernel<G, V><<<slot_grid(c, ba + bb), kBlock, 0, st>>>(cps, cus, ba, c->kp)
+    DISPATCH_GV(c->code_k, CALL);
+#undef CALL
+  } else if (nsp_b + nsu_b > 0) {
+#define CALL(G, V) \
+  seg_combine_kernel<G, V><<<slot_grid(c, nsp_b + nsu_b), kBlock, lds, st>>>(cpb, cub, nsp_b, c->kp)
     DISPATCH_GV(c->code_k, CALL);
 #undef CALL
   }
