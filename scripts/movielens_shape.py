@@ -1,4 +1,7 @@
-import sys; sys.path.insert(0, "/root/repo")
+"""The MovieLens-100k shape (100k ratings, 943 users x 1,682 items, log-normal popularity): microseconds per EM iteration and
+per launch (the triple passes are timed as a stage there: seg_pass + the combine launch for split segments)."""
+import os
+import sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from mmsbm_amd import HipEM
 rng = np.random.default_rng(0)
