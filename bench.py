@@ -48,6 +48,7 @@ def parse_args():
                          "dense N x K x L oracle fits the time budget: C1-C3; C5: 60,000)")
     ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)   # internal: one process of the CPU baseline
     ap.add_argument("--batched-restarts", type=int, default=0,
                     help="after the timed region also report the rate with this many restarts per "
                          "GPU advancing as slots of one context (e.g. 8); never part of `value`.  Off by "
@@ -77,6 +78,10 @@ def self_launch(args):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    if not args.no_cpu_baseline and CPU_BASELINE_ENV not in env:
+        # the reference's side of an N-GPU number: `sampling` = N processes, one restart each (src/mmsbm.py:182-185),
+        # timed HERE -- this parent never touches the GPU -- before the ranks exist, and handed to rank 0
+        env[CPU_BASELINE_ENV] = json.dumps(cpu_baseline_processes(args, args.gpus))
     return subprocess.run(cmd, env=env).returncode
 
 
@@ -108,6 +113,103 @@ def gather_ranks(mine, world, device=None):
     return [json.loads(bytes(p.cpu().numpy().tobytes()).rstrip(b"\0").decode()) for p in parts]
 
 
+CPU_BASELINE_ENV = "MMSBM_BENCH_CPU_BASELINE"
+
+
+def cpu_rows(args, procs=1):
+    """Rows of the workload one CPU process iterates over: all of them where the dense N x K x L oracle fits the
+    time budget and the host's memory (C1-C3), else a bounded sample (C5: 60,000) -- scaled by rows afterwards."""
+    from mmsbm_amd.synthetic import CONFIGS
+    n, _, _, _, k, l = CONFIGS[args.config]
+    rows = args.cpu_sample_rows if args.cpu_sample_rows > 0 else (60_000 if args.config == "c5" else n)
+    rows = min(rows, n)
+    try:   # `procs` processes at once, ~2.5 dense (rows, K, L) float64 tensors each: stay inside half of what is free
+        import psutil
+        fit = int(0.5 * psutil.virtual_memory().available / procs / (2.5 * 8 * k * l))
+        rows = min(rows, max(1000, fit))
+    except Exception:  # noqa: BLE001
+        pass
+    return rows
+
+
+def cpu_worker(spec):
+    """One process of the CPU baseline (`--cpu-worker` = JSON {config, rows, iters, restart, procs, dir}): the
+    oracle's EM iteration for restart `restart` on the config's triples.  After the warm-up iteration the
+    processes wait for each other (a file per process in `dir`), so that the timed iterations of all of them
+    overlap like the reference's Pool(processes=sampling) workers do.  Imports numpy and the oracle only."""
+    import numpy as np
+    from oracle import mmsbm_oracle as orc
+    from mmsbm_amd.synthetic import CONFIGS
+    spec = json.loads(spec)
+    n, u, i, r, k, l = CONFIGS[spec["config"]]
+    train = orc.synthetic_triples(n, u, i, r, seed=0)
+    n_u, n_i, n_r = (int(train[:, j].max()) + 1 for j in range(3))
+    sub = train[:spec["rows"]]
+    d_u, d_i = orc.degrees(sub, n_u, n_i)
+    seed = orc.child_seeds(0, spec["procs"])[spec["restart"]]      # restart i of sampling = procs, model seed 0
+    theta, eta, pr = orc.init_params(seed, n_u, n_i, n_r, k, l, d_u, d_i)
+    theta, eta, pr = orc.em_step(sub, theta, eta, pr, d_u, d_i)    # warm-up (page faults)
+    open(os.path.join(spec["dir"], f"ready.{spec['restart']}"), "w").close()
+    deadline = time.time() + 600
+    while len([f for f in os.listdir(spec["dir"]) if f.startswith("ready.")]) < spec["procs"]:
+        if time.time() > deadline:
+            raise SystemExit("cpu worker: the other processes never got ready")
+        time.sleep(0.01)
+    times = []
+    t_begin = time.time()
+    for _ in range(spec["iters"]):
+        t0 = time.perf_counter()
+        theta, eta, pr = orc.em_step(sub, theta, eta, pr, d_u, d_i)
+        times.append(time.perf_counter() - t0)
+    print(json.dumps({"restart": spec["restart"], "times": times, "begin": t_begin, "end": time.time(),
+                      "checksum": float(np.sum(theta))}))
+
+
+def cpu_baseline_processes(args, procs):
+    """The CPU restatement on `procs` processes, one restart each -- what the reference's
+    `Pool(processes=sampling)` (src/mmsbm.py:182-185) does with sampling = procs -- as child processes that
+    never load torch or the HIP library.  value = procs iterations / the slowest process's median iteration."""
+    import tempfile
+    import numpy as np
+    from mmsbm_amd.synthetic import CONFIGS
+    n = CONFIGS[args.config][0]
+    rows = cpu_rows(args, procs)
+    env = {k_: v for k_, v in os.environ.items() if k_ not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    with tempfile.TemporaryDirectory(prefix="mmsbm_cpu_") as tmp:
+        kids = []
+        for j in range(procs):
+            spec = {"config": args.config, "rows": rows, "iters": args.cpu_iters, "restart": j, "procs": procs, "dir": tmp}
+            kids.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", json.dumps(spec)],
+                                         env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+        outs = [kid.communicate() for kid in kids]
+    recs = []
+    for kid, (so, se) in zip(kids, outs):
+        if kid.returncode != 0:
+            raise RuntimeError("cpu baseline worker failed: " + se[-2000:])
+        recs.append(json.loads(so.strip().splitlines()[-1]))
+    per = [float(np.median(rec["times"])) for rec in recs]
+    slowest = max(per) * (n / rows)
+    overlap = min(rec["end"] for rec in recs) - max(rec["begin"] for rec in recs)
+    out = {"value": procs / slowest, "unit": "it/s", "cores": procs, "kind": "port",
+           "sample": (f"all {n} triples" if rows == n else f"first {rows} of {n} triples (same U,I,R,K,L), scaled by rows") +
+                     f" in each of {procs} processes (one restart each, started together: the reference's "
+                     f"Pool(processes=sampling), src/mmsbm.py:182-185); 1 warm-up + {args.cpu_iters} timed iterations, "
+                     f"value = {procs} / slowest process's median iteration ({max(per):.3f} s; fastest {min(per):.3f} s)",
+           "seconds_per_iteration": slowest, "per_process_seconds": [p_ * (n / rows) for p_ in per],
+           "timed_regions_overlap_s": overlap, "host_cpus": os.cpu_count()}
+    return add_calibration(out)
+
+
+def add_calibration(out):
+    cal_path = os.path.join(ROOT, "oracle", "calibration.json")
+    if os.path.exists(cal_path):
+        with open(cal_path) as fh:
+            cal = json.load(fh)
+        out["port_over_reference"] = cal.get("port_over_reference")
+        out["calibration"] = cal.get("note")
+    return out
+
+
 def cpu_baseline(cfg, sample_rows, iters):
     """The oracle (numpy restatement of the reference's numpy backend: same dense N x K x L
     dataflow, one core) on the same workload -- all rows where that fits the budget (C3: ~3 s per
@@ -137,13 +239,7 @@ def cpu_baseline(cfg, sample_rows, iters):
                       f"N*K*L dataflow is linear in N)") +
                      f"; 1 warm-up + {iters} timed iterations, median {dt:.3f} s per iteration",
            "seconds_per_iteration": full, "host_cpus": os.cpu_count()}
-    cal_path = os.path.join(ROOT, "oracle", "calibration.json")
-    if os.path.exists(cal_path):
-        with open(cal_path) as fh:
-            cal = json.load(fh)
-        out["port_over_reference"] = cal.get("port_over_reference")
-        out["calibration"] = cal.get("note")
-    return out
+    return add_calibration(out)
 
 
 def fp64_valu(n, q, k, l, its_per_gpu):
@@ -229,10 +325,20 @@ def roofline_object(args, ctx, prof, n, k, l):
 
 def main():
     args = parse_args()
+    if args.cpu_worker:
+        return cpu_worker(args.cpu_worker)
     from mmsbm_amd.build import ensure_library   # (no HIP, no torch: safe before the ranks are started)
     ensure_library()                             # a fresh clone has no libmmsbm_hip.so yet
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
+    # N > 1 under somebody else's launcher (the driver's `python -m torch.distributed.run ... bench.py --gpus N`):
+    # nobody has timed the CPU side yet.  Rank 0 does it NOW, before anything in this process touches the GPU, as
+    # N child processes (one restart each); the other ranks wait for it in the rendezvous of the process group.
+    cpu_pre = None
+    if os.environ.get(CPU_BASELINE_ENV):
+        cpu_pre = json.loads(os.environ[CPU_BASELINE_ENV])
+    elif args.gpus > 1 and int(os.environ.get("RANK", "0")) == 0 and not args.no_cpu_baseline:
+        cpu_pre = cpu_baseline_processes(args, args.gpus)
     # stdout carries exactly ONE line (rank 0's JSON): whatever libraries print while the job runs
     # (RCCL's version banner, for one) goes to stderr instead
     sys.stdout.flush()
@@ -262,13 +368,23 @@ def main():
     n, u, i, r, k, l = cfg
     train = synthetic_triples(n, u, i, r, seed=0)
     model = MMSBM(k, l, iterations=args.steps, sampling=world, seed=0, backend="hip")
+    # `job`: the wall clock of what a restart-per-GPU fit consists of, stage by stage (max over ranks below)
+    job_t = {}
+    t_job = time.perf_counter()
     model._prepare_objects(train)
     restarts.check_single_hip_runtime()
     ctx = model._ctx(local)
     ctx.set_graph_mode(1 if args.graph else 0)
+    ctx.synchronize()
+    job_t["context_s"] = time.perf_counter() - t_job
+    t_job = time.perf_counter()
     ctx.init_params(model.child_states[rank])  # restart `rank`, random start drawn on the device
+    ctx.synchronize()
+    job_t["random_start_s"] = time.perf_counter() - t_job
 
+    t_job = time.perf_counter()
     ctx.iterate(args.warmup)
+    job_t["iterate_s"] = time.perf_counter() - t_job
 
     def fence():
         restarts.barrier(device)
@@ -281,6 +397,7 @@ def main():
     ctx.synchronize()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    job_t["iterate_s"] += elapsed
     t = torch.tensor([elapsed], dtype=torch.float64, device=restarts._collective_device(device))
     if dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -289,21 +406,47 @@ def main():
     # MMSBM_HIP_LIBRARY may point elsewhere): recorded, and `traffic` is dropped when it is not
     from mmsbm_amd import _lib
     build_id = _lib.build_id()
-    # steady state: the same loop, long enough to leave the clock ramp behind (HIP events on the library's stream)
-    steady_ms = ctx.time_iterations(args.steady_steps) / args.steady_steps if args.steady_steps > 0 else None
 
-    # end of the job: likelihood of this rank's restart + ONE all-reduce to pick the best
+    # end of the job: likelihood of this rank's restart + ONE all-reduce to pick the best + the winner's theta / eta /
+    # pr from the rank that ran it to everyone (three tensor broadcasts) -- evaluated on the parameters after
+    # warmup + steps iterations, BEFORE the steady-state loop below advances them further
     coll_error = None
     if world == 1 and not args.no_collective_at_1:
-        try:
+        try:    # (process-group start-up is not part of `job` at any N: for N > 1 it happened before the job began)
             restarts.init_from_env(args.dist_backend, force_init=True)
         except Exception as exc:  # a one-rank group is a nicety: report without it rather than not at all
             coll_error = f"{type(exc).__name__}: {exc}"
+    t_job = time.perf_counter()
     lik = ctx.likelihood()
+    job_t["likelihood_s"] = time.perf_counter() - t_job
+    t_job = time.perf_counter()
     best, best_lik, liks = restarts.pick_max_likelihood({rank: lik}, world, device)
-    # who ran what: one record per rank (device identity from the library's own HIP runtime), gathered with
-    # one all_gather_object -- so that a line from an 8-GPU node shows eight different PCI bus ids, each
-    # rank's own time for the K steps and its restart's likelihood
+    job_t["pick_allreduce_s"] = time.perf_counter() - t_job
+    t_job = time.perf_counter()
+    mine_res = None
+    if best % world == rank:
+        theta_w, eta_w, pr_w = ctx.get_params()
+        mine_res = {"likelihood": lik, "theta": theta_w, "eta": eta_w, "pr": pr_w}
+    winner = restarts.broadcast_result(mine_res, best % world, restarts.result_shapes(model, train), best_lik, device)
+    job_t["winner_broadcast_s"] = time.perf_counter() - t_job
+    winner_sum = float(winner["theta"].sum() + winner["eta"].sum() + winner["pr"].sum()) if winner is not None else None
+    job_names = ["context_s", "random_start_s", "iterate_s", "likelihood_s", "pick_allreduce_s", "winner_broadcast_s"]
+    jt = torch.tensor([job_t[nm] for nm in job_names] + [sum(job_t.values())], dtype=torch.float64,
+                      device=restarts._collective_device(device))
+    if dist.is_initialized():
+        dist.all_reduce(jt, op=dist.ReduceOp.MAX)
+    job = dict(zip(job_names + ["total_s"], (float(x) for x in jt.tolist())))
+    job.update({"iterations": args.warmup + args.steps, "winner": best, "winner_checksum": winner_sum,
+                "definition": "wall clock from building the context (upload + sorts) to every rank holding the "
+                              "maximum-likelihood restart's theta / eta / pr: context, device-side random start, "
+                              "warmup + steps iterations, likelihood, ONE all-reduce(MAX), three tensor broadcasts; "
+                              "each stage the max over ranks (total_s: max over ranks of the rank's own sum); "
+                              "process-group start-up excluded"})
+    # steady state: the same loop, long enough to leave the clock ramp behind (HIP events on the library's stream)
+    steady_ms = ctx.time_iterations(args.steady_steps) / args.steady_steps if args.steady_steps > 0 else None
+    # who ran what: one record per rank (device identity from the library's own HIP runtime), gathered with ONE
+    # tensor all_gather of fixed-size records -- so that a line from an 8-GPU node shows eight different PCI bus
+    # ids, each rank's own time for the K steps and its restart's likelihood
     ident = _lib.device_identity(local)
     ranks = gather_ranks({"rank": rank, "local_rank": local, "device_index": local, "device_name": ident["name"],
                           "pci_bus_id": ident["pci_bus_id"], "compute_units": ident["compute_units"],
@@ -360,15 +503,17 @@ def main():
                                 "gbps": (v[2] / (v[0] * 1e-6) / 1e9) if v[0] > 0 else None}
                            for nm, v in prof.items()},
             "likelihoods": [float(x) for x in liks], "best_restart": best,
+            "iterations_at_likelihood": args.warmup + args.steps,
+            "job": job,
         }
         if args.batched_restarts > 1:
             out["batched_restarts"] = batched_rate(model, train, local, args.batched_restarts,
                                                    max(20, args.steps // 10))
-        if world == 1 and not args.no_cpu_baseline:
-            rows = args.cpu_sample_rows
-            if rows <= 0 and args.config == "c5":
-                rows = 60_000  # the dense oracle needs 20 KB per row at K = L = 50
-            out["cpu_baseline"] = cpu_baseline(cfg, rows, args.cpu_iters)
+        if cpu_pre is not None:      # N > 1: timed on N processes before the ranks touched their GPUs (above)
+            out["cpu_baseline"] = cpu_pre
+            out["gpu_over_cpu"] = its / cpu_pre["value"]
+        elif world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, cpu_rows(args), args.cpu_iters)
             out["gpu_over_cpu"] = its / out["cpu_baseline"]["value"]
     fence()
     if rank == 0:  # the line first: nothing that happens while the process group is torn down can lose it

@@ -229,6 +229,13 @@ int mmsbm_hip_layout_build(int64_t n_obs, int32_t n_users, int32_t n_items,
 int mmsbm_hip_layout_array(const mmsbm_hip_layout *layout, int which, int32_t *out,
                            int64_t capacity, int64_t *count);
 int mmsbm_hip_layout_free(mmsbm_hip_layout *layout);
+/* No exception ever crosses this ABI: every entry point runs inside one handler that turns whatever is thrown
+ * -- the library's own errors, std::exception, std::bad_alloc, and anything else -- into a status code and a
+ * message for mmsbm_hip_last_error().  This entry throws on purpose from inside that handler so the rule can be
+ * tested without a GPU: kind 0 nothing (returns MMSBM_OK), 1 std::invalid_argument (MMSBM_E_INVALID), 2
+ * std::runtime_error, 3 std::bad_alloc, 4 an int, 5 a class not derived from std::exception (all four:
+ * MMSBM_E_INTERNAL). */
+int mmsbm_hip_selftest_throw(int kind);
 
 #ifdef __cplusplus
 }

@@ -39,6 +39,10 @@ int guarded(F &&f) {
   } catch (const std::exception &e) {
     g_last_error = e.what();
     return MMSBM_E_INTERNAL;
+  } catch (...) {  // anything that is not a std::exception (a library's own type, a thrown int): a status, never a
+                   // process death across the C ABI
+    g_last_error = "unknown exception (not derived from std::exception)";
+    return MMSBM_E_INTERNAL;
   }
 }
 

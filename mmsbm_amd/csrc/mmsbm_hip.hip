@@ -244,6 +244,8 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
         throw;
       } catch (const std::exception &e) {
         throw ApiError(MMSBM_E_HIP, std::string("device layout: ") + e.what());
+      } catch (...) {
+        throw ApiError(MMSBM_E_INTERNAL, "device layout: unknown exception (not derived from std::exception)");
       }
       c->pair_user.ptr = dev_idx.pair_user; c->pair_user.count = static_cast<size_t>(n_obs);
       c->user_pair.ptr = dev_idx.user_pair; c->user_pair.count = static_cast<size_t>(n_obs);
@@ -1294,6 +1296,20 @@ int mmsbm_hip_layout_array(const mmsbm_hip_layout *h, int which, int32_t *out, i
     if (out) {
       if (capacity < *count) throw ApiError(MMSBM_E_TOOLARGE, "buffer too small");
       std::memcpy(out, v->data(), sizeof(int32_t) * v->size());
+    }
+  });
+}
+
+int mmsbm_hip_selftest_throw(int kind) {
+  return guarded([&] {
+    struct NotStd { int x; };
+    switch (kind) {
+      case 0: return;
+      case 1: throw std::invalid_argument("selftest: invalid argument");
+      case 2: throw std::runtime_error("selftest: runtime error");
+      case 3: throw std::bad_alloc();
+      case 4: throw 42;
+      default: throw NotStd{kind};
     }
   });
 }

@@ -479,7 +479,8 @@ void mark_a(mmsbm_hip_ctx *c, bool ok) {
 // form shares the index stream among them)
 constexpr long long kFusedWorkMax = 14000000, kFusedRatingsMax = 1500000;
 bool use_fused(const mmsbm_hip_ctx *c) {
-  return c->fused && (c->fused_forced || c->n_obs * c->launch_slots * (c->kp + c->lp) <= kFusedWorkMax);
+  // (fused_possible again: options set after create() -- "mfma", "direct" ... -- change what it depends on)
+  return c->fused && fused_possible(c) && (c->fused_forced || c->n_obs * c->launch_slots * (c->kp + c->lp) <= kFusedWorkMax);
 }
 
 void launch_iteration(mmsbm_hip_ctx *c, bool commit) {
@@ -527,6 +528,9 @@ void run_iterations(mmsbm_hip_ctx *c, int n) {
         // capture only records: cur is back where it started and nothing has run yet
       }
       HIP_CHECK(hipGraphLaunch(c->graph_exec[slot], c->stream));
+      // (a replay runs none of launch_iteration's host code: the bookkeeping of "atab[cur] holds A of the current
+      // parameters" has to be repeated here -- true after the four-launch form, false after the two-launch one)
+      mark_a(c, !use_fused(c));
       n -= 2;
     }
   }
@@ -563,12 +567,14 @@ void alloc_state(mmsbm_hip_ctx *c, int slots) {
     zeroed(c->pt[b], klr);
     zeroed(c->atab[b], static_cast<size_t>(c->n_pairs) * c->kp);
   }
-  c->ctab.alloc_slots(static_cast<size_t>(c->n_pairs) * c->kp, slots);
-  c->ttab.alloc_slots(static_cast<size_t>(c->n_pairs) * c->lp, slots);
-  c->partial.alloc_slots(c->lay.mv_chunks.size() * c->kp * c->lp, slots);
-  c->npr.alloc_slots(klr, slots);
-  c->pair_parts.alloc_slots(static_cast<size_t>(c->lay.pair_work.n_parts) * c->kp, slots);
-  c->user_parts.alloc_slots(static_cast<size_t>(c->lay.user_work.n_parts) * c->kp, slots);
+  // (the scratch tables too: every entry a kernel reads is written by the launch before it -- audited, EXPERIMENTS.md
+  // -- but padding rows and the slabs of empty units then hold zeros rather than whatever the pages held before)
+  zeroed(c->ctab, static_cast<size_t>(c->n_pairs) * c->kp);
+  zeroed(c->ttab, static_cast<size_t>(c->n_pairs) * c->lp);
+  zeroed(c->partial, c->lay.mv_chunks.size() * c->kp * c->lp);
+  zeroed(c->npr, klr);
+  zeroed(c->pair_parts, static_cast<size_t>(c->lay.pair_work.n_parts) * c->kp);
+  zeroed(c->user_parts, static_cast<size_t>(c->lay.user_work.n_parts) * c->kp);
   HIP_CHECK(hipStreamSynchronize(s));
   c->n_slots = slots;
   c->sel = 0;

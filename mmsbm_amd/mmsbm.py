@@ -270,6 +270,7 @@ class MMSBM:
                 ctx.set_params(a["theta"], a["eta"], a["pr"])
             per_run.append(ctx.predict_add())
         matrix, raw = ctx.predict_finish()
+        self._raw_per_run = per_run                  # the six sums of each scored restart (restarts.predict_distributed)
         return matrix, raw, [ctx.final_stats(st) for st in per_run]
 
     def _keep_best_run(self, best, res=None):

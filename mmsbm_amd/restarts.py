@@ -5,9 +5,12 @@ The reference runs restarts in a ``multiprocessing.Pool`` (src/mmsbm.py:182-185)
 lets them communicate.  Restarts are independent here too: there is NO collective on the
 data path.  After every rank has finished its restarts one all-reduce (MAX over a
 ``sampling``-long vector that each rank fills at its own restart indices, -inf elsewhere)
-tells every rank all likelihoods, hence the maximum-likelihood run.  The parameters of all
-restarts can additionally be gathered (the reference's ``predict`` averages over all of
-them, src/mmsbm.py:297-315).
+tells every rank all likelihoods, hence the maximum-likelihood run, whose theta / eta / pr are
+then broadcast from the rank that ran it as three float64 tensors.  That is the whole end of the
+job.  The reference's ``predict`` averages over all restarts (src/mmsbm.py:297-315):
+``predict_distributed`` does that with one all-reduce of the (M, R) matrix, every restart staying
+where it ran; ``fit_distributed(gather=True)`` hands every rank every restart if asked to (tensor
+all_gathers).  Every collective here is a plain tensor collective -- nothing is pickled.
 
 torch is imported here -- before the HIP library is first loaded -- so that the process
 holds ONE HIP runtime (torch's wheel bundles its own libamdhip64).
@@ -50,7 +53,9 @@ def init_from_env(backend=None, force_init=False):
                 with socket.socket() as sock:
                     sock.bind(("127.0.0.1", 0))
                     os.environ["MASTER_PORT"] = str(sock.getsockname()[1])
-        dist.init_process_group(backend, rank=rank, world_size=world)
+        # (a generous rendezvous: with N > 1 rank 0 of bench.py times the CPU baseline before it joins)
+        import datetime
+        dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(minutes=30))
     # tensors for the collectives live where the backend wants them
     coll = torch.device("cuda", local) if (use_gpu and backend == "nccl") else torch.device("cpu")
     init_from_env.collective_device = coll
@@ -107,31 +112,101 @@ def pick_max_likelihood(local, sampling, device=None):
     return best, float(liks[best]), liks
 
 
-def gather_results(local_results, sampling):
-    """local_results: {restart index: result dict}.  Every rank gets the list of all
-    ``sampling`` results in restart order."""
-    if not (dist.is_available() and dist.is_initialized()):
+def _grouped():
+    return dist.is_available() and dist.is_initialized()
+
+
+def result_shapes(model, train):
+    """((U, K), (I, L), (K, L, R)) of a restart's theta / eta / pr -- every rank can tell them from the training
+    triples and the model, so no collective has to carry them."""
+    train = np.asarray(train)
+    n_r = len(np.flatnonzero(np.bincount(train[:, 2]))) if len(train) else 0
+    k, l = int(model.user_groups), int(model.item_groups)
+    return (int(train[:, 0].max()) + 1, k), (int(train[:, 1].max()) + 1, l), (k, l, n_r)
+
+
+def _pack(res, shapes, device):
+    """theta | eta | pr of a result dict as ONE flat float64 tensor where the backend wants it (zeros for None)."""
+    sizes = [int(np.prod(sh)) for sh in shapes]
+    if res is None:
+        return torch.zeros(sum(sizes), dtype=torch.float64, device=device)
+    flat = np.concatenate([np.ascontiguousarray(res[key], dtype=np.float64).reshape(-1)
+                           for key in ("theta", "eta", "pr")])
+    assert flat.size == sum(sizes), (flat.size, shapes)
+    return torch.from_numpy(flat).to(device)
+
+
+def _unpack(flat, shapes, likelihood):
+    flat = flat.cpu().numpy()
+    out, at = {"likelihood": likelihood}, 0
+    for key, sh in zip(("theta", "eta", "pr"), shapes):
+        n = int(np.prod(sh))
+        out[key] = flat[at:at + n].reshape(sh).copy()
+        at += n
+    return out
+
+
+def broadcast_result(res, src, shapes, likelihood, device=None):
+    """One restart's theta / eta / pr from rank ``src`` to every rank: three float64 TENSOR broadcasts (RCCL over
+    xGMI on the nccl backend; 19 MB at BASELINE's config 3, 440 MB at config 5) -- no pickles.  ``res`` is the
+    result dict on ``src`` and ignored elsewhere; the likelihood is already known to everyone (all_likelihoods)."""
+    if not _grouped():   # (a one-rank group still goes through the backend: that is how one GPU exercises RCCL)
+        return res
+    dev = _collective_device(device)
+    me = dist.get_rank()
+    out = {"likelihood": float(likelihood)}
+    for key, sh in zip(("theta", "eta", "pr"), shapes):
+        if me == src:
+            t = torch.from_numpy(np.ascontiguousarray(res[key], dtype=np.float64)).to(dev)
+            assert tuple(t.shape) == tuple(sh), (key, tuple(t.shape), sh)
+        else:
+            t = torch.empty(sh, dtype=torch.float64, device=dev)
+        dist.broadcast(t, src=src)
+        out[key] = res[key] if me == src else t.cpu().numpy()
+    return out
+
+
+def gather_results(local_results, sampling, shapes=None, liks=None, device=None):
+    """local_results: {restart index: result dict}.  Every rank gets the list of all ``sampling`` results in
+    restart order -- the explicit ``gather=True`` of fit_distributed (the reference's ``predict`` averages over
+    all restarts, src/mmsbm.py:297-315; predict_distributed does that WITHOUT moving parameters).  Tensor
+    ``all_gather``s, one per round of restarts (restart r + j * world in round j), each a flat theta | eta | pr
+    vector; the likelihoods are the ones the all-reduce already gave every rank."""
+    if not _grouped():
         return [local_results[i] for i in range(sampling)]
-    parts = [None] * dist.get_world_size()
-    dist.all_gather_object(parts, local_results)
-    merged = {}
-    for part in parts:
-        merged.update(part)
+    world, me = dist.get_world_size(), dist.get_rank()
+    dev = _collective_device(device)
+    merged = dict(local_results)
+    for j in range((sampling + world - 1) // world):
+        mine = me + j * world
+        buf = _pack(local_results.get(mine) if mine < sampling else None, shapes, dev)
+        parts = [torch.empty_like(buf) for _ in range(world)]
+        dist.all_gather(parts, buf)
+        for r, part in enumerate(parts):
+            i = r + j * world
+            if i < sampling and i not in merged:
+                merged[i] = _unpack(part, shapes, float(liks[i]))
     return [merged[i] for i in range(sampling)]
 
 
-def fit_distributed(model, train, runner=None, gather=True, device=None):
+def fit_distributed(model, train, runner=None, gather=False, device=None, share_best=True):
     """Run ``model.sampling`` restarts sharded over the ranks of the current process group.
 
     model  : an ``mmsbm_amd.MMSBM`` (only ``sampling`` / ``child_states`` are used when a
              ``runner`` is given).
     runner : ``runner(i, child_seed) -> result dict``; default runs this rank's restarts on
              its GPU through ``model.fit_encoded`` (batched as slots of one context).
-    Returns (best index, best likelihood, likelihood vector); ``model.results`` holds all
-    restarts (``gather``) or this rank's share.
+
+    End of the job (north_star / SURVEY 8(e)): ONE all-reduce(MAX) of the likelihood vector, then -- with
+    ``share_best`` -- the maximum-likelihood restart's theta / eta / pr broadcast from the rank that ran it as
+    three float64 tensors (``model.best_result`` on every rank).  Nothing else moves: ``model.results`` holds
+    THIS rank's restarts (``model._restart_ids`` says which), and ``predict_distributed`` averages over all
+    restarts without any rank ever holding another rank's parameters.  ``gather=True`` additionally hands
+    every rank every restart (tensor all_gathers; 8 x 440 MB per rank at BASELINE's config 5 -- ask for it
+    only if you need it).  Returns (best index, best likelihood, likelihood vector).
     """
-    world = dist.get_world_size() if dist.is_initialized() else 1
-    rank = dist.get_rank() if dist.is_initialized() else 0
+    world = dist.get_world_size() if _grouped() else 1
+    rank = dist.get_rank() if _grouped() else 0
     mine = shard_restarts(model.sampling, rank, world)
     if runner is None:  # this rank's restarts, batched as slots of one context on its GPU
         local_dev = device.index if (device is not None and device.type == "cuda") else 0
@@ -144,70 +219,89 @@ def fit_distributed(model, train, runner=None, gather=True, device=None):
     best, best_lik, liks = pick_max_likelihood({i: r["likelihood"] for i, r in local.items()},
                                                model.sampling, device)
     model.best_by_likelihood = best
-    model.results = gather_results(local, model.sampling) if gather else [local[i] for i in mine]
-    model._restart_ids = list(range(model.sampling)) if gather else mine
+    model._all_liks = liks
+    shapes = result_shapes(model, train)
+    model.best_result = local.get(best)
+    if share_best:
+        model.best_result = broadcast_result(local.get(best), best % world, shapes, best_lik, device)
+    if gather:
+        model.results = gather_results(local, model.sampling, shapes, liks, device)
+        model._restart_ids = list(range(model.sampling))
+    else:
+        model.results = [local[i] for i in mine]
+        model._restart_ids = mine
     return best, best_lik, liks
 
 
 def predict_distributed(model, data, device=None, share_best=True):
     """``MMSBM.predict`` (src/mmsbm.py:279-317) for restarts that live on different ranks
-    (``fit_distributed(..., gather=False)``; after ``gather=True`` every rank holds all restarts and each is
-    scored by the lowest rank holding it): every rank adds the rating distributions of ITS restarts on
+    (``fit_distributed``'s default; after ``gather=True`` every rank holds all restarts and each is scored by ONE
+    of its holders, dealt round robin): every rank adds the rating distributions of ITS restarts on
     its GPU, ONE all-reduce(SUM) of the (M, R) matrix makes the mean over all restarts -- no rank ever holds
     another rank's parameters (at BASELINE's config 5 a restart is 440 MB; the matrix of 1M test rows is
     80 MB).  ``data``: what ``model.predict`` takes, or encoded (M,3) triples after ``fit_encoded``.
     Sets prediction_matrix / run_stats on every rank; theta / eta / pr / likelihood of the restart with the
-    best test accuracy on the rank that ran it -- on all ranks with ``share_best`` (one broadcast).
+    best test accuracy on the rank that ran it -- on all ranks with ``share_best`` (tensor broadcasts).
+    Every collective is a plain tensor collective (who holds what: an all_gather of a 0/1 vector; the six raw
+    sums of each restart: an all-reduce of a (sampling, 6) matrix).
     The mean differs from a one-process predict only in the association order of the sum over restarts."""
     test = model.data_handler.transform(data, model.logger) if model.data_handler is not None else np.asarray(data)
     held = list(model._restart_ids)
-    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    multi = _grouped() and dist.get_world_size() > 1
     mine = held
+    scorer = {i: 0 for i in held}
+    dev = _collective_device(device)
     if multi:
         # A restart may be held by SEVERAL ranks (fit_distributed(gather=True) leaves every rank with all of
-        # them): it is scored once, by the lowest rank that holds it -- otherwise the all-reduce(SUM) below
-        # would count it once per holder and the mean would come out world-size times too large.
-        everyone = [None] * dist.get_world_size()
-        dist.all_gather_object(everyone, held)
-        me = dist.get_rank()
-        first = {}
-        for r, ids in enumerate(everyone):
-            for i in ids:
-                first.setdefault(i, r)
-        missing = [i for i in range(model.sampling) if i not in first]
+        # them): it is scored ONCE -- otherwise the all-reduce(SUM) below would count it once per holder -- by
+        # holder number (restart mod holders), so that the work stays spread over the ranks.
+        world, me = dist.get_world_size(), dist.get_rank()
+        flags = torch.zeros(model.sampling, dtype=torch.int64, device=dev)
+        if held:
+            flags[torch.as_tensor(held, dtype=torch.int64, device=dev)] = 1
+        everyone = [torch.empty_like(flags) for _ in range(world)]
+        dist.all_gather(everyone, flags)
+        table = torch.stack(everyone).cpu().numpy()            # (world, sampling)
+        scorer, missing = {}, []
+        for i in range(model.sampling):
+            holders = np.flatnonzero(table[:, i])
+            if holders.size == 0:
+                missing.append(i)
+            else:
+                scorer[i] = int(holders[i % holders.size])
         if missing:
             raise RuntimeError(f"predict_distributed: no rank holds restart(s) {missing}")
-        mine = [i for i in held if first[i] == me]
+        mine = [i for i in held if scorer[i] == me]
+    raw_all = np.zeros((model.sampling, 6), dtype=np.float64)
     if mine:
-        mean_local, _, stats_local = model._predict_runs(test, subset=[held.index(i) for i in mine])
+        mean_local, _, _ = model._predict_runs(test, subset=[held.index(i) for i in mine])
         total = np.ascontiguousarray(mean_local * float(len(mine)), dtype=np.float64)
+        for i, raw in zip(mine, model._raw_per_run):
+            raw_all[i] = raw
     else:   # more ranks than restarts: this one only takes part in the collectives
-        model.test, stats_local = test, []
+        model.test = test
         total = np.zeros((len(test), len(model.ratings)), dtype=np.float64)
-    per_run = dict(zip(mine, stats_local))
-    owner = {i: 0 for i in mine}
     if multi:
-        dev = _collective_device(device)
         t = torch.from_numpy(total).to(dev)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         total = t.cpu().numpy()
-        parts = [None] * dist.get_world_size()
-        dist.all_gather_object(parts, per_run)      # six numbers per restart
-        per_run, owner = {}, {}
-        for r, part in enumerate(parts):
-            per_run.update(part)
-            owner.update({i: r for i in part})
-    model.run_stats = [per_run[i] for i in range(model.sampling)]
+        t6 = torch.from_numpy(raw_all).to(dev)                  # six numbers per restart, each filled by one rank
+        dist.all_reduce(t6, op=dist.ReduceOp.SUM)
+        raw_all = t6.cpu().numpy()
+    from . import mmsbm as _host
+    model.run_stats = [_host.HipEM.final_stats(raw_all[i]) for i in range(model.sampling)]
     model.prediction_matrix = total / float(model.sampling)
     model._scored = None                            # score(): from the matrix (host side)
     best = int(np.argmax([st["accuracy"] for st in model.run_stats]))    # first best restart, src/mmsbm.py:474-478
-    rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
-    res = model.results[held.index(best)] if best in mine else None
+    res = model.results[held.index(best)] if best in held else None
     if share_best and multi:
-        box = [res]
-        dist.broadcast_object_list(box, src=owner[best])
-        res = box[0]
+        if getattr(model, "_all_liks", None) is not None:
+            lik = float(model._all_liks[best])
+        else:                                        # the owner tells everyone (one scalar)
+            lt = torch.tensor([res["likelihood"] if dist.get_rank() == scorer[best] else 0.0], dtype=torch.float64, device=dev)
+            dist.broadcast(lt, src=scorer[best])
+            lik = float(lt.item())
+        res = broadcast_result(res, scorer[best], result_shapes(model, model.train), lik, device)
     if res is not None:
         model._keep_best_run(best, res)
     return model.prediction_matrix
-

@@ -52,6 +52,20 @@ def test_no_device_means_loud_failure_not_fallback():
         load_backend("numpy")  # this package has no numpy fallback
 
 
+def test_nothing_thrown_crosses_the_abi():
+    """VERDICT r3 item 7: whatever is thrown inside an entry point -- also a type that is not a std::exception --
+    comes back as a status and a message, never as a dead process."""
+    lib = _lib.load()
+    assert lib.mmsbm_hip_selftest_throw(0) == _lib.OK
+    for kind, code, text in ((1, _lib.E_INVALID, "invalid argument"), (2, _lib.E_INTERNAL, "runtime error"),
+                             (3, _lib.E_INTERNAL, "allocation"), (4, _lib.E_INTERNAL, "unknown exception"),
+                             (5, _lib.E_INTERNAL, "unknown exception")):
+        assert lib.mmsbm_hip_selftest_throw(kind) == code
+        assert text in lib.mmsbm_hip_last_error().decode()
+    with pytest.raises(_lib.HipLibraryError, match="unknown exception"):
+        _lib.call("mmsbm_hip_selftest_throw", 4)
+
+
 def test_product_code_never_touches_the_oracle():
     pkg = os.path.join(ROOT, "mmsbm_amd")
     for dirpath, _, files in os.walk(pkg):

@@ -73,14 +73,33 @@ def test_self_launch_starts_torch_distributed_run_as_a_child(monkeypatch):
         return types.SimpleNamespace(returncode=7)
 
     monkeypatch.setattr(bench.subprocess, "run", fake_run)
+    monkeypatch.setattr(bench, "cpu_baseline_processes", lambda args, procs: {"value": 1.5, "cores": procs, "kind": "port"})
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "20", "--warmup", "5"])
-    rc = bench.self_launch(types.SimpleNamespace(gpus=4))
+    rc = bench.self_launch(types.SimpleNamespace(gpus=4, no_cpu_baseline=False))
     assert rc == 7
+    # the GPU-free parent times the CPU side on N processes BEFORE the ranks exist and hands it to rank 0
+    assert json.loads(seen["env"][bench.CPU_BASELINE_ENV]) == {"value": 1.5, "cores": 4, "kind": "port"}
     cmd = seen["cmd"]
     assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
     assert cmd[-6:] == ["--gpus", "4", "--steps", "20", "--warmup", "5"] and cmd[-7].endswith("bench.py")
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_cpu_baseline_on_as_many_processes_as_ranks():
+    """VERDICT r3 missing 2: the CPU side of an N-GPU line is the CPU restatement on N processes, one restart each
+    (the reference's Pool(processes=sampling), src/mmsbm.py:182-185): child processes that load neither torch nor
+    the HIP library, timed regions overlapping, value = N / the slowest process's median iteration."""
+    args = types.SimpleNamespace(config="c1", cpu_sample_rows=0, cpu_iters=3)
+    out = bench.cpu_baseline_processes(args, 2)
+    assert out["cores"] == 2 and out["kind"] == "port" and out["unit"] == "it/s"
+    assert len(out["per_process_seconds"]) == 2 and out["seconds_per_iteration"] == max(out["per_process_seconds"])
+    assert out["value"] == pytest.approx(2 / out["seconds_per_iteration"])
+    assert "all 100 triples in each of 2 processes" in out["sample"] and "port_over_reference" in out
+    # a sample where the whole workload would not fit the budget: scaled by rows
+    args = types.SimpleNamespace(config="c2", cpu_sample_rows=5000, cpu_iters=1)
+    out = bench.cpu_baseline_processes(args, 2)
+    assert "first 5000 of 100000 triples" in out["sample"] and out["cores"] == 2
 
 
 def test_argument_defaults(monkeypatch):

@@ -35,7 +35,12 @@ ONE_RANK_NCCL = textwrap.dedent("""
     # the reference's sampling=3 run (SURVEY B.6): likelihoods, winner, every restart's parameters
     assert np.allclose(liks, g["likelihoods"], rtol=1e-10, atol=0), (liks, g["likelihoods"])
     assert best == int(np.argmax(g["likelihoods"])) == model.best_by_likelihood
-    assert len(model.results) == 3      # gathered through all_gather_object on the nccl group
+    assert len(model.results) == 3      # (one rank: all three restarts are its own)
+    for key in ("theta", "eta", "pr"):  # the winner, as every rank of a bigger group would hold it after the broadcast
+        assert np.array_equal(model.best_result[key], model.results[best][key])
+    # the explicit gather and the winner's broadcast on CUDA tensors through RCCL (one rank: identity, but the nccl calls run)
+    full = restarts.gather_results(dict(enumerate(model.results)), 3, restarts.result_shapes(model, train), liks, device)
+    assert len(full) == 3
     for s in range(3):
         assert np.max(np.abs(model.results[s]["theta"] - g[f"theta_{{s}}"])) < 1e-9
     # the collectives themselves, on CUDA tensors through RCCL
@@ -107,6 +112,9 @@ def test_bench_one_gpu_line_has_roofline_cpu_baseline_and_rccl_collective():
     assert r0["rank"] == 0 and r0["device_index"] == 0 and "gfx950" in r0["device_name"] and ":" in r0["pci_bus_id"]
     assert r0["ms_per_step"] == pytest.approx(out["ms_per_step"], rel=1e-9) and r0["likelihood"] == out["likelihoods"][0]
     assert out["library"]["matches_sources"] and out["library"]["build_id"] == r0["build_id"]
+    job = out["job"]
+    assert job["winner"] == 0 and job["iterations"] == 25 and 0 < job["iterate_s"] <= job["total_s"]
+    assert job["winner_broadcast_s"] >= 0 and job["winner_checksum"] > 0
     ss = out["steady_state"]
     assert ss["steps"] == 1000 and 0 < ss["ms_per_step"] < 2 * out["ms_per_step"]
     assert ss["value"] == pytest.approx(1000.0 / ss["ms_per_step"], rel=1e-9)
@@ -124,7 +132,17 @@ def test_bench_gpus2_starts_its_own_ranks():
     assert out["n_gpus"] == 2 and out["collective"] == {"backend": "gloo", "world_size": 2}
     assert len(out["likelihoods"]) == 2 and len(set(out["likelihoods"])) == 2   # two different restarts
     assert out["best_restart"] == int(np.argmax(out["likelihoods"]))
-    assert "cpu_baseline" not in out                                              # rank 0 at N=1 only
+    # the N > 1 line is complete -- the CPU restatement on as many processes as ranks (timed by the
+    # GPU-free parent before the ranks exist), the roofline of the dominant kernel, the job's wall clock by stage
+    cb = out["cpu_baseline"]
+    assert cb["cores"] == 2 and cb["kind"] == "port" and cb["value"] > 0 and "in each of 2 processes" in cb["sample"]
+    assert len(cb["per_process_seconds"]) == 2 and out["gpu_over_cpu"] == pytest.approx(out["value"] / cb["value"])
+    assert out["roofline"]["bound"] == "hbm" and 0 < out["roofline"]["frac"] < 1.5
+    job = out["job"]
+    assert set(job) >= {"context_s", "random_start_s", "iterate_s", "likelihood_s", "pick_allreduce_s",
+                        "winner_broadcast_s", "total_s", "winner", "winner_checksum"}
+    assert job["winner"] == out["best_restart"] and job["iterations"] == 25 == out["iterations_at_likelihood"]
+    assert 0 < job["iterate_s"] <= job["total_s"] and all(job[k_] >= 0 for k_ in job if k_.endswith("_s"))
     assert out["value"] == pytest.approx(2 * 20 / (out["ms_per_step"] * 20e-3), rel=1e-6)
     # self-validation for the day a driver has N GPUs: one record per rank, gathered over the process group
     ranks = out["ranks"]
@@ -139,3 +157,20 @@ def test_bench_gpus2_starts_its_own_ranks():
     assert out["ms_per_step"] == pytest.approx(max(r["ms_per_step"] for r in ranks), rel=1e-9)   # max over ranks
     assert out["steady_state"]["ms_per_step"] == max(r["steady_ms_per_step"] for r in ranks)
     assert out["steady_state"]["value"] == pytest.approx(2 * 1000.0 / out["steady_state"]["ms_per_step"], rel=1e-9)
+
+
+def test_bench_under_the_drivers_launcher_times_the_cpu_side_before_touching_the_gpu():
+    """What the driver runs for N > 1: `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` -- no
+    parent of ours.  Rank 0 then times the CPU restatement on N processes itself, BEFORE anything in it touches the
+    GPU (the other ranks wait in the rendezvous), and the line is as complete as the self-launched one."""
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    res = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2", "--share-gpu", "--dist-backend",
+                "gloo", "--steps", "20", "--warmup", "5", "--config", "c2", "--steady-steps", "100", "--cpu-iters", "1"])
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    out = _json_line(res.stdout)
+    assert out["n_gpus"] == 2 and out["cpu_baseline"]["cores"] == 2 and "roofline" in out and "job" in out
+    assert out["job"]["winner"] == out["best_restart"] == int(np.argmax(out["likelihoods"]))

@@ -429,6 +429,35 @@ def test_two_launch_iteration_is_bitwise_the_four_launch_one(hip, shape):
         assert rel_err(got, want) < TOL_STEP, nm
 
 
+def test_graph_replay_keeps_track_of_whether_a_is_current(hip):
+    """a hipGraph replay runs none of the host code of an iteration, so the note "atab[cur] holds A of
+    the current parameters" has to be kept by the replay loop.  Two-launch form captured, a one-step
+    update_coefficients in between (which refreshes A and says so), replays, then the four-launch form -- whose triple
+    passes READ atab[cur] -- must recompute A: bitwise an eager four-launch run of the same iterations."""
+    g = load_golden("g4_2k_k10")
+    start = (g["theta_0"], g["eta_0"], g["pr_0"])
+    outs = []
+    for graph in (1, 0):
+        with make_ctx(hip, g["train"], *start) as em:
+            assert em.get_option("launches") == 2.0
+            em.set_graph_mode(graph)
+            em.iterate(4)                       # (graph: captured and replayed twice)
+            em.update_coefficients()            # not committed: A of the current parameters is refreshed on its way
+            em.iterate(4)                       # replays: A in atab[cur] is stale again afterwards
+            em.set_graph_mode(0)
+            em.set_option("fused", 0)
+            em.iterate(3)                       # four launches: needs A of the current parameters
+            outs.append((em.get_params(), em.likelihood()))
+        with make_ctx(hip, g["train"], *start) as em:   # the same in a context that never ran the two-launch form
+            em.set_option("fused", 0)
+            em.iterate(11)
+            outs.append((em.get_params(), em.likelihood()))
+    for params, lik in outs[1:]:
+        for a, b in zip(params, outs[0][0]):
+            assert np.array_equal(a, b)
+        assert lik == outs[0][1]
+
+
 def test_two_launch_iteration_is_chosen_by_size_and_refused_where_it_does_not_apply(hip):
     big = orc.synthetic_triples(400_000, 30_000, 6_000, 5, seed=2)
     with hip.HipEM(big, 20, 20) as em:                   # ratings x slots x (K + L) beyond 14M: four launches ...
@@ -1301,6 +1330,8 @@ def test_pair_stage_on_the_matrix_cores_blocked(hip, k, l, mode):
             for on in (mode, 0):
                 em.set_option("mfma", on)
                 assert em.get_option("mfma") == (2.0 if on else 0.0)
+                if on:                                                # (a small problem must not stay with the
+                    assert em.get_option("launches") == 4.0           # two-launch kernels once a pair-stage family is forced)
                 em.select(1).set_params(theta2, eta2, pr2)
                 em.select(0).set_params(theta, eta, pr)
                 if on:

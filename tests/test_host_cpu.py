@@ -156,13 +156,27 @@ WORKER = textwrap.dedent("""
         return orc.run_one_sampling(train, seed, 2, 2, 10)
 
     mine = restarts.shard_restarts(3, rank, world)
-    best, best_lik, liks = restarts.fit_distributed(model, train, runner=runner, gather=True, device=device)
+    # the default end of the job: ONE all-reduce + the winner's three tensors; nobody holds anybody else's restart
+    best, best_lik, liks = restarts.fit_distributed(model, train, runner=runner, device=device)
     assert mine == ([0, 2] if rank == 0 else [1]), mine
     assert np.array_equal(liks, g["likelihoods"]), (liks, g["likelihoods"])
     assert best == int(np.argmax(g["likelihoods"])) and model.best_by_likelihood == best
-    assert len(model.results) == 3
+    assert list(model._restart_ids) == mine and len(model.results) == len(mine)
+    win = model.best_result
+    assert win["likelihood"] == g["likelihoods"][best]
+    for key in ("theta", "eta", "pr"):
+        assert np.array_equal(win[key], g[f"{{key}}_{{best}}"]), key
+    # without the broadcast only the rank that ran the winner has it
+    restarts.fit_distributed(model, train, runner=runner, device=device, share_best=False)
+    assert (model.best_result is not None) == (best in mine)
+    # gather=True (explicit): every rank gets every restart, through tensor all_gathers
+    best2, _, liks2 = restarts.fit_distributed(model, train, runner=runner, gather=True, device=device)
+    assert best2 == best and np.array_equal(liks2, liks)
+    assert len(model.results) == 3 and list(model._restart_ids) == [0, 1, 2]
     for s in range(3):
-        assert np.array_equal(model.results[s]["theta"], g[f"theta_{{s}}"])
+        for key in ("theta", "eta", "pr"):
+            assert np.array_equal(model.results[s][key], g[f"{{key}}_{{s}}"]), (s, key)
+        assert model.results[s]["likelihood"] == g["likelihoods"][s]
     dist.barrier()
     dist.destroy_process_group()
     print("rank", rank, "ok")
@@ -232,12 +246,13 @@ def test_two_rank_gloo_predict_without_gathering_parameters(tmp_path, gather):
         assert f"rank {rank} ok" in out
 
 
-def test_four_rank_gloo_more_ranks_than_restarts(tmp_path):
+@pytest.mark.parametrize("gather", [False, True])
+def test_four_rank_gloo_more_ranks_than_restarts(tmp_path, gather):
     """sampling = 3 on four ranks: rank 3 runs nothing and only takes part in the collectives (the likelihood
     all-reduce, the (M, R) all-reduce of predict_distributed, the broadcast of the best restart); the result is the
     one-process result."""
     script = tmp_path / "predict_worker4.py"
-    text = PREDICT_WORKER.format(root=ROOT, gather=False)
+    text = PREDICT_WORKER.format(root=ROOT, gather=gather)
     text = text.replace("assert [r for r in model._restart_ids] == ([0, 2] if rank == 0 else [1])",
                         "assert [r for r in model._restart_ids] == [[0], [1], [2], []][rank]")
     script.write_text(text)
