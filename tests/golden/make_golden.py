@@ -216,6 +216,50 @@ def g5():
     save("g5_c2_sampled", **out)
 
 
+def c2_problem():
+    """C2 with the EM object built directly (skipping the reference's O(U*N) _prepare_objects)."""
+    train = uniform_triples(100_000, 10_000, 5_000, 5, 0)
+    mm = MMSBM(10, 10, iterations=1, seed=0, backend="numpy")
+    d_u = np.maximum(np.bincount(train[:, 0]), 1); d_i = np.maximum(np.bincount(train[:, 1]), 1)
+    k = l = 10
+    mm.p, mm.m = int(train[:, 0].max()), int(train[:, 1].max())
+    mm._dims = {"n_samples": len(train), "n_user_groups": k, "n_item_groups": l, "n_ratings": 5}
+    mm.em = ExpectationMaximization(
+        dims=mm._dims, user_indices=None, item_indices=None, rating_indices=None,
+        norm_factors={"user": np.repeat(d_u[:, None], k, 1), "item": np.repeat(d_i[:, None], l, 1)},
+        backend="numpy")
+    mm.train = train
+    return mm, train
+
+
+def g5_long():
+    """C2 over the reference's DEFAULT run length (iterations=400, src/mmsbm.py:63-72): the same problem, start
+    and sampled positions as G5, snapshots after 100, 200 and 400 iterations -- sampled theta / eta entries, column
+    sums, full p, the likelihood, and the argmax prediction of every training row with a bit saying whether its
+    top-2 gap exceeds 1e-9 (the tie rule of SURVEY 7.3 item 6).  About two minutes of reference time."""
+    mm, train = c2_problem()
+    k = l = 10
+    snaps = (100, 200, 400)
+    kept, _, lik = loop_with_snapshots(mm, train, mm.child_states[0], 400, set(snaps))
+    pick = np.random.default_rng(7)
+    ut = pick.integers(0, mm.p + 1, 1000); kt = pick.integers(0, k, 1000)
+    ie = pick.integers(0, mm.m + 1, 1000); le = pick.integers(0, l, 1000)
+    out = {"n": 100_000, "u": 10_000, "i": 5_000, "r": 5, "gen_seed": 0, "model_seed": 0,
+           "train_sum": train.sum(axis=0), "ut": ut, "kt": kt, "ie": ie, "le": le,
+           "snapshots": np.array(snaps), "likelihood_400": np.float64(lik)}
+    for it in snaps:
+        t, e, p = kept[it]
+        out[f"theta_s_{it}"] = t[ut, kt]; out[f"eta_s_{it}"] = e[ie, le]; out[f"pr_{it}"] = p
+        out[f"theta_colsum_{it}"] = t.sum(axis=0); out[f"eta_colsum_{it}"] = e.sum(axis=0)
+        out[f"theta_min_{it}"] = np.float64(t[t > 0].min()) if (t > 0).any() else np.float64(0)
+        pdist = ref_k.prod_dist(train, t, e, p)
+        srt = np.sort(pdist, axis=1)
+        out[f"argmax_{it}"] = np.argmax(pdist, 1).astype(np.int8)
+        out[f"clear_{it}"] = np.packbits((srt[:, -1] - srt[:, -2]) > 1e-9)
+    out["likelihood_at"] = np.array([mm.em.compute_likelihood(train, *kept[it]) for it in snaps])
+    save("g5_c2_400", **out)
+
+
 def edge():
     com, upd, prd, _ = load_backend("numpy")
     norm = ExpectationMaximization.normalize_with_self
@@ -273,3 +317,7 @@ def g6_cv():
 
 if __name__ == "__main__" and os.environ.get("MMSBM_GOLDEN_ONLY", "g6") == "g6":
     g6_cv()
+
+
+if __name__ == "__main__" and os.environ.get("MMSBM_GOLDEN_ONLY", "g5long") == "g5long":
+    g5_long()

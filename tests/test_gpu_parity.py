@@ -268,6 +268,40 @@ def test_c2_50_iterations_sampled_entries_and_argmax(hip):
     assert clear.mean() > 0.99
 
 
+def test_c2_400_iterations_the_references_default_run_length(hip):
+    """the reference's DEFAULT run length (iterations=400, src/mmsbm.py:63-72) in the suite.
+    C2 from the reference's own start, against snapshots of the reference's run after 100, 200 and 400 iterations
+    (tests/golden/g5_c2_400.npz, made by make_golden.py: g5_long): sampled theta / eta entries and all of p
+    ELEMENT-WISE to 1e-6 (north_star's bar: 1e-5; measured 1.6e-8 at 400 -- an entry that has decayed through 200
+    orders of magnitude is a product of hundreds of ratios), max-norm 1e-9, likelihood 1e-9, and the argmax
+    prediction of every training row whose top-2 gap in the reference exceeds 1e-9."""
+    g = load_golden("g5_c2_400")
+    train = orc.synthetic_triples(int(g["n"]), int(g["u"]), int(g["i"]), int(g["r"]), int(g["gen_seed"]))
+    assert np.array_equal(train.sum(0), g["train_sum"])
+    mm = hip.MMSBM(10, 10, iterations=400, seed=int(g["model_seed"]))
+    mm._prepare_objects(train)
+    ctx = mm._ctx(0)
+    d_u, d_i = ctx.degrees()
+    ctx.set_params(*mm.init_params(mm.child_states[0], d_u, d_i))
+    snaps = [int(x) for x in g["snapshots"]]
+    assert snaps == [100, 200, 400]
+    done = 0
+    for j, it in enumerate(snaps):
+        ctx.iterate(it - done)
+        done = it
+        t, e, p = ctx.get_params()
+        for got, want, nm in ((t[g["ut"], g["kt"]], g[f"theta_s_{it}"], "theta entries"),
+                              (e[g["ie"], g["le"]], g[f"eta_s_{it}"], "eta entries"), (p, g[f"pr_{it}"], "p")):
+            assert rel_err(got, want) < TOL_LOOP, (nm, it)
+            assert_elementwise(got, want, f"{nm} after {it} iterations", rtol=1e-6)
+        assert rel_err(t.sum(0), g[f"theta_colsum_{it}"]) < TOL_LOOP and rel_err(e.sum(0), g[f"eta_colsum_{it}"]) < TOL_LOOP
+        assert ctx.likelihood() == pytest.approx(float(g["likelihood_at"][j]), rel=1e-9)
+        clear = np.unpackbits(g[f"clear_{it}"])[:len(train)].astype(bool)
+        assert clear.mean() > 0.99
+        assert np.array_equal(np.argmax(ctx.prod_dist(train), 1)[clear], g[f"argmax_{it}"][clear]), it
+    assert float(g["likelihood_at"][2]) == float(g["likelihood_400"])
+
+
 def test_c3_full_size_invariants(hip):
     """BASELINE config 2 (1M ratings, 100k x 20k, R=5, K=L=20): size-independent properties.
     sum_kl inc = 1 per triple  =>  rows of n_theta sum to d_u, of n_eta to d_i, n_p sums to N;

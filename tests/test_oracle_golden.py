@@ -126,6 +126,22 @@ def test_g5_c2_sampled_entries():
         assert rel_err(p, g[f"pr_{it}"]) < 1e-13
 
 
+@pytest.mark.slow
+def test_g5_long_run_first_snapshot():
+    """The 400-iteration fixture of the reference's default run length (g5_c2_400, snapshots at 100 / 200 / 400):
+    the oracle reproduces the first snapshot BIT FOR BIT (100 iterations, ~20 s); the later ones are the same loop."""
+    g = load_golden("g5_c2_400")
+    train = orc.synthetic_triples(int(g["n"]), int(g["u"]), int(g["i"]), int(g["r"]), int(g["gen_seed"]))
+    assert np.array_equal(train.sum(0), g["train_sum"])
+    out = orc.run_one_sampling(train, orc.child_seeds(int(g["model_seed"]), 1)[0], 10, 10, 100, snapshots=(100,))
+    t, e, p = out["snapshots"][100]
+    assert np.array_equal(t[g["ut"], g["kt"]], g["theta_s_100"]) and np.array_equal(e[g["ie"], g["le"]], g["eta_s_100"])
+    assert np.array_equal(p, g["pr_100"]) and np.array_equal(t.sum(0), g["theta_colsum_100"])
+    assert float(out["likelihood"]) == float(g["likelihood_at"][0])
+    pd_ = orc.prod_dist(train, t, e, p)
+    assert np.array_equal(np.argmax(pd_, 1).astype(np.int8), g["argmax_100"])
+
+
 # ---- the factorised checker (oracle/mmsbm_factorised.py): pinned to the dense oracle above ------------------
 FAC_TOL = 1e-13
 
