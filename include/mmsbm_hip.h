@@ -229,6 +229,16 @@ int mmsbm_hip_layout_build(int64_t n_obs, int32_t n_users, int32_t n_items,
 int mmsbm_hip_layout_array(const mmsbm_hip_layout *layout, int which, int32_t *out,
                            int64_t capacity, int64_t *count);
 int mmsbm_hip_layout_free(mmsbm_hip_layout *layout);
+/* Small problems with uneven degrees (the two-launch iteration): the lists that give every workgroup WHOLE segments
+ * -- all pieces of a cut segment -- so that their partial rows are added up in its LDS instead of in a combine
+ * launch.  side 0: pair segments, the 64-pair units rebuilt with at most cap_items work items each; side 1: user
+ * segments, workgroups of at most cap_items items (a longer segment gets a workgroup of its own).  which: 0 units
+ * (items begin, end, splits begin, end), 1 work items in (segment, piece) order (segment, begin, end, workgroup-local
+ * partial row or -1), 2 split segments (segment, first local partial row, pieces, 1 = combined in the strided order of
+ * seg_combine_kernel), 3 the rebuilt unit list as (rating, q_begin, q_end, 0) (side 0), 4 { most partial rows a
+ * workgroup holds, 1 if the lists could be built }.  Pass out == NULL to query count. */
+int mmsbm_hip_layout_fused(const mmsbm_hip_layout *layout, int side, int32_t cap_items, int which, int32_t *out,
+                           int64_t capacity, int64_t *count);
 /* No exception ever crosses this ABI: every entry point runs inside one handler that turns whatever is thrown
  * -- the library's own errors, std::exception, std::bad_alloc, and anything else -- into a status code and a
  * message for mmsbm_hip_last_error().  This entry throws on purpose from inside that handler so the rule can be

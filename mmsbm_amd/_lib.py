@@ -62,6 +62,7 @@ SIGNATURES = {
                                          c_i32p, C.c_int32, C.POINTER(C.c_void_p)]),
     "mmsbm_hip_layout_array": (C.c_int, [C.c_void_p, C.c_int, c_i32p, C.c_int64, c_i64p]),
     "mmsbm_hip_layout_free": (C.c_int, [C.c_void_p]),
+    "mmsbm_hip_layout_fused": (C.c_int, [C.c_void_p, C.c_int, C.c_int32, C.c_int, c_i32p, C.c_int64, c_i64p]),
     "mmsbm_hip_selftest_throw": (C.c_int, [C.c_int]),
 }
 

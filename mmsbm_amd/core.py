@@ -336,8 +336,10 @@ class HipEM:
         _lib.call("mmsbm_hip_set_graph_mode", self._h, int(mode))
 
 
-def build_layout(data, n_users, n_items, n_ratings, target_chunks=1024):
-    """Host-only: the sorted CSR layout the library uploads (dict of int32 arrays)."""
+def build_layout(data, n_users, n_items, n_ratings, target_chunks=1024, fused_caps=None):
+    """Host-only: the sorted CSR layout the library uploads (dict of int32 arrays).  ``fused_caps = (pair cap, user
+    cap)`` adds the whole-segment lists of the two-launch iteration (mmsbm_hip_layout_fused): ``fused_pairs`` /
+    ``fused_users`` = {"units", "items", "splits", "chunks", "max_parts", "built"}."""
     u, i, r = split_triples(data)
     h = C.c_void_p()
     _lib.call("mmsbm_hip_layout_build", len(u), int(n_users), int(n_items), int(n_ratings),
@@ -355,6 +357,18 @@ def build_layout(data, n_users, n_items, n_ratings, target_chunks=1024):
                 _lib.call("mmsbm_hip_layout_array", h, which, _p(arr, C.c_int32), arr.size,
                           C.byref(cnt))
             out[nm] = arr.reshape(-1, 4) if which >= 10 else arr
+        if fused_caps is not None:
+            for side, (key, cap) in enumerate(zip(("fused_pairs", "fused_users"), fused_caps)):
+                rec = {}
+                for which, nm in enumerate(("units", "items", "splits", "chunks", "info")):
+                    cnt = C.c_int64(0)
+                    _lib.call("mmsbm_hip_layout_fused", h, side, int(cap), which, None, 0, C.byref(cnt))
+                    arr = np.empty(cnt.value, dtype=np.int32)
+                    if cnt.value:
+                        _lib.call("mmsbm_hip_layout_fused", h, side, int(cap), which, _p(arr, C.c_int32), arr.size, C.byref(cnt))
+                    rec[nm] = arr.reshape(-1, 4) if which < 4 else arr
+                rec["max_parts"], rec["built"] = int(rec["info"][0]), bool(rec["info"][1])
+                out[key] = rec
     finally:
         _lib.call("mmsbm_hip_layout_free", h)
     return out

@@ -165,6 +165,13 @@ struct mmsbm_hip_ctx {
   int seg_batch = 4;  // row gathers a group of seg_pass keeps in flight (4, or 8)
   bool fused = false;          // small problems: two launches per iteration (fused_small.hpp)
   bool fused_forced = false;   // option "fused" = 1: whatever the size (else: while ratings x restart slots x (K + L) <= 14M)
+  // ... with segments that are cut into pieces (uneven degrees): every segment's pieces inside one workgroup
+  // (layout.hpp: FusedLists), pair side (the units of pairs_fused_kernel) and / or user side (blocks of tail_fused_kernel)
+  bool fs_pairs = false, fs_users = false;
+  DevBuf<mmsbm::FusedUnit> fp_units, fu_units;
+  DevBuf<mmsbm::WorkItem> fp_items, fu_items;
+  DevBuf<mmsbm::FusedSplit> fp_splits, fu_splits;
+  int fp_max_parts = 0, fu_max_parts = 0, fu_blocks = 0;
   std::vector<char> a_ok;      // per slot: atab[cur] holds A of the CURRENT parameters (the fused form computes A at
                                // the start of an iteration, so after a committed fused iteration it does not)
   bool mfma = false;    // both pair-stage launches run pair_mfma_kernel (tiles beyond the scalar cache, K, L <= 64)

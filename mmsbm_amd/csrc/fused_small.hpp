@@ -34,14 +34,55 @@ struct FusedPairArgs {
   double *partial;         // one K x L slab per workgroup
   int kp, lp, spb, nsub, nt;  // nt: A and T rows as non-temporal stores
   size_t bs_tiles, bs_eta, bs_t, bs_partial;  // restart slots (blockIdx.y): strides of the streamed tables
+  // data whose long pair segments are cut into pieces (SPLIT): the unit's work items in (pair, piece) order and
+  // its split pairs (layout.hpp: FusedLists); null otherwise
+  const mmsbm::FusedUnit *units;
+  const mmsbm::WorkItem *items;
+  const mmsbm::FusedSplit *splits;
 };
 
-size_t pairs_fused_lds(int kp, int lp) {
-  return (static_cast<size_t>(lp) * (kUnitPairs + 1) + static_cast<size_t>(kUnitPairs) * lp +
-          static_cast<size_t>(kUnitPairs) * kp + static_cast<size_t>(kp) * (kUnitPairs + 1)) * sizeof(double);
+// The pieces' partial rows of a split segment, added in the order the combine kernels of the separate launches use
+// (seg_pass.hpp) -- seg_combine_small: one after the other; seg_combine_big (more than kSmallSplitParts pieces): group
+// g of a workgroup's NG adds the pieces g, g + NG, ..., then the groups' sums are added in group order -- so that the
+// result is bit for bit theirs.  parts: the unit's partial rows in LDS, [piece][dp].
+template <int G, int VEC>
+__device__ __forceinline__ void combine_lds(const double *parts, const mmsbm::FusedSplit &sp, int dp, int lane_off,
+                                            double (&tot)[VEC]) {
+  constexpr int NG = kBlock / G;
+  const double *src = parts + static_cast<size_t>(sp.first_part) * dp + lane_off;
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) tot[v] = 0.0;
+  if (!sp.big || sp.n_parts <= NG) {
+    for (int j = 0; j < sp.n_parts; ++j) {
+      double t[VEC];
+      load_vec<VEC>(src + static_cast<size_t>(j) * dp, t);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) tot[v] += t[v];
+    }
+    return;
+  }
+  for (int g = 0; g < NG; ++g) {
+    double a[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) a[v] = 0.0;
+    for (int j = g; j < sp.n_parts; j += NG) {
+      double t[VEC];
+      load_vec<VEC>(src + static_cast<size_t>(j) * dp, t);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) a[v] += t[v];
+    }
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) tot[v] += a[v];
+  }
 }
 
-template <int G, int VEC>
+size_t pairs_fused_lds(int kp, int lp, int split_parts = 0) {  // split_parts: partial rows of a unit's split pairs
+  return (static_cast<size_t>(lp) * (kUnitPairs + 1) + static_cast<size_t>(kUnitPairs) * lp +
+          static_cast<size_t>(kUnitPairs) * kp + static_cast<size_t>(kp) * (kUnitPairs + 1) +
+          static_cast<size_t>(split_parts) * kp) * sizeof(double);
+}
+
+template <int G, int VEC, bool SPLIT>
 __global__ __launch_bounds__(kBlock) void pairs_fused_kernel(FusedPairArgs fa) {
   constexpr int CS = kUnitPairs + 1, KT = 2, TV = KT * 4, B = 8;
   const size_t slot = blockIdx.y;
@@ -57,9 +98,12 @@ __global__ __launch_bounds__(kBlock) void pairs_fused_kernel(FusedPairArgs fa) {
   double *es = etaT + static_cast<size_t>(lp) * CS;         // [64][lp]  the same rows, row-major (S); later the T rows
   double *aout = es + static_cast<size_t>(kUnitPairs) * lp; // [64][kp]  A rows of the unit
   double *cT = aout + static_cast<size_t>(kUnitPairs) * kp; // [kp][CS]  C rows, transposed
+  double *parts = cT + static_cast<size_t>(kp) * CS;        // (SPLIT) [pieces of the unit's split pairs][kp]
   STAMP(0);
   STAMP_WHERE(9);
   const mmsbm::Chunk ch = fa.chunks[blockIdx.x];
+  mmsbm::FusedUnit fu{0, 0, 0, 0};
+  if (SPLIT) fu = fa.units[blockIdx.x];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int q0 = ch.q_begin, np = ch.q_end - ch.q_begin;  // (np <= 64; 0 for the padding of the unit lists)
   typedef const double __attribute__((address_space(4))) * const_tile_ptr;
@@ -82,13 +126,22 @@ __global__ __launch_bounds__(kBlock) void pairs_fused_kernel(FusedPairArgs fa) {
   constexpr int NE = 4;  // eta loads per thread: 64 pairs x <= 32 entries / 2 per load / 256 threads
   const int tot = np * lp;
   int beg[ROUNDS], end[ROUNDS], mine[ROUNDS][IPL], nxt[ROUNDS][IPL];
+  int col[ROUNDS], prt[ROUNDS];  // (SPLIT) the item's pair within the unit (-1: no item) and its partial row (-1: whole pair)
   int pr[NE], d[NE], ids[NE];
 #pragma unroll
   for (int r = 0; r < ROUNDS; ++r) {  // level 1
     const int p0 = grp + r * NGRP;
-    const bool on = p0 < np;
-    beg[r] = on ? fa.pair_off[q0 + p0] : 0;
-    end[r] = on ? fa.pair_off[q0 + p0 + 1] : 0;
+    if (SPLIT) {  // work item p0 of the unit (at most kUnitPairs of them: the unit list is built that way)
+      const bool on = fu.it_begin + p0 < fu.it_end;
+      mmsbm::WorkItem it{-1, 0, 0, -1};
+      if (on) it = fa.items[fu.it_begin + p0];
+      beg[r] = it.begin; end[r] = it.end; prt[r] = it.part;
+      col[r] = on ? it.seg - q0 : -1;
+    } else {
+      const bool on = p0 < np;
+      beg[r] = on ? fa.pair_off[q0 + p0] : 0;
+      end[r] = on ? fa.pair_off[q0 + p0 + 1] : 0;
+    }
   }
 #pragma unroll
   for (int j = 0; j < NE; ++j) {
@@ -182,8 +235,8 @@ __global__ __launch_bounds__(kBlock) void pairs_fused_kernel(FusedPairArgs fa) {
   {
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
-      const int pr = grp + r * NGRP;
-      if (pr >= kUnitPairs) continue;  // (whole groups)
+      const int pr = SPLIT ? col[r] : grp + r * NGRP;
+      if (SPLIT ? pr < 0 : pr >= kUnitPairs) continue;  // (whole groups)
       double f[VEC], acc[VEC];
 #pragma unroll
       for (int v = 0; v < VEC; ++v) {
@@ -245,8 +298,26 @@ __global__ __launch_bounds__(kBlock) void pairs_fused_kernel(FusedPairArgs fa) {
         for (int i = 0; i < IPL; ++i) n[i] = nn[i];
       }
       if (act) {
+        if (SPLIT && prt[r] >= 0) {  // a piece of a long pair segment: its partial row, added up below
+          store_vec<VEC>(parts + static_cast<size_t>(prt[r]) * kp + lane_off, acc);
+        } else {
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) cT[(lane_off + v) * CS + pr] = acc[v];  // (pairs >= np: zero columns)
+          for (int v = 0; v < VEC; ++v) cT[(lane_off + v) * CS + pr] = acc[v];  // (pairs >= np: zero columns)
+        }
+      }
+    }
+  }
+  if (SPLIT) {
+    // (the columns no item writes: those beyond the unit's pairs are zero; a split pair's column comes from its pieces)
+    for (int t = tid; t < (kUnitPairs - np) * kp; t += kBlock) cT[(t / (kUnitPairs - np)) * CS + np + t % (kUnitPairs - np)] = 0.0;
+    __syncthreads();
+    for (int s = fu.sp_begin + grp; s < fu.sp_end; s += NGRP) {
+      const mmsbm::FusedSplit sp = fa.splits[s];
+      double tot[VEC];
+      combine_lds<G, VEC>(parts, sp, kp, lane_off, tot);
+      if (act) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) cT[(lane_off + v) * CS + (sp.seg - q0)] = tot[v];
       }
     }
   }
@@ -439,14 +510,102 @@ __device__ __forceinline__ void seg_body_small(const SegArgs &a, int unit, int d
   store_vec_out<VEC>(rowtab_ptr(outt, seg, lane_off), o, (a.nt_out & 1) != 0 && a.mode != 0);
 }
 
+// User segments cut into pieces, every segment's pieces inside ONE workgroup (layout.hpp: build_fused_users): the
+// workgroup's groups of lanes take its work items round robin -- whole segments are finished as in seg_body_small,
+// a piece leaves its raw partial row in LDS -- and after a barrier one group per split segment adds the pieces up in
+// the combine kernels' order (combine_lds) and applies their epilogue.  Bit for bit seg_pass + seg_combine.
+struct FusedUserArgs {
+  const mmsbm::FusedUnit *units;
+  const mmsbm::WorkItem *items;
+  const mmsbm::FusedSplit *splits;
+};
+template <int G, int VEC, int CH>
+__device__ __forceinline__ void users_split_block(const SegArgs &a, const FusedUserArgs &fu_args, int blk, int dp, double *parts) {
+  constexpr int IPL = CH / G, NGRP = kBlock / G;
+  static_assert(IPL >= 1 && CH % G == 0, "groups of up to 16 lanes");
+  const int gl = threadIdx.x % G, grp = threadIdx.x / G;
+  const size_t sidx = blockIdx.y;
+  const RowTab fixed = slot_tab(a.fixed, sidx), gath = slot_tab(a.gath, sidx), outt = slot_tab(a.out, sidx);
+  const mmsbm::FusedUnit fu = fu_args.units[blk];
+  const bool act = gl * VEC < dp;
+  const int lane_off = act ? gl * VEC : 0;
+  const bool g_main = lane_off < gath.mw;
+  const double *gbase = g_main ? gath.main + lane_off : gath.tail + (lane_off - gath.mw);
+  const size_t gstride = g_main ? gath.rs_m : gath.rs_t;
+  for (int it = fu.it_begin + grp; it < fu.it_end; it += NGRP) {  // (whole groups)
+    const mmsbm::WorkItem w = fu_args.items[it];
+    const int beg = w.begin, end = w.end;
+    double f[VEC], acc[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v] = 0.0;
+    load_vec<VEC>(rowtab_ptr(fixed, w.seg, lane_off), f);
+    if (!act) {
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) f[v] = 0.0;
+    }
+    const int last = max(end - 1, beg);
+    int n[IPL];
+#pragma unroll
+    for (int i = 0; i < IPL; ++i) n[i] = end - beg > i * G ? a.idx[min(beg + i * G + gl, last)] : 0;
+    for (int c0 = beg; c0 < end; c0 += CH) {
+      const int cnt = min(CH, end - c0);
+      double g[CH][VEC];
+#pragma unroll
+      for (int b = 0; b < CH; ++b) {
+        const int id = __shfl(n[b / G], b % G, G);
+        if (b < cnt) load_vec<VEC>(gbase + static_cast<size_t>(id) * gstride, g[b]);
+      }
+      if (c0 + CH < end) {
+#pragma unroll
+        for (int i = 0; i < IPL; ++i) n[i] = a.idx[min(c0 + CH + i * G + gl, last)];
+      }
+#pragma unroll
+      for (int b = 0; b < CH; ++b) {
+        if (b < cnt) {
+          double pt = 0.0;
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) pt = fma(g[b][v], f[v], pt);
+          const double s = group_sum<G>(pt);
+          const double wgt = 1.0 / fmax(s, kEps);
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) acc[v] = fma(g[b][v], wgt, acc[v]);
+        }
+      }
+    }
+    if (!act) continue;
+    if (w.part >= 0) {
+      store_vec<VEC>(parts + static_cast<size_t>(w.part) * dp + lane_off, acc);
+      continue;
+    }
+    double o[VEC];
+    const double d = static_cast<double>(max(end - beg, 1));
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) o[v] = a.mode == 0 ? acc[v] : (a.mode == 1 ? (f[v] * acc[v]) / d : f[v] * acc[v]);
+    store_vec<VEC>(rowtab_ptr(outt, w.seg, lane_off), o);
+  }
+  __syncthreads();
+  for (int s = fu.sp_begin + grp; s < fu.sp_end; s += NGRP) {
+    const mmsbm::FusedSplit sp = fu_args.splits[s];
+    double tot[VEC], f[VEC], o[VEC];
+    combine_lds<G, VEC>(parts, sp, dp, lane_off, tot);
+    if (!act) continue;
+    load_vec<VEC>(rowtab_ptr(fixed, sp.seg, lane_off), f);
+    const double d = static_cast<double>(max(a.off[sp.seg + 1] - a.off[sp.seg], 1));
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) o[v] = a.mode == 0 ? tot[v] : (a.mode == 1 ? (f[v] * tot[v]) / d : f[v] * tot[v]);
+    store_vec<VEC>(rowtab_ptr(outt, sp.seg, lane_off), o);
+  }
+}
+
 // Rows in flight per user segment (UCH): 32 while the launch is ONE round of workgroups at one workgroup per CU (32 rows
 // of 4 doubles per lane are 256 registers); 16 beyond.  Measured at BASELINE's config 1 on one box, per iteration:
 // 8 (seg_body) 20.8 us, 16 20.4, 24 20.6, 32 19.8, 48 20.7; with the 157 user workgroups split into 314 smaller ones
 // (a second round at 32) 23.5.
 // launch 2: blocks [0, nb_p) p_update, [nb_p, nb_p + bu) user segments, the rest item_sum
-template <int G, int VEC, int GL, int VECL, int UCH>
-__global__ __launch_bounds__(kBlock) void tail_fused_kernel(SegArgs su, EtaPArgs a, int bu, int dp) {
+template <int G, int VEC, int GL, int VECL, int UCH, bool SPLIT>
+__global__ __launch_bounds__(kBlock) void tail_fused_kernel(SegArgs su, EtaPArgs a, int bu, int dp, FusedUserArgs fu) {
   __shared__ double red[kRedGroup][kRedRows][kRedCols];  // (eta_p_kernel's pattern: the same sums in the same order)
+  extern __shared__ double split_parts[];                // (SPLIT) the partial rows of the workgroup's split user segments
   const int bx = static_cast<int>(blockIdx.x);
   const size_t slot = blockIdx.y;
   STAMP(0);
@@ -456,7 +615,8 @@ __global__ __launch_bounds__(kBlock) void tail_fused_kernel(SegArgs su, EtaPArgs
                                       a.p_old + slot * a.bs_p, a.p_new + slot * a.bs_p, a.pt_new + slot * a.bs_p,
                                       a.npr + slot * a.bs_p, a.n_ratings, a.kp, a.lp, a.normalize);
   } else if (bx < a.nb_p + bu) {
-    seg_body_small<G, VEC, UCH>(su, (bx - a.nb_p) * (kBlock / G) + threadIdx.x / G, dp);
+    if (SPLIT) users_split_block<G, VEC, (UCH > 16 ? 16 : UCH)>(su, fu, bx - a.nb_p, dp, split_parts);
+    else seg_body_small<G, VEC, UCH>(su, (bx - a.nb_p) * (kBlock / G) + threadIdx.x / G, dp);
   } else {
     item_sum_block<GL, VECL>(bx - bu - a.nb_p, a.ttab + slot * a.bs_t, a.item_off, a.item_pairs, a.item_deg,
                              a.eta + slot * a.bs_eta, a.eta_new + slot * a.bs_eta, a.n_items, a.lp, a.normalize,

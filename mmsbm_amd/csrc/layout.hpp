@@ -314,6 +314,129 @@ inline void build_mv_chunks(Layout &L, int32_t pairs) {
   }
 }
 
+// ---- split segments inside ONE workgroup (the two-launch iteration of small problems, fused_small.hpp) --------------
+// Data with uneven degrees (real rating tables: a few hundred users with ~100 ratings each, popular items with
+// thousands) has its long segments cut into work items above, whose partial sums a separate combine launch adds up --
+// and the two-launch iteration keeps C in LDS, so it needs every piece of a pair segment inside the workgroup that
+// owns the pair's 64-pair unit.  These lists give every workgroup WHOLE segments: its work items in (segment, piece)
+// order and the segments among them that are split; the pieces' partial rows then meet in LDS and are added in the
+// order the combine kernels use (seg_pass.hpp), so the results are bit for bit those of the separate launches.
+struct FusedUnit {   // one workgroup
+  int32_t it_begin, it_end;   // its work items (FusedLists::items)
+  int32_t sp_begin, sp_end;   // its split segments (FusedLists::splits)
+};
+struct FusedSplit {
+  int32_t seg, first_part, n_parts, big;  // first_part: the unit-LOCAL partial row of piece 0; big: the strided order
+};
+struct FusedLists {
+  std::vector<WorkItem> items;     // part = unit-local partial row, or -1: the item is the whole segment
+  std::vector<FusedSplit> splits;
+  std::vector<FusedUnit> units;
+  int32_t max_parts = 0;           // partial rows a workgroup holds at most
+};
+// Every segment's pieces in piece order, whatever kind of work list cut them (none: one whole piece per segment).
+struct SegPieces {
+  std::vector<int32_t> first;      // [nseg + 1] into `pieces`
+  std::vector<WorkItem> pieces;    // (seg, begin, end, part = the GLOBAL partial row or -1)
+  std::vector<char> big;           // [nseg] combined by seg_combine_big (more than kSmallSplitParts pieces)
+};
+inline SegPieces segment_pieces(const std::vector<int32_t> &off, const WorkList &w) {
+  const int32_t nseg = int32_t(off.size()) - 1;
+  SegPieces sp;
+  sp.first.assign(size_t(nseg) + 1, 0);
+  sp.big.assign(size_t(std::max(nseg, 0)), 0);
+  std::vector<int32_t> count(size_t(std::max(nseg, 0)), 1), first_part(size_t(std::max(nseg, 0)), -1);
+  for (size_t j = 0; j < w.splits.size(); ++j) {
+    const SplitSeg &s = w.splits[j];
+    count[size_t(s.seg)] = s.n_parts;
+    first_part[size_t(s.seg)] = s.first_part;
+    sp.big[size_t(s.seg)] = int32_t(j) >= w.n_small;
+  }
+  std::vector<WorkItem> by_part(size_t(w.n_parts));
+  for (const WorkItem &it : w.items)
+    if (it.seg >= 0 && it.part >= 0) by_part[size_t(it.part)] = it;
+  for (int32_t s = 0; s < nseg; ++s) sp.first[size_t(s) + 1] = sp.first[size_t(s)] + count[size_t(s)];
+  sp.pieces.resize(size_t(sp.first[size_t(nseg)]));
+  for (int32_t s = 0; s < nseg; ++s) {
+    WorkItem *dst = sp.pieces.data() + sp.first[size_t(s)];
+    if (first_part[size_t(s)] < 0) dst[0] = WorkItem{s, off[size_t(s)], off[size_t(s) + 1], -1};
+    else for (int32_t j = 0; j < count[size_t(s)]; ++j) dst[j] = by_part[size_t(first_part[size_t(s)] + j)];
+  }
+  return sp;
+}
+// The pair_block / pairs_fused work list with at most `pairs` pairs AND at most `cap_items` work items per
+// workgroup (a popular item's pairs bring several pieces each).  False -- and nothing changed -- when a single
+// pair has more pieces than that.
+inline bool build_mv_chunks_capped(Layout &L, const SegPieces &sp, int32_t pairs, int32_t cap_items) {
+  for (int32_t q = 0; q < L.n_pairs; ++q)
+    if (sp.first[size_t(q) + 1] - sp.first[size_t(q)] > cap_items) return false;
+  const bool align = std::getenv("MMSBM_HIP_NO_CHUNK_ALIGN") == nullptr;
+  L.mv_chunks.clear();
+  L.mv_chunk_off.assign(size_t(L.n_ratings) + 1, 0);
+  for (int r = 0; r < L.n_ratings; ++r) {
+    const int32_t end = L.rating_off[r + 1];
+    int32_t q = L.rating_off[r];
+    while (q < end) {
+      int32_t e = q, items = 0;
+      while (e < end && e - q < pairs && items + (sp.first[size_t(e) + 1] - sp.first[size_t(e)]) <= cap_items) {
+        items += sp.first[size_t(e) + 1] - sp.first[size_t(e)];
+        ++e;
+      }
+      L.mv_chunks.push_back(Chunk{r, q, e, 0});
+      q = e;
+    }
+    if (align && L.n_ratings > 1 && end > L.rating_off[r])
+      while ((L.mv_chunks.size() - size_t(L.mv_chunk_off[r])) % size_t(kXcds)) L.mv_chunks.push_back(Chunk{r, end, end, 0});
+    L.mv_chunk_off[r + 1] = int32_t(L.mv_chunks.size());
+  }
+  return true;
+}
+inline void fused_append(FusedLists &out, const SegPieces &sp, int32_t s_begin, int32_t s_end) {
+  FusedUnit u{int32_t(out.items.size()), 0, int32_t(out.splits.size()), 0};
+  int32_t parts = 0;
+  for (int32_t s = s_begin; s < s_end; ++s) {
+    const int32_t a = sp.first[size_t(s)], n = sp.first[size_t(s) + 1] - a;
+    if (n == 1 && sp.pieces[size_t(a)].part < 0) {
+      out.items.push_back(sp.pieces[size_t(a)]);
+      continue;
+    }
+    out.splits.push_back(FusedSplit{s, parts, n, sp.big[size_t(s)]});
+    for (int32_t j = 0; j < n; ++j) {
+      WorkItem it = sp.pieces[size_t(a + j)];
+      it.part = parts + j;
+      out.items.push_back(it);
+    }
+    parts += n;
+  }
+  u.it_end = int32_t(out.items.size());
+  u.sp_end = int32_t(out.splits.size());
+  out.units.push_back(u);
+  out.max_parts = std::max(out.max_parts, parts);
+}
+// pair side: one unit per mv_chunk (its pairs' pieces)
+inline FusedLists build_fused_pairs(const Layout &L, const SegPieces &sp) {
+  FusedLists out;
+  for (const Chunk &ch : L.mv_chunks) fused_append(out, sp, ch.q_begin, ch.q_end);
+  return out;
+}
+// user side: consecutive segments while the workgroup's items stay within `cap_items` (= its groups of lanes: one
+// round); a segment with more pieces than that gets a workgroup of its own, which makes several rounds.
+inline FusedLists build_fused_users(const SegPieces &sp, int32_t cap_items) {
+  FusedLists out;
+  const int32_t nseg = int32_t(sp.first.size()) - 1;
+  int32_t s = 0;
+  while (s < nseg) {
+    int32_t e = s, items = 0;
+    while (e < nseg && (e == s || items + (sp.first[size_t(e) + 1] - sp.first[size_t(e)]) <= cap_items)) {
+      items += sp.first[size_t(e) + 1] - sp.first[size_t(e)];
+      ++e;
+    }
+    fused_append(out, sp, s, e);
+    s = e;
+  }
+  return out;
+}
+
 // Host threads for the sorts below: one for small inputs, up to 8 for millions of triples.
 inline int &layout_threads_override() {  // tests: force a thread count (0 = automatic)
   static int v = 0;

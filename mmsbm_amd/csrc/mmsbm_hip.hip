@@ -331,6 +331,42 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
       c->ranges_users = ru;
     }
     lap("xcd-local work lists");
+    // Small problems with uneven degrees (round 4): segments are cut into pieces above; give every workgroup of the
+    // two-launch form WHOLE segments (layout.hpp: FusedLists) so that the pieces' partial rows meet in its LDS instead
+    // of in a combine launch.  Pair side: the 64-pair units are rebuilt with at most 64 work items each (both forms
+    // of the iteration then use these units: their S sums associate the same way); a pair of more than 64 pieces, or a
+    // user whose pieces' partial rows exceed the LDS budget, leaves the data with the separate launches.
+    if (n_obs <= kFusedRatingsMax && fused_shape_ok(c.get()) && std::getenv("MMSBM_HIP_NO_FUSED_SPLIT") == nullptr &&
+        (!c->lay.pair_work.splits.empty() || !c->lay.user_work.splits.empty())) {
+      const int lanes = group_lanes(c->code_k);
+      if (!c->lay.pair_work.splits.empty()) {
+        const mmsbm::SegPieces sp = mmsbm::segment_pieces(c->lay.pair_off, c->lay.pair_work);
+        if (mmsbm::build_mv_chunks_capped(c->lay, sp, mmsbm::kMvChunkPairs, kUnitPairs)) {
+          c->n_chunks = static_cast<int>(c->lay.mv_chunks.size());
+          const mmsbm::FusedLists fl = mmsbm::build_fused_pairs(c->lay, sp);
+          if (pairs_fused_lds(c->kp, c->lp, fl.max_parts) <= kLdsMax) {
+            c->fp_units.upload(fl.units, c->stream); c->fp_items.upload(fl.items, c->stream);
+            c->fp_splits.upload(fl.splits, c->stream);
+            HIP_CHECK(hipStreamSynchronize(c->stream));  // (`fl` is a local)
+            c->fp_max_parts = fl.max_parts;
+            c->fs_pairs = true;
+          }
+        }
+      }
+      if (!c->lay.user_work.splits.empty()) {
+        const mmsbm::SegPieces sp = mmsbm::segment_pieces(c->lay.user_off, c->lay.user_work);
+        const mmsbm::FusedLists fl = mmsbm::build_fused_users(sp, kBlock / lanes);
+        if (static_cast<size_t>(fl.max_parts) * c->kp * sizeof(double) <= kFusedSplitLds) {
+          c->fu_units.upload(fl.units, c->stream); c->fu_items.upload(fl.items, c->stream);
+          c->fu_splits.upload(fl.splits, c->stream);
+          HIP_CHECK(hipStreamSynchronize(c->stream));
+          c->fu_max_parts = fl.max_parts;
+          c->fu_blocks = static_cast<int>(fl.units.size());
+          c->fs_users = true;
+        }
+      }
+      lap("whole-segment lists (two launches)");
+    }
     // small problems (where eight rows in flight pay, above): two launches per iteration instead of four
     c->fused = n_obs <= kFusedRatingsMax && fused_possible(c.get()) && std::getenv("MMSBM_HIP_NO_FUSED") == nullptr;
 
@@ -1206,6 +1242,9 @@ int mmsbm_hip_get_option(const mmsbm_hip_ctx *ctx, const char *name, double *val
     else if (key == "n_chunks") *value = ctx->n_chunks;            // read-only: pair-stage workgroups (= slabs), padding included
     else if (key == "items_pairs") *value = static_cast<double>(ctx->lay.pair_work.items.size());
     else if (key == "items_users") *value = static_cast<double>(ctx->lay.user_work.items.size());
+    else if (key == "splits_pairs") *value = static_cast<double>(ctx->lay.pair_work.splits.size());  // read-only: segments cut into pieces
+    else if (key == "splits_users") *value = static_cast<double>(ctx->lay.user_work.splits.size());
+    else if (key == "fused_split") *value = (ctx->fs_pairs ? 1 : 0) + (ctx->fs_users ? 2 : 0);  // read-only: whole-segment lists built (1 pair side, 2 user side)
     else throw std::invalid_argument("unknown option: " + key);
   });
 }
@@ -1296,6 +1335,42 @@ int mmsbm_hip_layout_array(const mmsbm_hip_layout *h, int which, int32_t *out, i
     if (out) {
       if (capacity < *count) throw ApiError(MMSBM_E_TOOLARGE, "buffer too small");
       std::memcpy(out, v->data(), sizeof(int32_t) * v->size());
+    }
+  });
+}
+
+// side 0: pair segments (the 64-pair units rebuilt with at most cap_items work items each), 1: user segments
+// (workgroups of at most cap_items items).  which: 0 units, 1 items, 2 splits (4-int records), 3 the unit list as
+// chunks (side 0 only), 4 { max partial rows of a workgroup, built (0 / 1) } (2 ints)
+int mmsbm_hip_layout_fused(const mmsbm_hip_layout *h, int side, int32_t cap_items, int which, int32_t *out,
+                           int64_t capacity, int64_t *count) {
+  return guarded([&] {
+    if (!h || !count) throw std::invalid_argument("null argument");
+    if ((side != 0 && side != 1) || cap_items < 1 || which < 0 || which > 4) throw std::invalid_argument("bad argument");
+    mmsbm::Layout lay = h->lay;  // (the capped unit list replaces mv_chunks: work on a copy)
+    mmsbm::FusedLists fl;
+    bool built = true;
+    if (side == 0) {
+      const mmsbm::SegPieces sp = mmsbm::segment_pieces(lay.pair_off, lay.pair_work);
+      built = mmsbm::build_mv_chunks_capped(lay, sp, mmsbm::kMvChunkPairs, cap_items);
+      if (built) fl = mmsbm::build_fused_pairs(lay, sp);
+    } else {
+      fl = mmsbm::build_fused_users(mmsbm::segment_pieces(lay.user_off, lay.user_work), cap_items);
+    }
+    const int32_t info[2] = {fl.max_parts, built ? 1 : 0};
+    const void *src = nullptr;
+    size_t n = 0;
+    switch (which) {
+      case 0: src = fl.units.data(); n = fl.units.size() * 4; break;
+      case 1: src = fl.items.data(); n = fl.items.size() * 4; break;
+      case 2: src = fl.splits.data(); n = fl.splits.size() * 4; break;
+      case 3: src = lay.mv_chunks.data(); n = side == 0 ? lay.mv_chunks.size() * 4 : 0; break;
+      default: src = info; n = 2; break;
+    }
+    *count = static_cast<int64_t>(n);
+    if (out && n) {
+      if (capacity < *count) throw ApiError(MMSBM_E_TOOLARGE, "buffer too small");
+      std::memcpy(out, src, sizeof(int32_t) * n);
     }
   });
 }

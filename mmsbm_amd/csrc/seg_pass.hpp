@@ -292,6 +292,9 @@ __device__ __forceinline__ void seg_combine_big(const CombineArgs &ca, const Com
   if (act) store_vec<VEC>(lds + grp * dp + lane_off, acc);
   __syncthreads();
   if (grp != 0 || !act) return;
+  // (four loads in flight, not all NG - 1 of them: fully unrolled with its loads hoisted this loop took 256 registers
+  // and spilled at G = 4 -- NG = 64 rows of VEC doubles; the additions stay in group order)
+#pragma unroll 4
   for (int g = 1; g < NG; ++g) {
     double t[VEC];
     load_vec<VEC>(lds + g * dp + lane_off, t);

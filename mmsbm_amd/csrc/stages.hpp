@@ -407,15 +407,21 @@ void stage_matvec_a(mmsbm_hip_ctx *c, int slot, int a_slot, bool grid = false) {
 }
 
 // ---- small problems: the iteration in two launches (fused_small.hpp) -------------------------------------
-bool fused_possible(const mmsbm_hip_ctx *c) {
+constexpr size_t kFusedSplitLds = 96 * 1024;  // partial rows of a workgroup's split user segments, at most
+bool fused_shape_ok(const mmsbm_hip_ctx *c) {  // (everything but the data: the kernels exist for this shape)
   // (rows of up to 24 groups: beyond that the four-launch pair stage runs 512-thread workgroups, whose split of a
   // unit's pairs among the copies of the slab grid -- hence the association order of S -- 256 threads cannot mirror)
   return c->code_k <= 1 && c->code_l <= 1 && c->pb_threads_t == kBlock && c->pb_threads_a == kBlock && !c->tl_t &&
          !c->tl_a && c->pb_nacc == 1 && c->pb_kt == 2 && c->pb_spb * c->pb_nsub <= kBlock && !c->wide &&
          !c->mfma && !c->mfma_big && !c->direct_out && c->mv_chunk_pairs == mmsbm::kMvChunkPairs && c->n_chunks > 0 &&
-         // (no segment cut into pieces; a work list that only ORDERS whole segments is fine: the pair units ignore it
-         // -- every segment's result is its own -- and the user pass follows it as before)
-         c->lay.pair_work.splits.empty() && c->lay.user_work.splits.empty() && pairs_fused_lds(c->kp, c->lp) <= kLdsBudget;
+         pairs_fused_lds(c->kp, c->lp) <= kLdsBudget;
+}
+bool fused_possible(const mmsbm_hip_ctx *c) {
+  // A work list that only ORDERS whole segments is fine (the pair units ignore it -- every segment's result is its
+  // own -- and the user pass follows it as before); segments cut into pieces need all pieces of a segment inside one
+  // workgroup: the lists create() builds for small problems (fs_pairs / fs_users; round 4)
+  return fused_shape_ok(c) && (c->lay.pair_work.splits.empty() || c->fs_pairs) &&
+         (c->lay.user_work.splits.empty() || c->fs_users);
 }
 void stage_fused_pairs(mmsbm_hip_ctx *c) {
   LaunchScope ls(c, K_FUSED_PAIRS, true);
@@ -427,10 +433,19 @@ void stage_fused_pairs(mmsbm_hip_ctx *c) {
   fa.chunks = c->mv_chunks.ptr; fa.t_out = c->ttab.at(s); fa.partial = c->partial.at(s);
   fa.kp = c->kp; fa.lp = c->lp; fa.spb = c->pb_spb; fa.nsub = c->pb_nsub; fa.nt = nt_on(c) & 1;
   fa.bs_tiles = c->p[0].stride; fa.bs_eta = c->eta[0].stride; fa.bs_t = c->ttab.stride; fa.bs_partial = c->partial.stride;
-  const size_t lds = pairs_fused_lds(c->kp, c->lp);
+  const bool split = c->fs_pairs && !c->lay.pair_work.splits.empty();
+  fa.units = split ? c->fp_units.ptr : nullptr; fa.items = split ? c->fp_items.ptr : nullptr;
+  fa.splits = split ? c->fp_splits.ptr : nullptr;
+  const size_t lds = pairs_fused_lds(c->kp, c->lp, split ? c->fp_max_parts : 0);
   const dim3 grid = slot_grid(c, c->n_chunks);
-  if (c->code_k == 0) LAUNCH_IN(ls, (pairs_fused_kernel<4, 4>), grid, kBlock, lds, c->stream, fa);
-  else LAUNCH_IN(ls, (pairs_fused_kernel<8, 4>), grid, kBlock, lds, c->stream, fa);
+#define PF(G, S)                                                                  \
+  do {                                                                            \
+    allow_big_lds(pairs_fused_kernel<G, 4, S>, lds);                              \
+    LAUNCH_IN(ls, (pairs_fused_kernel<G, 4, S>), grid, kBlock, lds, c->stream, fa); \
+  } while (0)
+  if (c->code_k == 0) { if (split) PF(4, true); else PF(4, false); }
+  else { if (split) PF(8, true); else PF(8, false); }
+#undef PF
   ls.done();
 }
 void stage_fused_tail(mmsbm_hip_ctx *c, bool commit) {
@@ -438,14 +453,20 @@ void stage_fused_tail(mmsbm_hip_ctx *c, bool commit) {
   const SegArgs su = seg_users_args(c, commit, c->n_users);
   const EtaPArgs a = eta_p_args(c, commit, kRedCols);
   const int per_u = kBlock / group_lanes(c->code_k), per_i = kBlock / group_lanes(c->code_l);
-  const int bu = (su.nseg + per_u - 1) / per_u, nb_i = (c->n_items + per_i - 1) / per_i;
+  const bool split = c->fs_users && !c->lay.user_work.splits.empty();
+  const int bu = split ? c->fu_blocks : (su.nseg + per_u - 1) / per_u, nb_i = (c->n_items + per_i - 1) / per_i;
   const dim3 grid = slot_grid(c, bu + a.nb_p + nb_i);
+  const FusedUserArgs fu{split ? c->fu_units.ptr : nullptr, split ? c->fu_items.ptr : nullptr, split ? c->fu_splits.ptr : nullptr};
+  const size_t lds = split ? static_cast<size_t>(c->fu_max_parts) * c->kp * sizeof(double) : 0;
   // (32 rows in flight per user segment leave one workgroup per CU: only while that is a single round)
   const bool deep = static_cast<long long>(grid.x) * grid.y <= c->n_cus;
 #define TAIL(G, V, GL, VL)                                                                                        \
   do {                                                                                                            \
-    if (deep) LAUNCH_IN(ls, (tail_fused_kernel<G, V, GL, VL, 32>), grid, kBlock, 0, c->stream, su, a, bu, c->kp); \
-    else LAUNCH_IN(ls, (tail_fused_kernel<G, V, GL, VL, 16>), grid, kBlock, 0, c->stream, su, a, bu, c->kp);      \
+    if (split) {                                                                                                  \
+      allow_big_lds(tail_fused_kernel<G, V, GL, VL, 16, true>, lds);                                              \
+      LAUNCH_IN(ls, (tail_fused_kernel<G, V, GL, VL, 16, true>), grid, kBlock, lds, c->stream, su, a, bu, c->kp, fu); \
+    } else if (deep) LAUNCH_IN(ls, (tail_fused_kernel<G, V, GL, VL, 32, false>), grid, kBlock, 0, c->stream, su, a, bu, c->kp, fu); \
+    else LAUNCH_IN(ls, (tail_fused_kernel<G, V, GL, VL, 16, false>), grid, kBlock, 0, c->stream, su, a, bu, c->kp, fu);      \
   } while (0)
   switch (c->code_k * 2 + c->code_l) {
     case 0: TAIL(4, 4, 4, 4); break;

@@ -394,7 +394,7 @@ def test_launch_modes_give_identical_results(hip, slots):
             assert np.array_equal(a, b)
 
 
-@pytest.mark.parametrize("shape", ["c1", "g4", "k20", "k12x24", "ragged", "busy", "c2"])
+@pytest.mark.parametrize("shape", ["c1", "g4", "k20", "k12x24", "ragged", "busy", "c2", "ml10", "ml20", "bigsplit"])
 def test_two_launch_iteration_is_bitwise_the_four_launch_one(hip, shape):
     """fused_small.hpp: for small problems an iteration is pairs_fused_kernel (A, the pair pass and T + S
     of a 64-pair unit in one workgroup, C never leaving LDS) + tail_fused_kernel (user pass || p_update ||
@@ -417,6 +417,19 @@ def test_two_launch_iteration_is_bitwise_the_four_launch_one(hip, shape):
             i_col = rng.integers(0, 400, n) * 3 % 401
             u_col = rng.integers(0, 900, n) * 2
             data, k, l = np.stack([u_col, i_col, r_col], axis=1).astype(np.int64), 7, 13
+        elif shape in ("ml10", "ml20"):   # the MovieLens-100k shape in small: few users with ~100 ratings each, popular
+            n, n_uu, n_ii = 30_000, 300, 500   # items -- segments cut into pieces on BOTH sides, every piece of a
+            pu, pi = rng.lognormal(0, 0.8, n_uu), rng.lognormal(0, 1.2, n_ii)   # segment inside one workgroup (round 4)
+            data = np.stack([rng.choice(n_uu, n, p=pu / pu.sum()), rng.choice(n_ii, n, p=pi / pi.sum()), rng.integers(0, 5, n)],
+                            axis=1).astype(np.int64)
+            k, l = (10, 10) if shape == "ml10" else (20, 16)
+        elif shape == "bigsplit":  # a user with 40 % of the rows (225 pieces: more than a workgroup has groups, strided
+            n = 24_000             # combine order) and an (item, rating) pair with 12 % (45 pieces of 64)
+            u_col = np.where(rng.random(n) < 0.4, 5, rng.integers(0, 900, n))
+            hot = rng.random(n) < 0.12
+            data = np.stack([u_col, np.where(hot, 2, rng.integers(0, 400, n)), np.where(hot, 1, rng.integers(0, 5, n))],
+                            axis=1).astype(np.int64)
+            k, l = 7, 13
         elif shape == "busy":     # 20 users with 50 ratings each among 780 with ~11: segments of two steps of rows in flight
             u_col = np.concatenate([np.repeat(np.arange(20), 50), rng.integers(20, 800, 8_600)])
             data = np.stack([u_col, rng.integers(0, 300, u_col.size), rng.integers(0, 4, u_col.size)], axis=1).astype(np.int64)
@@ -432,6 +445,9 @@ def test_two_launch_iteration_is_bitwise_the_four_launch_one(hip, shape):
         with hip.HipEM(data, k, l, n_u, n_i, n_r, slots=2) as em:
             if fused:
                 assert em.get_option("fused") == 1.0     # the library's own choice for a problem of this size
+                if shape in ("ml10", "ml20", "bigsplit"):
+                    assert em.get_option("splits_pairs") > 0 and em.get_option("splits_users") > 0
+                    assert em.get_option("fused_split") == 3.0 and em.get_option("launches") == 2.0
             em.set_option("fused", fused)
             em.select(0).set_params(*start)
             em.select(1).set_params(start[0] * 0.5 + 0.01, start[1], start[2])
@@ -513,8 +529,16 @@ def test_two_launch_iteration_is_chosen_by_size_and_refused_where_it_does_not_ap
     n = 9_000
     skew = np.stack([np.where(rng.random(n) < 0.3, 3, rng.integers(0, 900, n)), rng.integers(0, 400, n),
                      rng.integers(0, 5, n)], axis=1).astype(np.int64)
-    with hip.HipEM(skew, 10, 10) as em:
-        assert em.get_option("items_users") > 0 and em.get_option("fused") == 0.0
+    with hip.HipEM(skew, 10, 10) as em:                  # ... its pieces all sit in one workgroup of the tail launch (round 4)
+        assert em.get_option("items_users") > 0 and em.get_option("splits_users") > 0
+        assert em.get_option("fused") == 1.0 and em.get_option("fused_split") == 2.0 and em.get_option("launches") == 2.0
+    hot = skew.copy()                                    # an (item, rating) pair of 4,500 triples: more than the 64 pieces a
+    hot[:4500, 1:] = (7, 2)                              # 64-pair unit may hold -- this data keeps the separate launches
+    hot[:4500, 0] = np.arange(4500) % 900
+    with hip.HipEM(hot, 10, 10) as em:
+        assert em.get_option("splits_pairs") > 0 and em.get_option("fused") == 0.0 and em.get_option("launches") == 4.0
+        with pytest.raises(Exception, match="fused"):
+            em.set_option("fused", 1)
 
 
 def test_non_temporal_output_rows_change_nothing_but_the_cache_policy(hip):

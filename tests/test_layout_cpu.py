@@ -185,3 +185,78 @@ def test_cut_policy_for_sparse_dense_and_skewed_data():
     assert cut == 64
     assert check_worklist(lay, "user", lay["user_off"], cut) == 1
     assert lay["user_splits"][0, 2] == -(-np.diff(lay["user_off"])[7] // 64) > 32
+
+
+def _check_fused_lists(off, work_items, work_splits, fl, cap, whole_workgroups=None):
+    """Every workgroup holds WHOLE segments; its items are the segments' pieces in (segment, piece) order and cover
+    every triple once; split segments carry workgroup-local partial rows 0 .. max_parts - 1."""
+    units, items, splits = fl["units"], fl["items"], fl["splits"]
+    nseg = len(off) - 1
+    n_pieces = {int(s): int(n) for s, _, n, _ in work_splits}
+    seen_seg, cover = np.zeros(nseg, dtype=int), np.zeros(int(off[-1]), dtype=int)
+    assert units[0, 0] == 0 and units[-1, 1] == len(items) and units[0, 2] == 0 and units[-1, 3] == len(splits)
+    assert np.array_equal(units[1:, 0], units[:-1, 1]) and np.array_equal(units[1:, 2], units[:-1, 3])
+    most = 0
+    for ib, ie, sb, se in units:
+        its, sps = items[ib:ie], splits[sb:se]
+        segs = its[:, 0]
+        assert np.all(np.diff(segs) >= 0)                                  # segment order
+        for s in np.unique(segs):
+            mine = its[segs == s]
+            seen_seg[s] += 1                                               # ... and a segment is in ONE workgroup
+            assert mine[0, 1] == off[s] and mine[-1, 2] == off[s + 1] and np.array_equal(mine[1:, 1], mine[:-1, 2])
+            if len(mine) == 1 and mine[0, 3] < 0:
+                assert s not in n_pieces
+            else:
+                assert n_pieces[s] == len(mine) and np.array_equal(mine[:, 3], mine[0, 3] + np.arange(len(mine)))
+        for b, e in its[:, 1:3]:
+            cover[b:e] += 1
+        parts = 0
+        for s, first, n, big in sps:
+            assert first == parts and n == n_pieces[s] and big == (n > 32)
+            parts += n
+        assert parts == int((its[:, 3] >= 0).sum())
+        most = max(most, parts)
+        if len(np.unique(segs)) > 1:
+            assert len(its) <= cap
+    assert np.all(seen_seg == 1) and np.all(cover == 1) and most == fl["max_parts"]
+
+
+def test_whole_segment_lists_of_the_two_launch_iteration():
+    """layout.hpp: FusedLists -- data with uneven degrees (the MovieLens-100k shape: few users with many ratings each,
+    popular items): every cut segment's pieces in ONE workgroup, pair side (64-pair units rebuilt with at most 64 work
+    items) and user side (workgroups of at most 64 / 32 items, a longer segment alone)."""
+    rng = np.random.default_rng(0)
+    n, u, i = 40_000, 400, 700
+    pu, pi = rng.lognormal(0, 0.8, u), rng.lognormal(0, 1.4, i)
+    data = np.stack([rng.choice(u, n, p=pu / pu.sum()), rng.choice(i, n, p=pi / pi.sum()), rng.integers(0, 5, n)], axis=1).astype(np.int64)
+    data[:200, 0] = 7                                                       # (a user with more pieces than a workgroup has groups)
+    for cap_u in (64, 32):
+        lay = build_layout(data, u, i, 5, fused_caps=(64, cap_u))
+        assert len(lay["pair_splits"]) > 0 and len(lay["user_splits"]) > 0
+        fp, fu = lay["fused_pairs"], lay["fused_users"]
+        assert fp["built"] and fu["built"]
+        _check_fused_lists(lay["pair_off"], lay["pair_items"], lay["pair_splits"], fp, 64)
+        _check_fused_lists(lay["user_off"], lay["user_items"], lay["user_splits"], fu, cap_u)
+        # the rebuilt units: rating-homogeneous, at most 64 pairs and 64 items, tiling every rating's pairs once,
+        # padded to a multiple of 8 per rating like the plain list; unit j of the lists is chunk j
+        ch = fp["chunks"]
+        assert len(ch) == len(fp["units"])
+        covered = np.zeros(len(lay["pair_item"]), dtype=int)
+        for (rr, qb, qe, _), (ib, ie, _, _) in zip(ch, fp["units"]):
+            assert lay["rating_off"][rr] <= qb <= qe <= lay["rating_off"][rr + 1] and qe - qb <= 64 and ie - ib <= 64
+            covered[qb:qe] += 1
+            segs = fp["items"][ib:ie, 0]
+            assert (len(segs) == 0 and qb == qe) or (segs.min() == qb and segs.max() == qe - 1)
+        assert np.all(covered == 1) and np.all(np.bincount(ch[:, 0], minlength=5) % 8 == 0)
+        assert len(ch) > len(lay["mv_chunks"]) - 8                           # (a few more units than the plain 64-pair list)
+    # a pair with more pieces than a unit may hold: the lists cannot be built (the data keeps the separate launches)
+    heavy = data.copy()
+    heavy[:6000, 1:] = (3, 2)
+    lay = build_layout(heavy, u, i, 5, fused_caps=(64, 64))
+    assert np.diff(lay["pair_off"]).max() >= 6000 and not lay["fused_pairs"]["built"]
+    # no segment cut: one whole item per segment
+    small = random_triples(rng, 3000, 300, 100, 4)
+    lay = build_layout(small, 300, 100, 4, fused_caps=(64, 64))
+    assert len(lay["pair_splits"]) == 0 and lay["fused_pairs"]["max_parts"] == 0 and len(lay["fused_pairs"]["splits"]) == 0
+    assert len(lay["fused_users"]["items"]) == 300 and np.all(lay["fused_users"]["items"][:, 3] == -1)
