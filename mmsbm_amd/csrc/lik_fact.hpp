@@ -237,4 +237,91 @@ __global__ __launch_bounds__(kLikWaveThreads) __attribute__((amdgpu_waves_per_eu
   }
 }
 
+// ======================================================================================
+// Rows of up to 32 groups (round 4; BASELINE's configs 1-4: K = L = 10, 20).  A wave per pair would leave most of its
+// lanes idle there (one column per lane), so here a LANE takes a triple -- every lane busy whatever L is -- and the
+// rating's tile comes through the scalar unit instead of theta:
+//   * the triple's theta row and its logarithms sit in registers (KP 16-byte loads in ONE burst from the table of
+//     (theta, log theta) pairs; likelihood_fast_kernel fetched them inside its row loop, two dependent loads per row:
+//     SQ_WAIT_ANY 66 % of the wave cycles at C3);
+//   * s_n = theta_n . A[q_n] from the A table of the iteration (K multiply-adds instead of K L additions), so that
+//     ls = log max(s, eps) is known BEFORE the elements are visited and the sum of the clamped omegas is not needed:
+//     an element is  max(omega, eps) * max(log omega - ls, log eps - ls);
+//   * the workgroup's triples share one rating, so (p_kl, log p_kl) is the same for every lane: scalar loads of
+//     contiguous (value, logarithm) pairs of the TRANSPOSED tile, operands of the vector instructions as SGPRs;
+//   * the item's (eta_l, log eta_l) pair is one 16-byte load per column, asked for a column ahead.
+// Seven vector instructions per element (multiply, multiply, max, add, add, max, fused multiply-add) against nine and
+// two LDS / scalar round trips.  Padded rows (theta = 0, log theta = -inf) each add exactly eps (log eps - ls) per
+// column and are taken off in closed form.
+// ======================================================================================
+template <int KP, int NT>
+__global__ __launch_bounds__(NT) void lik_lane_kernel(
+    const mmsbm::Chunk *__restrict__ units, const int32_t *__restrict__ pair_off,
+    const int32_t *__restrict__ pair_user, const int32_t *__restrict__ pair_item, const double2 *__restrict__ tl,
+    RowTab a_tab, const double2 *__restrict__ el, const double2 *__restrict__ ptl, double *__restrict__ block_out,
+    int k_groups, int l_groups, int lp) {
+  __shared__ int32_t poff[kUnitPairs + 4];
+  __shared__ double red[NT / 64];
+  const mmsbm::Chunk ch = units[blockIdx.x];
+  const int tid = threadIdx.x;
+  const int npairs = ch.q_end - ch.q_begin;
+  if (tid <= npairs) poff[tid] = pair_off[ch.q_begin + tid];
+  __syncthreads();
+  // (value, logarithm) pairs of the transposed tile of this rating: [l][k][2] doubles, uniform addresses
+  const const_f64_ptr tile = (const_f64_ptr)(reinterpret_cast<uintptr_t>(ptl + static_cast<size_t>(ch.rating) * lp * KP));
+  const double log_eps = log(kEps);
+  const int t0 = poff[0], t1 = poff[npairs];
+  double total = 0.0;
+  for (int base = t0; base < t1; base += NT) {
+    const int n = base + tid;
+    const bool have = n < t1;
+    const int nn = have ? n : t1 - 1;
+    int lo = 0, hi = npairs;  // pair of triple nn: last q with poff[q] <= nn
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (poff[mid] <= nn) lo = mid; else hi = mid;
+    }
+    const size_t urow = static_cast<size_t>(pair_user[nn]);
+    const size_t q = static_cast<size_t>(ch.q_begin + lo);
+    const double2 *__restrict__ erow = el + static_cast<size_t>(pair_item[q]) * lp;
+    double2 th[KP];
+#pragma unroll
+    for (int k = 0; k < KP; ++k) th[k] = tl[urow * KP + k];
+    double2 ev = erow[0];
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < KP; k += 2) {
+      const double2 av = *reinterpret_cast<const double2 *>(rowtab_ptr(a_tab, q, k));
+      s = fma(th[k].x, av.x, s);
+      s = fma(th[k + 1].x, av.y, s);
+    }
+    const double ls = log(fmax(s, kEps)), cl = log_eps - ls;
+#pragma unroll
+    for (int k = 0; k < KP; ++k) th[k].y -= ls;
+    double acc0 = 0.0, acc1 = 0.0;
+    for (int l = 0; l < l_groups; ++l) {
+      const double2 nxt = erow[min(l + 1, l_groups - 1)];
+      const const_f64_ptr tr = tile + static_cast<size_t>(l) * KP * 2;
+#pragma unroll
+      for (int k = 0; k < KP; k += 2) {
+        const double ep0 = ev.x * tr[2 * k], ep1 = ev.x * tr[2 * k + 2];
+        const double lw0 = (th[k].y + ev.y) + tr[2 * k + 1], lw1 = (th[k + 1].y + ev.y) + tr[2 * k + 3];
+        acc0 = fma(fmax(th[k].x * ep0, kEps), fmax(lw0, cl), acc0);
+        acc1 = fma(fmax(th[k + 1].x * ep1, kEps), fmax(lw1, cl), acc1);
+      }
+      ev = nxt;
+    }
+    if (have) total += (acc0 + acc1) - static_cast<double>((KP - k_groups) * l_groups) * (kEps * cl);
+  }
+  total = group_sum<64>(total);
+  if ((tid & 63) == 0) red[tid >> 6] = total;
+  __syncthreads();
+  if (tid == 0) {
+    double tot = 0.0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) tot += red[w];
+    block_out[blockIdx.x] = tot;
+  }
+}
+
 }  // namespace

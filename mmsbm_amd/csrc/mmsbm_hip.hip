@@ -737,6 +737,47 @@ int likelihood_pairs(mmsbm_hip_ctx *c) {
   return nb;
 }
 
+// ---- rows of up to 32 groups: a lane per triple, the tile through scalar loads (lik_fact.hpp: lik_lane_kernel) ----
+constexpr int kLikLaneThreads = 128;
+bool lik_lanes_usable(const mmsbm_hip_ctx *c) {
+  return c->lik_mode == 2 && c->kp <= 32 && c->lp <= 32 && c->n_lik_units > 0 && c->n_pairs > 0;
+}
+int likelihood_lanes(mmsbm_hip_ctx *c) {
+  ensure_a(c);  // (s_n = theta_n . A[q_n])
+  const int cur = c->cur, sl = c->sel;
+  hipStream_t st = c->stream;
+  const size_t nt = static_cast<size_t>(c->n_users) * c->kp, ne = static_cast<size_t>(c->n_items) * c->lp;
+  const size_t np = static_cast<size_t>(c->n_ratings) * c->kp * c->lp;
+  if (c->lg_theta.count < 2 * nt) c->lg_theta.alloc(2 * nt);  // (value, logarithm) pairs, plain rows
+  if (c->lg_eta.count < 2 * ne) c->lg_eta.alloc(2 * ne);
+  if (c->lg_p.count < 2 * np) c->lg_p.alloc(2 * np);
+  auto blocks = [](size_t n) { return static_cast<unsigned>((n + kBlock - 1) / kBlock); };
+  double2 *tl = reinterpret_cast<double2 *>(c->lg_theta.ptr), *el = reinterpret_cast<double2 *>(c->lg_eta.ptr);
+  double2 *ptl = reinterpret_cast<double2 *>(c->lg_p.ptr);
+  if (nt > 0) theta_log_pairs_kernel<<<blocks(nt), kBlock, 0, st>>>(theta_tab(c, cur), tl, static_cast<size_t>(c->n_users), c->kp);
+  if (ne > 0) theta_log_pairs_kernel<<<blocks(ne), kBlock, 0, st>>>(plain_tab(c->eta[cur].at(sl), c->lp), el, static_cast<size_t>(c->n_items), c->lp);
+  theta_log_pairs_kernel<<<blocks(np), kBlock, 0, st>>>(plain_tab(c->pt[cur].at(sl), c->kp), ptl,
+                                                         static_cast<size_t>(c->n_ratings) * c->lp, c->kp);   // pT: [R][lp][kp]
+  const int nb = c->n_lik_units;
+  if (c->lik_part.count < static_cast<size_t>(nb)) c->lik_part.alloc(static_cast<size_t>(nb));
+#define LANE_GO(KP_)                                                                                          \
+  lik_lane_kernel<KP_, kLikLaneThreads><<<nb, kLikLaneThreads, 0, st>>>(                                      \
+      c->lik_units.ptr, c->pair_off.ptr, c->pair_user.ptr, c->pair_item.ptr, tl, a_tab(c, cur), el, ptl,     \
+      c->lik_part.ptr, c->k, c->l, c->lp)
+  switch (c->kp) {
+    case 4: LANE_GO(4); break;
+    case 8: LANE_GO(8); break;
+    case 12: LANE_GO(12); break;
+    case 16: LANE_GO(16); break;
+    case 20: LANE_GO(20); break;
+    case 24: LANE_GO(24); break;
+    case 28: LANE_GO(28); break;
+    default: LANE_GO(32); break;
+  }
+#undef LANE_GO
+  return nb;
+}
+
 // likelihood of the selected slot (the caller holds a OneSlot): kernels onto the context's stream, no wait;
 // returns the number of partial sums likelihood_finish adds up
 int likelihood_enqueue(mmsbm_hip_ctx *ctx) {
@@ -744,6 +785,8 @@ int likelihood_enqueue(mmsbm_hip_ctx *ctx) {
   int nb;
   if (lik_pairs_usable(ctx)) {
     nb = likelihood_pairs(ctx);
+  } else if (lik_lanes_usable(ctx)) {
+    nb = likelihood_lanes(ctx);
   } else if (lik_fast_usable(ctx)) {
     nb = likelihood_fast(ctx);
   } else {
