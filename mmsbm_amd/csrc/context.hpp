@@ -177,6 +177,7 @@ struct mmsbm_hip_ctx {
   bool mfma = false;    // both pair-stage launches run pair_mfma_kernel (tiles beyond the scalar cache, K, L <= 64)
   size_t lds_mt = 0, lds_ma = 0;
   int mfma_threads = kPairBlockMax;  // T+S launch: 512 (eight waves) or 256
+  int mfma_blocks = 1;  // option "mfma_blocks": 4- and 8-wide remainders of a tile side as 4 x 4 blocks (v_mfma_f64_4x4x4_4b_f64): 1 in the A launch, 2 in the T + S launch too (slower: registers), 0: padded 16-tiles
   bool mfma_big = false;  // K or L beyond 64: the blocked forms (mfma_rows_kernel + mfma_slab_kernel)
   bool wide = false;    // K, L beyond the LDS stage: wide_matvec / wide_slab kernels (any size)
   int nt_out = 7;          // option "nt_out" (bits: 1 T and A rows, 2 theta' rows as non-temporal stores, 4 the segments' own rows as non-temporal loads) where that pays (nt_on, stages.hpp)

@@ -1250,6 +1250,9 @@ int mmsbm_hip_set_option(mmsbm_hip_ctx *ctx, const char *name, double value) {
     } else if (key == "mfma_threads") {
       if (value != kBlock && value != kPairBlockMax) throw std::invalid_argument("mfma_threads: 256 or 512");
       ctx->mfma_threads = static_cast<int>(value);
+    } else if (key == "mfma_blocks") {  // 0: remainders of 4 or 8 groups as padded 16-tiles (the form before round 4)
+      if (value != 0.0 && value != 1.0 && value != 2.0) throw std::invalid_argument("mfma_blocks: 0, 1 or 2");
+      ctx->mfma_blocks = static_cast<int>(value);
     } else if (key == "mfma") {  // the pair stage on the matrix cores: 0 off, 1 on (one-block form if K, L <= 64,
                                  // else the blocked form), 2 the blocked form whatever the shape
       ctx->mfma = value == 1.0 && mfma_possible(ctx);
@@ -1270,6 +1273,7 @@ int mmsbm_hip_get_option(const mmsbm_hip_ctx *ctx, const char *name, double *val
     else if (key == "quad") *value = ctx->quad_a;
     else if (key == "mfma") *value = ctx->mfma ? 1.0 : (ctx->mfma_big ? 2.0 : 0.0);
     else if (key == "mfma_threads") *value = ctx->mfma_threads;
+    else if (key == "mfma_blocks") *value = ctx->mfma_blocks;
     else if (key == "predict_fast") *value = ctx->predict_fast;
     else if (key == "seg_batch") *value = ctx->seg_batch;
     else if (key == "fused") *value = ctx->fused;

@@ -53,6 +53,7 @@ struct PairBlockArgs {
   int out_mw, out_rs_m, out_rs_t;
   double *out_tail;
   size_t bs_tiles, bs_in, bs_e, bs_out, bs_out_t, bs_partial;  // restart slots (blockIdx.y): offsets
+  int mg0, mg1;  // pair_mfma_kernel: tiles and 4 x 4 blocks of this launch's product (pair_big.hpp: mfma_geometry)
 };
 // element j (a multiple of 2) of output row q
 __device__ __forceinline__ double *pair_out_ptr(const PairBlockArgs &pa, double *out, double *out_tail,

@@ -119,6 +119,7 @@ PairBlockArgs pair_block_t_args(const mmsbm_hip_ctx *c) {
   pa.out_mw = c->lp; pa.out_rs_m = c->lp; pa.out_rs_t = 0; pa.out_tail = c->ttab.at(s);
   pa.bs_tiles = c->p[0].stride; pa.bs_in = c->ctab.stride; pa.bs_e = c->eta[0].stride;
   pa.bs_out = c->ttab.stride; pa.bs_out_t = 0; pa.bs_partial = c->partial.stride;
+  mfma_geometry(pa.dinp, pa.doutp, true, c->mfma_threads / 64, c->mfma_blocks == 2, &pa.mg0, &pa.mg1);
   return pa;
 }
 PairBlockArgs pair_block_a_args(const mmsbm_hip_ctx *c, int param_slot, int a_slot) {
@@ -133,6 +134,7 @@ PairBlockArgs pair_block_a_args(const mmsbm_hip_ctx *c, int param_slot, int a_sl
   pa.out_mw = at.mw; pa.out_rs_m = at.rs_m; pa.out_rs_t = at.rs_t; pa.out_tail = at.tail;
   pa.bs_tiles = c->pt[0].stride; pa.bs_in = c->eta[0].stride; pa.bs_e = 0;
   pa.bs_out = at.so_m; pa.bs_out_t = at.so_t; pa.bs_partial = 0;
+  mfma_geometry(pa.dinp, pa.doutp, false, 4, c->mfma_blocks != 0, &pa.mg0, &pa.mg1);
   return pa;
 }
 EtaPArgs eta_p_args(const mmsbm_hip_ctx *c, bool commit, int cols_per_block) {
@@ -290,13 +292,17 @@ void stage_dense(mmsbm_hip_ctx *c) {  // T = P^T C  and the K x L slabs for p
     LaunchScope ls(c, K_DENSE, true);
     const int nb = static_cast<int>(c->lay.mv_chunks.size());
     const PairBlockArgs pa = pair_block_t_args(c);
-    if (c->mfma_threads == kBlock) {
-      allow_big_lds(pair_mfma_kernel<false, true, kBlock>, c->lds_mt);
-      LAUNCH_IN(ls, (pair_mfma_kernel<false, true, kBlock>), slot_grid(c, nb), kBlock, c->lds_mt, c->stream, pa, pa.tiles);
-    } else {
-      allow_big_lds(pair_mfma_kernel<false, true, kPairBlockMax>, c->lds_mt);
-      LAUNCH_IN(ls, (pair_mfma_kernel<false, true, kPairBlockMax>), slot_grid(c, nb), kPairBlockMax, c->lds_mt, c->stream, pa, pa.tiles);
-    }
+    // (4 x 4 blocks in the T + S launch only on request, option mfma_blocks = 2: its 128-register budget does not hold
+    // them -- C5 355 -> 390 us -- so its remainders stay padded tiles; the A launch has the room, see stage_matvec_a)
+#define MF_TS(NT_, BLK_)                                                                          \
+  do {                                                                                            \
+    allow_big_lds(pair_mfma_kernel<false, true, NT_, BLK_>, c->lds_mt);                           \
+    LAUNCH_IN(ls, (pair_mfma_kernel<false, true, NT_, BLK_>), slot_grid(c, nb), NT_, c->lds_mt, c->stream, pa, pa.tiles); \
+  } while (0)
+    const bool blk = c->mfma_blocks == 2;
+    if (c->mfma_threads == kBlock) { if (blk) MF_TS(kBlock, true); else MF_TS(kBlock, false); }
+    else { if (blk) MF_TS(kPairBlockMax, true); else MF_TS(kPairBlockMax, false); }
+#undef MF_TS
     ls.done();
     return;
   }
@@ -372,8 +378,13 @@ void stage_matvec_a(mmsbm_hip_ctx *c, int slot, int a_slot, bool grid = false) {
     allow_big_lds(wide_matvec_kernel<true>, lds);
     LAUNCH_IN(ls, (wide_matvec_kernel<true>), slot_grid(c, nb * subs), kBlock, lds, c->stream, pa, subs);
   } else if (c->mfma) {
-    allow_big_lds(pair_mfma_kernel<true, false, kBlock>, c->lds_ma);
-    LAUNCH_IN(ls, (pair_mfma_kernel<true, false, kBlock>), slot_grid(c, nb), kBlock, c->lds_ma, c->stream, pa, pa.tiles);
+    if (c->mfma_blocks) {
+      allow_big_lds(pair_mfma_kernel<true, false, kBlock, true>, c->lds_ma);
+      LAUNCH_IN(ls, (pair_mfma_kernel<true, false, kBlock, true>), slot_grid(c, nb), kBlock, c->lds_ma, c->stream, pa, pa.tiles);
+    } else {
+      allow_big_lds(pair_mfma_kernel<true, false, kBlock, false>, c->lds_ma);
+      LAUNCH_IN(ls, (pair_mfma_kernel<true, false, kBlock, false>), slot_grid(c, nb), kBlock, c->lds_ma, c->stream, pa, pa.tiles);
+    }
   } else if (c->quad_a) {
     const dim3 grid = slot_grid(c, std::min(nb, c->n_cus));
 #define QA(NL)                                                                                    \

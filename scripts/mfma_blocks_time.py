@@ -1,0 +1,36 @@
+"""Round 4: 4- and 8-wide remainders of a tile side as 4 x 4 blocks (v_mfma_f64_4x4x4_4b_f64) against padded 16-tiles:
+stage and iteration times.   usage: mfma_blocks_time.py <config|K,L>"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+from mmsbm_amd import MMSBM
+from mmsbm_amd.synthetic import CONFIGS, synthetic_triples
+
+arg = sys.argv[1] if len(sys.argv) > 1 else "c5"
+if arg in CONFIGS:
+    n, u, i, r, k, l = CONFIGS[arg]
+else:
+    k, l = (int(x) for x in arg.split(","))
+    n, u, i, r = 4_000_000, 400_000, 50_000, 8
+train = synthetic_triples(n, u, i, r, 0)
+mm = MMSBM(k, l, iterations=1, seed=0)
+mm._prepare_objects(train)
+ctx = mm._ctx(0)
+d_u, d_i = ctx.degrees()
+start = mm.init_params(mm.child_states[0], d_u, d_i)
+outs = []
+for blocks in (1, 0, 2, 1, 0):
+    ctx.set_option("mfma_blocks", blocks)
+    ctx.set_params(*start)
+    ctx.iterate(3)
+    outs.append(ctx.get_params())
+    ctx.iterate(10)
+    reps = 30
+    it = min(ctx.time_iterations(reps) for _ in range(3)) * 1000 / reps
+    st = [min(ctx.time_stage(s, 10) for _ in range(2)) for s in range(4)]
+    print(f"K={k} L={l} mfma_blocks={blocks}: iteration {it:8.2f} us   stages " + "  ".join(f"{x:7.2f}" for x in st), flush=True)
+err = max(float(np.max(np.abs(a - b) / np.maximum(np.abs(a), 1e-300))) for a, b in zip(outs[0], outs[1]))
+print("max relative difference between the two forms after 3 iterations:", err)
