@@ -139,6 +139,11 @@ struct mmsbm_hip_ctx {
   hipStream_t stream = nullptr;
   hipStream_t copy_stream = nullptr;  // parameter downloads that overlap kernels of `stream` (mmsbm_hip_result)
   hipStream_t xfer = nullptr;         // when set: the stream copy_rows / fetch_params use instead of `stream`
+  // Experiment (round 4, option "fork" = 1; slower at every size measured, stages.hpp: use_fork): the user pass of an
+  // iteration needs nothing of its dense chain (T + S, eta_p, the A launch) and can run beside it on a second stream.
+  hipStream_t side_stream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  int fork = 0;
   bool swapped = false;
   // external dims
   int64_t n_obs = 0;
@@ -231,6 +236,9 @@ struct mmsbm_hip_ctx {
       (void)hipEventDestroy(pe.second.first);
       (void)hipEventDestroy(pe.second.second);
     }
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_join) (void)hipEventDestroy(ev_join);
+    if (side_stream) (void)hipStreamDestroy(side_stream);
     if (copy_stream) (void)hipStreamDestroy(copy_stream);
     if (stream) (void)hipStreamDestroy(stream);
   }

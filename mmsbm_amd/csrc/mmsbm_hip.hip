@@ -1250,6 +1250,9 @@ int mmsbm_hip_set_option(mmsbm_hip_ctx *ctx, const char *name, double value) {
     } else if (key == "mfma_threads") {
       if (value != kBlock && value != kPairBlockMax) throw std::invalid_argument("mfma_threads: 256 or 512");
       ctx->mfma_threads = static_cast<int>(value);
+    } else if (key == "fork") {  // experiment: the user pass beside the dense chain on a second stream (0 / 1)
+      if (value != 0.0 && value != 1.0) throw std::invalid_argument("fork: 0 or 1");
+      ctx->fork = static_cast<int>(value);
     } else if (key == "mfma_blocks") {  // 0: remainders of 4 or 8 groups as padded 16-tiles (the form before round 4)
       if (value != 0.0 && value != 1.0 && value != 2.0) throw std::invalid_argument("mfma_blocks: 0, 1 or 2");
       ctx->mfma_blocks = static_cast<int>(value);
@@ -1274,6 +1277,8 @@ int mmsbm_hip_get_option(const mmsbm_hip_ctx *ctx, const char *name, double *val
     else if (key == "mfma") *value = ctx->mfma ? 1.0 : (ctx->mfma_big ? 2.0 : 0.0);
     else if (key == "mfma_threads") *value = ctx->mfma_threads;
     else if (key == "mfma_blocks") *value = ctx->mfma_blocks;
+    else if (key == "fork") *value = ctx->fork;
+    else if (key == "forked") *value = use_fork(ctx) && !use_fused(ctx) ? 1.0 : 0.0;  // read-only: what the next iteration does
     else if (key == "predict_fast") *value = ctx->predict_fast;
     else if (key == "seg_batch") *value = ctx->seg_batch;
     else if (key == "fused") *value = ctx->fused;

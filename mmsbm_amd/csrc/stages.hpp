@@ -515,6 +515,15 @@ bool use_fused(const mmsbm_hip_ctx *c) {
   return c->fused && fused_possible(c) && (c->fused_forced || c->n_obs * c->launch_slots * (c->kp + c->lp) <= kFusedWorkMax);
 }
 
+// The user pass beside the dense chain (second stream) -- an experiment that lost at every size (round 4, per iteration,
+// serial / forked, scripts/fork_time.py: C3 94.4 / 107.7 us, 3M ratings K = L = 20 296.9 / 316.0, 4M K = L = 50 910.7 /
+// 928.6, 10M K = L = 20 554.4 / 677.8, 20M x 138k x 27k 878 / 1,059, C5 2,228 / 2,328): two gather launches instead of
+// one (each with its ramp and drain, and the XCD-local lists of the two passes no longer share a grid), and a dense
+// chain that is slower, not faster, with gathers beside it.  Off unless option "fork" = 1 asks for it.
+bool use_fork(const mmsbm_hip_ctx *c) {
+  return c->fork == 1 && !c->profiling && !c->graph_mode;
+}
+
 void launch_iteration(mmsbm_hip_ctx *c, bool commit) {
   if (use_fused(c)) {
     stage_fused_pairs(c);  // (writes A of the current parameters on its way)
@@ -524,6 +533,28 @@ void launch_iteration(mmsbm_hip_ctx *c, bool commit) {
     return;
   }
   ensure_a(c);
+  if (commit && use_fork(c)) {
+    // pair pass -> T + S -> eta_p -> A on the context's stream; the user pass (theta' from theta, A of the CURRENT
+    // parameters: nothing the chain writes) on the side stream, between two events.  The next iteration -- or whatever
+    // the caller enqueues next -- waits for both.
+    if (!c->side_stream) {
+      HIP_CHECK(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+      HIP_CHECK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+      HIP_CHECK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    }
+    HIP_CHECK(hipEventRecord(c->ev_fork, c->stream));       // everything before this iteration is done
+    HIP_CHECK(hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
+    stage_seg(c, commit, true, false, c->stream);
+    stage_seg(c, commit, false, true, c->side_stream);
+    HIP_CHECK(hipEventRecord(c->ev_join, c->side_stream));
+    stage_dense(c);
+    stage_eta_p(c, commit);
+    stage_matvec_a(c, c->cur ^ 1, c->cur ^ 1);
+    HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    c->cur ^= 1;
+    mark_a(c, true);
+    return;
+  }
   stage_seg(c, commit, true, true, c->stream);
   stage_dense(c);
   stage_eta_p(c, commit);
