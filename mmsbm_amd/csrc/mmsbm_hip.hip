@@ -355,7 +355,9 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
       }
       if (!c->lay.user_work.splits.empty()) {
         const mmsbm::SegPieces sp = mmsbm::segment_pieces(c->lay.user_off, c->lay.user_work);
-        const mmsbm::FusedLists fl = mmsbm::build_fused_users(sp, kBlock / lanes);
+        int ucap = kBlock / lanes;  // work items per workgroup: one round of its groups of lanes
+        if (const char *e = std::getenv("MMSBM_HIP_FUSED_UCAP")) ucap = std::max(1, std::atoi(e));  // (tuning)
+        const mmsbm::FusedLists fl = mmsbm::build_fused_users(sp, ucap);
         if (static_cast<size_t>(fl.max_parts) * c->kp * sizeof(double) <= kFusedSplitLds) {
           c->fu_units.upload(fl.units, c->stream); c->fu_items.upload(fl.items, c->stream);
           c->fu_splits.upload(fl.splits, c->stream);

@@ -27,7 +27,13 @@ while time.time() - t0 < budget:
         k, l = (int(rng.integers(200, 1300)), int(rng.integers(1, 6)))[:: 1 if rng.random() < 0.5 else -1]
     n_u, n_i, n_r = int(rng.integers(1, 400)), int(rng.integers(1, 200)), int(rng.integers(1, 9))
     n = int(rng.integers(1, 6000)) if k * l < 4000 else int(rng.integers(1, 600))
-    if rng.random() < 0.3:   # skewed degrees
+    shape = rng.random()
+    if shape < 0.25 and k * l <= 700:   # few busy users, popular items (the MovieLens-100k shape in small): segments cut into
+        n = int(rng.integers(3000, 30000))   # pieces on both sides -- whole-segment lists of the two-launch form (round 4)
+        n_u, n_i = int(rng.integers(20, 400)), int(rng.integers(20, 600))
+        pu, pi = rng.lognormal(0, rng.uniform(0.3, 1.5), n_u), rng.lognormal(0, rng.uniform(0.3, 2.0), n_i)
+        u_col, i_col = rng.choice(n_u, n, p=pu / pu.sum()), rng.choice(n_i, n, p=pi / pi.sum())
+    elif shape < 0.5:   # skewed degrees
         u_col = (rng.zipf(1.3, n) - 1) % n_u
         i_col = (rng.zipf(1.3, n) - 1) % n_i
     else:
@@ -45,8 +51,8 @@ while time.time() - t0 < budget:
     lik = float(orc.compute_likelihood(data, t, e, p))
     tag = f"K={k} L={l} N={n} U={n_u} I={n_i} R={n_r} slots={slots} swap={swap} iters={iters}"
     with HipEM(data, k, l, n_u, n_i, n_r, slots=slots, swap_sides=swap) as em:
-        fused = em.get_option("fused")
-        if fused and rng.random() < 0.3:
+        fused = em.get_option("fused") + 10 * em.get_option("fused_split")
+        if em.get_option("fused") and rng.random() < 0.3:
             em.set_option("fused", 0)
         if em.get_option("mfma") and rng.random() < 0.2:
             em.set_option("mfma", 0)

@@ -20,7 +20,8 @@ def short(name):
                     # (K x L > 1024: the same two launches run pair_mfma_kernel; full_name keeps the kernel's own name)
                     ("pair_mfma_kernel<false", "pair_block_kernel(T+S)"), ("pair_mfma_kernel<true", "pair_block_kernel(A)"),
                     ("eta_p_kernel", "eta_p_kernel"), ("pairs_fused_kernel", "pairs_fused_kernel"), ("tail_fused_kernel", "tail_fused_kernel"),
-                    ("lik_wave_kernel", "lik_wave_kernel"), ("theta_log_pairs_kernel", "theta_log_pairs_kernel"),
+                    ("lik_wave_kernel", "lik_wave_kernel"), ("lik_lane_kernel", "lik_lane_kernel"),
+                    ("seg_combine_both_kernel", "seg_combine_both_kernel"), ("theta_log_pairs_kernel", "theta_log_pairs_kernel"),
                     ("seg_combine_small_kernel", "seg_combine_small_kernel"),
                     ("seg_combine_kernel", "seg_combine_kernel"), ("likelihood_fast_kernel", "likelihood_fast_kernel"), ("log_table_kernel", "log_table_kernel"),
                     ("init_rows_kernel", "init_rows_kernel"), ("likelihood_units_kernel", "likelihood_units_kernel"),
