@@ -5,7 +5,8 @@
         examples/fit_multi_gpu.py --sampling 8 --iterations 400
 
 Restart i runs on rank i mod W (no collective on the data path); one all-reduce over RCCL at the
-end tells every rank all likelihoods, i.e. the maximum-likelihood restart.  The reference's predict
+end tells every rank all likelihoods, i.e. the maximum-likelihood restart, whose theta / eta / pr are
+then broadcast from the rank that ran it as three tensors (model.best_result).  The reference's predict
 averages over ALL restarts: every rank scores its own on its GPU and one more all-reduce (SUM of the
 (M, R) matrix) makes the mean -- the restarts' parameters never leave the rank that computed them."""
 import argparse
@@ -36,13 +37,14 @@ def main():
     rank, world, local, device = restarts.init_from_env(args.dist_backend)
     train = synthetic_triples(args.ratings, args.ratings // 10, args.ratings // 50, 5, seed=0)
     model = MMSBM(args.groups, args.groups, iterations=args.iterations, sampling=args.sampling, seed=0)
-    best, best_lik, liks = restarts.fit_distributed(model, train, gather=False, device=device)
+    best, best_lik, liks = restarts.fit_distributed(model, train, device=device)   # (gather=False is the default)
     test = synthetic_triples(max(args.ratings // 10, 1), args.ratings // 10, args.ratings // 50, 5, seed=1)
     matrix = restarts.predict_distributed(model, test, device=device)      # mean over all restarts, every rank
     stats = model.score(silent=True)["stats"]
     if rank == 0:
         print(f"{world} rank(s), {args.sampling} restarts: likelihoods {np.round(liks, 3).tolist()}")
-        print(f"maximum-likelihood restart: {best} ({best_lik:.3f}); this rank kept {len(model.results)} of them")
+        print(f"maximum-likelihood restart: {best} ({best_lik:.3f}); this rank ran {len(model.results)} of them and holds the "
+              f"winner's theta {model.best_result['theta'].shape}")
         print(f"prediction over all restarts: {matrix.shape[0]} rows, accuracy {stats['accuracy']:.4f}, mae {stats['mae']:.4f}")
     if world > 1:
         import torch.distributed as dist
