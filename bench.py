@@ -412,8 +412,11 @@ def main():
     # warmup + steps iterations, BEFORE the steady-state loop below advances them further
     coll_error = None
     if world == 1 and not args.no_collective_at_1:
-        try:    # (process-group start-up is not part of `job` at any N: for N > 1 it happened before the job began)
+        try:    # (process-group start-up is not part of `job` at any N: for N > 1 it happened before the job began --
+            # the fence's barrier is the group's first collective and builds the RCCL communicator, 0.85 s; here the
+            # same is done by one throw-away all-reduce)
             restarts.init_from_env(args.dist_backend, force_init=True)
+            restarts.all_likelihoods({0: 0.0}, 1, device)
         except Exception as exc:  # a one-rank group is a nicety: report without it rather than not at all
             coll_error = f"{type(exc).__name__}: {exc}"
     t_job = time.perf_counter()
