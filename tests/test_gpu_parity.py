@@ -225,6 +225,42 @@ def test_host_class_reference_end_to_end_case(hip):
     assert set(sc["objects"]["pr"].keys()) == {"1", "2", "3", "4", "5"}
 
 
+def test_host_class_on_a_rating_table_with_string_ids_and_uneven_degrees(hip):
+    """The reference's front door on data shaped like a real rating table (src/data_handler.py:27-61 into the loop at
+    src/mmsbm.py:243-256): string user / item ids, a few busy users, popular items -- long segments on both sides, which
+    the library cuts into pieces and (round 4) still runs as two launches per iteration.  fit -> every restart against
+    the oracle's run of the same child seed on the encoded triples; predict -> the oracle's mean distribution and its
+    argmax; the context really ran the whole-segment form."""
+    import pandas as pd
+    rng = np.random.default_rng(5)
+    n, n_u, n_i = 20_000, 150, 260
+    pu, pi = rng.lognormal(0, 0.9, n_u), rng.lognormal(0, 1.3, n_i)
+    df = pd.DataFrame({"users": [f"u{x:03d}" for x in rng.choice(n_u, n, p=pu / pu.sum())],
+                       "items": [f"film-{x}" for x in rng.choice(n_i, n, p=pi / pi.sum())],
+                       "ratings": rng.integers(1, 6, n)})
+    test_df = df.sample(2000, random_state=1)
+    mm = hip.MMSBM(6, 7, iterations=40, sampling=2, seed=3, backend="hip")
+    mm.fit(df, silent=True)
+    ctx = mm._ctx(0)
+    assert ctx.get_option("splits_pairs") > 0 and ctx.get_option("splits_users") > 0
+    assert ctx.get_option("fused_split") == 3.0 and ctx.get_option("launches") == 2.0
+    train = mm.train
+    want = orc.fit(train, 6, 7, iterations=40, sampling=2, seed=3)
+    for got, w in zip(mm.results, want):
+        for nm in ("theta", "eta", "pr"):
+            assert rel_err(got[nm], w[nm]) < TOL_LOOP, nm
+            assert_elementwise(got[nm], w[nm], nm)
+        assert float(got["likelihood"]) == pytest.approx(float(w["likelihood"]), rel=1e-10)
+    pm = mm.predict(test_df)
+    test = mm.test
+    ref = np.mean([orc.prod_dist(test, w["theta"], w["eta"], w["pr"]) for w in want], axis=0)
+    assert np.allclose(pm, ref, rtol=1e-9, atol=1e-300)
+    srt = np.sort(ref, axis=1)
+    clear = srt[:, -1] - srt[:, -2] > 1e-9
+    assert clear.mean() > 0.99 and np.array_equal(np.argmax(pm, 1)[clear], np.argmax(ref, 1)[clear])
+    mm._release()
+
+
 def test_host_class_sampling3_matches_reference(hip):
     g = load_golden("g2_c1_sampling3")
     mm = hip.MMSBM(2, 2, iterations=10, sampling=3, seed=1, backend="auto")
