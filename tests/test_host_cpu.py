@@ -269,6 +269,63 @@ def test_four_rank_gloo_more_ranks_than_restarts(tmp_path, gather):
         assert f"rank {rank} ok" in out
 
 
+EIGHT_WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+    import numpy as np
+    import torch.distributed as dist
+    import fake_device
+    from mmsbm_amd import restarts, mmsbm as host
+    from conftest import load_golden
+    from oracle import mmsbm_oracle as orc
+
+    host.HipEM = fake_device.FakeHipEM                  # the oracle behind the device interface
+    host.load_backend = lambda name: (None, None, None, "hip")
+    restarts.check_single_hip_runtime = lambda: None
+    rank, world, local, device = restarts.init_from_env("gloo")
+    assert world == 8
+    g = load_golden("g2_c1_sampling3")
+    train, test = g["train"], g["train"][::3]
+    model = host.MMSBM(2, 2, iterations=10, sampling=8, seed=1)
+    best, best_lik, liks = restarts.fit_distributed(model, train, device=device)
+    assert list(model._restart_ids) == [rank] and len(model.results) == 1     # one restart per rank, nothing gathered
+    want = orc.fit(train, 2, 2, iterations=10, sampling=8, seed=1)             # the same eight restarts in one process
+    assert np.array_equal(liks, np.array([w["likelihood"] for w in want]))
+    assert np.array_equal(liks[:3], g["likelihoods"])                          # restart i does not depend on `sampling`
+    assert best == int(np.argmax(liks)) and best_lik == liks[best]
+    for key in ("theta", "eta", "pr"):                                         # the winner, on every rank
+        assert np.array_equal(model.best_result[key], want[best][key]), key
+    assert np.array_equal(model.results[0]["theta"], want[rank]["theta"])
+    matrix = restarts.predict_distributed(model, test, device=device)
+    ref = np.mean([orc.prod_dist(test, w["theta"], w["eta"], w["pr"]) for w in want], axis=0)
+    assert np.allclose(matrix, ref, rtol=1e-13, atol=0), np.max(np.abs(matrix - ref))
+    assert len(model.run_stats) == 8
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank", rank, "ok")
+""")
+
+
+def test_eight_rank_gloo_one_restart_per_rank(tmp_path):
+    """BASELINE's configs 3 and 4 are `sampling = 8` with ONE restart per GPU.  The same job shape on eight gloo ranks
+    (the oracle behind the device interface): every rank runs its restart, one all-reduce gives everyone all eight
+    likelihoods, the winner's parameters arrive by tensor broadcast, predict averages over all eight with one
+    all-reduce -- equal to the eight restarts run in one process."""
+    script = tmp_path / "eight_worker.py"
+    script.write_text(EIGHT_WORKER.format(root=ROOT))
+    port = _free_port()
+    procs = []
+    for rank in range(8):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="8", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, out[-3000:]
+        assert f"rank {rank} ok" in out
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
