@@ -509,10 +509,16 @@ void mark_a(mmsbm_hip_ctx *c, bool ok) {
 // 43.5; K = L = 16: 400k 36.0 / 41.7; K = L = 20: 100k 28.4 / 37.6, 300k 50.1 / 50.1, 600k 69.4 / 67.5, 1M 105.0 / 95.6.  100k ratings at K = L = 10
 // with 2 / 4 / 8 / 16 slots: 26.5 / 32.4, 40.9 / 42.8, 68.0 / 64.9, 119.9 / 115.9 -- with several slots the four-launch
 // form shares the index stream among them)
-constexpr long long kFusedWorkMax = 14000000, kFusedRatingsMax = 1500000;
+// Data whose segments are cut into pieces pays a combine launch in the separate form (five launches): there the two
+// launches win a little further out (log-normal popularity, separate / two, scripts/fused_split_sweep.py: 400k ratings
+// K = L = 10 38.4 / 31.3 us, 700k 43.8 / 39.8; 300k K = L = 20 45.1 / 41.4, 600k 54.0 / 65.5; 1M x 100k x 20k K = L = 10
+// 77.3 / 92.6) -- up to 18M.
+constexpr long long kFusedWorkMax = 14000000, kFusedWorkMaxSplit = 18000000, kFusedRatingsMax = 1500000;
 bool use_fused(const mmsbm_hip_ctx *c) {
   // (fused_possible again: options set after create() -- "mfma", "direct" ... -- change what it depends on)
-  return c->fused && fused_possible(c) && (c->fused_forced || c->n_obs * c->launch_slots * (c->kp + c->lp) <= kFusedWorkMax);
+  const bool cut = !c->lay.pair_work.splits.empty() || !c->lay.user_work.splits.empty();
+  return c->fused && fused_possible(c) &&
+         (c->fused_forced || c->n_obs * c->launch_slots * (c->kp + c->lp) <= (cut ? kFusedWorkMaxSplit : kFusedWorkMax));
 }
 
 // The user pass beside the dense chain (second stream) -- an experiment that lost at every size (round 4, per iteration,
