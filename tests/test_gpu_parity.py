@@ -430,7 +430,7 @@ def test_launch_modes_give_identical_results(hip, slots):
             assert np.array_equal(a, b)
 
 
-@pytest.mark.parametrize("shape", ["c1", "g4", "k20", "k12x24", "ragged", "busy", "c2", "ml10", "ml20", "bigsplit"])
+@pytest.mark.parametrize("shape", ["c1", "g4", "k20", "k12x24", "ragged", "busy", "c2", "ml10", "ml20", "bigsplit", "pairsplit"])
 def test_two_launch_iteration_is_bitwise_the_four_launch_one(hip, shape):
     """fused_small.hpp: for small problems an iteration is pairs_fused_kernel (A, the pair pass and T + S
     of a 64-pair unit in one workgroup, C never leaving LDS) + tail_fused_kernel (user pass || p_update ||
@@ -466,6 +466,12 @@ def test_two_launch_iteration_is_bitwise_the_four_launch_one(hip, shape):
             data = np.stack([u_col, np.where(hot, 2, rng.integers(0, 400, n)), np.where(hot, 1, rng.integers(0, 5, n))],
                             axis=1).astype(np.int64)
             k, l = 7, 13
+        elif shape == "pairsplit":  # popular items among many ordinary users: only the PAIR side has cut segments
+            n = 20_000
+            pi = rng.lognormal(0, 2.0, 150)
+            data = np.stack([rng.integers(0, 4_000, n), rng.choice(150, n, p=pi / pi.sum()), rng.integers(0, 3, n)],
+                            axis=1).astype(np.int64)
+            k, l = 10, 6
         elif shape == "busy":     # 20 users with 50 ratings each among 780 with ~11: segments of two steps of rows in flight
             u_col = np.concatenate([np.repeat(np.arange(20), 50), rng.integers(20, 800, 8_600)])
             data = np.stack([u_col, rng.integers(0, 300, u_col.size), rng.integers(0, 4, u_col.size)], axis=1).astype(np.int64)
@@ -484,6 +490,9 @@ def test_two_launch_iteration_is_bitwise_the_four_launch_one(hip, shape):
                 if shape in ("ml10", "ml20", "bigsplit"):
                     assert em.get_option("splits_pairs") > 0 and em.get_option("splits_users") > 0
                     assert em.get_option("fused_split") == 3.0 and em.get_option("launches") == 2.0
+                if shape == "pairsplit":
+                    assert em.get_option("splits_pairs") + em.get_option("splits_users") > 0
+                    assert em.get_option("fused_split") in (1.0, 2.0) and em.get_option("launches") == 2.0
             em.set_option("fused", fused)
             em.select(0).set_params(*start)
             em.select(1).set_params(start[0] * 0.5 + 0.01, start[1], start[2])
