@@ -299,15 +299,33 @@ __global__ __launch_bounds__(NT) void lik_lane_kernel(
 #pragma unroll
     for (int k = 0; k < KP; ++k) th[k].y -= ls;
     double acc0 = 0.0, acc1 = 0.0;
+    // The tile row of column l is KP (value, logarithm) pairs = KP / 4 scalar loads of four pairs; rows follow each
+    // other in memory, so the chunk after the current one is always 8 doubles further on.  It is asked for BEFORE the
+    // current chunk is multiplied (two sets of scalar registers): with one set the compiler put every load right in
+    // front of its use and every chunk waited out a scalar-cache round trip (5 per column at K = 20: more stall than work).
+    double tc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) tc[j] = tile[j];
     for (int l = 0; l < l_groups; ++l) {
       const double2 nxt = erow[min(l + 1, l_groups - 1)];
       const const_f64_ptr tr = tile + static_cast<size_t>(l) * KP * 2;
 #pragma unroll
-      for (int k = 0; k < KP; k += 2) {
-        const double ep0 = ev.x * tr[2 * k], ep1 = ev.x * tr[2 * k + 2];
-        const double lw0 = (th[k].y + ev.y) + tr[2 * k + 1], lw1 = (th[k + 1].y + ev.y) + tr[2 * k + 3];
+      for (int c = 0; c < KP / 4; ++c) {
+        double tn[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) tn[j] = tr[8 * (c + 1) + j];   // (the last chunk of the last row reads the 64 bytes behind the tile: allocated)
+        __builtin_amdgcn_sched_barrier(0);
+        const int k = 4 * c;
+        const double ep0 = ev.x * tc[0], ep1 = ev.x * tc[2], ep2 = ev.x * tc[4], ep3 = ev.x * tc[6];
+        const double lw0 = (th[k].y + ev.y) + tc[1], lw1 = (th[k + 1].y + ev.y) + tc[3];
+        const double lw2 = (th[k + 2].y + ev.y) + tc[5], lw3 = (th[k + 3].y + ev.y) + tc[7];
         acc0 = fma(fmax(th[k].x * ep0, kEps), fmax(lw0, cl), acc0);
         acc1 = fma(fmax(th[k + 1].x * ep1, kEps), fmax(lw1, cl), acc1);
+        acc0 = fma(fmax(th[k + 2].x * ep2, kEps), fmax(lw2, cl), acc0);
+        acc1 = fma(fmax(th[k + 3].x * ep3, kEps), fmax(lw3, cl), acc1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) tc[j] = tn[j];
       }
       ev = nxt;
     }

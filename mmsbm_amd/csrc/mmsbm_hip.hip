@@ -752,7 +752,7 @@ int likelihood_lanes(mmsbm_hip_ctx *c) {
   const size_t np = static_cast<size_t>(c->n_ratings) * c->kp * c->lp;
   if (c->lg_theta.count < 2 * nt) c->lg_theta.alloc(2 * nt);  // (value, logarithm) pairs, plain rows
   if (c->lg_eta.count < 2 * ne) c->lg_eta.alloc(2 * ne);
-  if (c->lg_p.count < 2 * np) c->lg_p.alloc(2 * np);
+  if (c->lg_p.count < 2 * np + 16) c->lg_p.alloc(2 * np + 16);   // (+ 16: lik_lane_kernel's scalar loads run one chunk ahead)
   auto blocks = [](size_t n) { return static_cast<unsigned>((n + kBlock - 1) / kBlock); };
   double2 *tl = reinterpret_cast<double2 *>(c->lg_theta.ptr), *el = reinterpret_cast<double2 *>(c->lg_eta.ptr);
   double2 *ptl = reinterpret_cast<double2 *>(c->lg_p.ptr);

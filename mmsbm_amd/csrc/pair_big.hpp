@@ -365,6 +365,9 @@ __global__ __launch_bounds__(NT, NT == 512 ? MMSBM_MFMA_WPE : 2) void pair_mfma_
     STAMP(3);
     if (q0 + kUnitPairs < ch.q_end) MFMA_FETCH(q0 + kUnitPairs);  // the next unit's rows travel during the products
     STAMP(4);
+    // (the products at a raised wave priority: a wave that has its operands should not queue behind the other
+    // workgroup's loads and stores -- C5's T + S launch 356 -> 351 us, variants side by side on one box, round 4)
+    __builtin_amdgcn_s_setprio(1);
     if (DO_S) {  // S += X^T E : the 64 pairs are the summed index, four per instruction
       if (s_on[SA - 1]) {
 #pragma unroll 4
@@ -426,6 +429,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? MMSBM_MFMA_WPE : 2) void pair_mfma_
       }
     }
     STAMP(6);
+    __builtin_amdgcn_s_setprio(0);
     if (BLK && tq > 0) {  // block results: lane = 16 i + 4 blk + j holds row 4 blk + i, column j of its block
       const int r = trow0 + 4 * ((lane >> 2) & 3) + lk;
       if (r < np) {
