@@ -260,6 +260,37 @@ def g5_long():
     save("g5_c2_400", **out)
 
 
+def uneven_frames():
+    """A rating table shaped like a real one: string user / item ids, a few busy users, popular items (log-normal
+    popularity on both sides) -- 20,000 ratings of 150 users x 260 items, and a 2,000-row test sample of it."""
+    rng = np.random.default_rng(5)
+    n, n_u, n_i = 20_000, 150, 260
+    pu, pi = rng.lognormal(0, 0.9, n_u), rng.lognormal(0, 1.3, n_i)
+    df = pd.DataFrame({"users": [f"u{x:03d}" for x in rng.choice(n_u, n, p=pu / pu.sum())],
+                       "items": [f"film-{x}" for x in rng.choice(n_i, n, p=pi / pi.sum())],
+                       "ratings": rng.integers(1, 6, n)})
+    return df, df.sample(2000, random_state=1)
+
+
+def g7_uneven():
+    """The reference's own fit -> predict -> score on that table (K = 6, L = 7, 40 iterations, sampling = 2, seed = 3):
+    every restart's theta / eta / pr and likelihood, the prediction matrix, the scores."""
+    df, test_df = uneven_frames()
+    mm = MMSBM(6, 7, iterations=40, sampling=2, seed=3, backend="numpy")
+    mm.fit(df.copy(), silent=True)
+    pm = mm.predict(test_df.copy())
+    sc = mm.score(silent=True)
+    out = {"train": mm.train, "test": mm.test, "prediction_matrix": pm,
+           "stats_keys": np.array(list(sc["stats"].keys())),
+           "stats_vals": np.array([float(np.sum(v)) for v in sc["stats"].values()]),
+           "likelihoods": np.array([float(r["likelihood"]) for r in mm.results])}
+    for s_, r in enumerate(mm.results):
+        out[f"theta_{s_}"], out[f"eta_{s_}"], out[f"pr_{s_}"] = r["theta"], r["eta"], r["pr"]
+    out.update(frame_cols(df, "train_raw")); out.update(frame_cols(test_df, "test_raw"))
+    out["test_index"] = np.asarray(test_df.index)
+    save("g7_uneven_strings", **out)
+
+
 def edge():
     com, upd, prd, _ = load_backend("numpy")
     norm = ExpectationMaximization.normalize_with_self
@@ -321,3 +352,7 @@ if __name__ == "__main__" and os.environ.get("MMSBM_GOLDEN_ONLY", "g6") == "g6":
 
 if __name__ == "__main__" and os.environ.get("MMSBM_GOLDEN_ONLY", "g5long") == "g5long":
     g5_long()
+
+
+if __name__ == "__main__" and os.environ.get("MMSBM_GOLDEN_ONLY", "g7") == "g7":
+    g7_uneven()

@@ -228,36 +228,39 @@ def test_host_class_reference_end_to_end_case(hip):
 def test_host_class_on_a_rating_table_with_string_ids_and_uneven_degrees(hip):
     """The reference's front door on data shaped like a real rating table (src/data_handler.py:27-61 into the loop at
     src/mmsbm.py:243-256): string user / item ids, a few busy users, popular items -- long segments on both sides, which
-    the library cuts into pieces and (round 4) still runs as two launches per iteration.  fit -> every restart against
-    the oracle's run of the same child seed on the encoded triples; predict -> the oracle's mean distribution and its
-    argmax; the context really ran the whole-segment form."""
+    the library cuts into pieces and (round 4) still runs as two launches per iteration.  Against what the REAL
+    reference gave for the same frames (tests/golden/g7_uneven_strings.npz, make_golden.py: g7_uneven; K = 6, L = 7, 40
+    iterations, sampling = 2, seed = 3): the encoding, every restart's theta / eta / pr and likelihood, the prediction
+    matrix with its argmax, the scores; and the context really ran the whole-segment form."""
     import pandas as pd
-    rng = np.random.default_rng(5)
-    n, n_u, n_i = 20_000, 150, 260
-    pu, pi = rng.lognormal(0, 0.9, n_u), rng.lognormal(0, 1.3, n_i)
-    df = pd.DataFrame({"users": [f"u{x:03d}" for x in rng.choice(n_u, n, p=pu / pu.sum())],
-                       "items": [f"film-{x}" for x in rng.choice(n_i, n, p=pi / pi.sum())],
-                       "ratings": rng.integers(1, 6, n)})
-    test_df = df.sample(2000, random_state=1)
+    g = load_golden("g7_uneven_strings")
+
+    def frame(prefix, index=None):
+        return pd.DataFrame({"users": g[prefix + "_users"], "items": g[prefix + "_items"],
+                             "ratings": g[prefix + "_ratings"].astype(np.int64)}, index=index)
     mm = hip.MMSBM(6, 7, iterations=40, sampling=2, seed=3, backend="hip")
-    mm.fit(df, silent=True)
+    mm.fit(frame("train_raw"), silent=True)
+    assert np.array_equal(mm.train, g["train"])                      # the reference's DataHandler encoding
     ctx = mm._ctx(0)
     assert ctx.get_option("splits_pairs") > 0 and ctx.get_option("splits_users") > 0
     assert ctx.get_option("fused_split") == 3.0 and ctx.get_option("launches") == 2.0
-    train = mm.train
-    want = orc.fit(train, 6, 7, iterations=40, sampling=2, seed=3)
-    for got, w in zip(mm.results, want):
+    for s_, got in enumerate(mm.results):
         for nm in ("theta", "eta", "pr"):
-            assert rel_err(got[nm], w[nm]) < TOL_LOOP, nm
-            assert_elementwise(got[nm], w[nm], nm)
-        assert float(got["likelihood"]) == pytest.approx(float(w["likelihood"]), rel=1e-10)
-    pm = mm.predict(test_df)
-    test = mm.test
-    ref = np.mean([orc.prod_dist(test, w["theta"], w["eta"], w["pr"]) for w in want], axis=0)
+            assert rel_err(got[nm], g[f"{nm}_{s_}"]) < TOL_LOOP, (s_, nm)
+            assert_elementwise(got[nm], g[f"{nm}_{s_}"], f"{nm} of restart {s_}")
+        assert float(got["likelihood"]) == pytest.approx(float(g["likelihoods"][s_]), rel=1e-10)
+    pm = mm.predict(frame("test_raw", index=g["test_index"]))
+    assert np.array_equal(mm.test, g["test"])
+    ref = g["prediction_matrix"]
     assert np.allclose(pm, ref, rtol=1e-9, atol=1e-300)
     srt = np.sort(ref, axis=1)
     clear = srt[:, -1] - srt[:, -2] > 1e-9
     assert clear.mean() > 0.99 and np.array_equal(np.argmax(pm, 1)[clear], np.argmax(ref, 1)[clear])
+    want = dict(zip(g["stats_keys"].tolist(), g["stats_vals"].tolist()))
+    st = mm.score(silent=True)["stats"]
+    assert st["accuracy"] == pytest.approx(want["accuracy"], abs=1e-12) and st["s2"] == want["s2"]
+    assert st["one_off_accuracy"] == pytest.approx(want["one_off_accuracy"], abs=1e-12)
+    assert st["mae"] == pytest.approx(want["mae"], abs=1e-12) and st["s2pond"] == pytest.approx(want["s2pond"], rel=1e-9)
     mm._release()
 
 

@@ -126,6 +126,31 @@ def test_g5_c2_sampled_entries():
         assert rel_err(p, g[f"pr_{it}"]) < 1e-13
 
 
+def test_g7_uneven_string_id_table():
+    """The reference's fit -> predict on a rating table with string ids and uneven degrees (g7_uneven_strings, made
+    by make_golden.py: g7_uneven): the encoder reproduces the reference's DataHandler encoding of both frames, the
+    oracle both restarts, their likelihoods and the prediction matrix, bit for bit."""
+    import pandas as pd
+    from mmsbm_amd.encode import Encoder
+    g = load_golden("g7_uneven_strings")
+    enc = Encoder()
+    train = enc.fit_transform(pd.DataFrame({"users": g["train_raw_users"], "items": g["train_raw_items"],
+                                            "ratings": g["train_raw_ratings"].astype(np.int64)}))
+    assert np.array_equal(train, g["train"])
+    import logging
+    test = enc.transform(pd.DataFrame({"users": g["test_raw_users"], "items": g["test_raw_items"],
+                                       "ratings": g["test_raw_ratings"].astype(np.int64)}), logging.getLogger("t"))
+    assert np.array_equal(test, g["test"])
+    runs = orc.fit(g["train"], 6, 7, iterations=40, sampling=2, seed=3)
+    for s_, run in enumerate(runs):
+        for nm in ("theta", "eta", "pr"):
+            assert np.array_equal(run[nm], g[f"{nm}_{s_}"]), (s_, nm)
+        assert float(run["likelihood"]) == float(g["likelihoods"][s_])
+    pm = np.mean([orc.prod_dist(g["test"], r["theta"], r["eta"], r["pr"]) for r in runs], axis=0)
+    assert np.array_equal(pm, g["prediction_matrix"])
+    assert np.diff(np.bincount(g["train"][:, 0])).size and np.bincount(g["train"][:, 0]).max() > 8 * np.median(np.bincount(g["train"][:, 0]))
+
+
 @pytest.mark.slow
 def test_g5_long_run_first_snapshot():
     """The 400-iteration fixture of the reference's default run length (g5_c2_400, snapshots at 100 / 200 / 400):
