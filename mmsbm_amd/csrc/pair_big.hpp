@@ -271,13 +271,15 @@ __global__ __launch_bounds__(NT, NT == 512 ? MMSBM_MFMA_WPE : 2) void pair_mfma_
 #define MG_COLS_T static_cast<int>((mg1 >> 7) & 127u)
 #define MG_NBR static_cast<int>((mg1 >> 14) & 127u)
 #define MG_NB4 static_cast<int>((mg1 >> 21) & 255u)
-  const int nto = MG_NTO, mti = MG_MTI, ro = BLK ? MG_RO : 0;
+  // (without the blocks: the plain padded geometry, worked out here as before round 4 -- the kernel's registers are counted)
+  const int nto = BLK ? MG_NTO : (doutp + 15) >> 4, mti = BLK ? MG_MTI : (dinp + 15) >> 4, ro = BLK ? MG_RO : 0;
   const int n4 = BLK ? (MG_NB4 + 3) >> 2 : 0;
   // T: wave = 16 rows x its share of the column work.  Eight waves: the two halves split the tiles, the second half
   // takes the blocks (it is the lighter one: it also gets more of S)
   const int trow0 = 16 * (wave & 3);
   const int half = NW == 8 ? (wave >> 2) : 0, nfh = NW == 8 ? (nto + 1) >> 1 : nto;
-  const int tlo = half == 0 ? 0 : nfh, tcnt = half == 0 ? nfh : nto - nfh;   // this wave's column tiles [tlo, tlo + tcnt)
+  // this wave's column tiles [tlo, tlo + tcnt) (without the blocks: TC per half, as before)
+  const int tlo = BLK ? (half == 0 ? 0 : nfh) : TC * half, tcnt = BLK ? (half == 0 ? nfh : nto - nfh) : max(min(nto - TC * half, TC), 0);
   const int tq = (NW == 4 || half == 1) ? ro : 0;                               // ... and column blocks (tcnt < TC then)
   int bcol[TC];  // this lane's column of each of its output tiles
 #pragma unroll
@@ -288,7 +290,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? MMSBM_MFMA_WPE : 2) void pair_mfma_
   bool s_on[SA];
 #pragma unroll
   for (int a = 0; a < SA; ++a) {
-    const int t = (NW == 8 && a == 1) ? 8 + ((wave + 4) & 7) : wave + NW * a;
+    const int t = (BLK && NW == 8 && a == 1) ? 8 + ((wave + 4) & 7) : wave + NW * a;
     s_on[a] = DO_S && t < mti * nto;
     const int m = s_on[a] ? t / nto : 0, n = s_on[a] ? t - m * nto : 0;
     s_a[a] = min(16 * m + li, dinp - 1) * CS + lk;         // + 4 s           : X[pair 4s + lk][k]
@@ -369,7 +371,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? MMSBM_MFMA_WPE : 2) void pair_mfma_
     // workgroup's loads and stores -- C5's T + S launch 356 -> 351 us, variants side by side on one box, round 4)
     __builtin_amdgcn_s_setprio(1);
     if (DO_S) {  // S += X^T E : the 64 pairs are the summed index, four per instruction
-      if (s_on[SA - 1]) {
+      if (!BLK || s_on[SA - 1]) {
 #pragma unroll 4
         for (int s = 0; s < kUnitPairs / 4; ++s) {
 #pragma unroll
@@ -470,7 +472,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? MMSBM_MFMA_WPE : 2) void pair_mfma_
 #pragma unroll
     for (int a = 0; a < SA; ++a) {
       if (!s_on[a]) continue;
-      const int t = (NW == 8 && a == 1) ? 8 + ((wave + 4) & 7) : wave + NW * a, m = t / nto, n = t - m * nto;
+      const int t = (BLK && NW == 8 && a == 1) ? 8 + ((wave + 4) & 7) : wave + NW * a, m = t / nto, n = t - m * nto;
       const int col = 16 * n + li;
       if (col < doutp) {
 #pragma unroll
