@@ -86,6 +86,14 @@ class FakeHipEM:
     def likelihood(self):
         return np.float64(orc.compute_likelihood(self.data, *self._params[self._sel]))
 
+    # -- level 1 (what mmsbm_amd/kernels_hip.py asks of a context)
+    def compute_omegas(self):
+        return orc.compute_omegas(self.data, *self._params[self._sel])
+
+    def update_coefficients(self):
+        LOG.append(("update_coefficients", self._sel))
+        return orc.update_coefficients(self.data, *self._params[self._sel])
+
     def prod_dist(self, pairs):
         return orc.prod_dist(np.asarray(pairs), *self._params[self._sel])
 

@@ -356,3 +356,86 @@ if __name__ == "__main__" and os.environ.get("MMSBM_GOLDEN_ONLY", "g5long") == "
 
 if __name__ == "__main__" and os.environ.get("MMSBM_GOLDEN_ONLY", "g7") == "g7":
     g7_uneven()
+
+
+# ------------------------------------------------------------------------------------------------------------
+# The two LONG fixtures (opt-in: MMSBM_GOLDEN_ONLY=g8 / =g9; never part of the default run, which stays ~2 min)
+# ------------------------------------------------------------------------------------------------------------
+def direct_problem(n, u, i, r, k, l, gen_seed=0, model_seed=0):
+    """A uniform problem with the EM object built directly (the reference's _prepare_objects is O(U*N) dead work
+    at these sizes, src/mmsbm.py:100-122); degrees by bincount, identical values."""
+    train = uniform_triples(n, u, i, r, gen_seed)
+    mm = MMSBM(k, l, iterations=1, seed=model_seed, backend="numpy")
+    d_u = np.maximum(np.bincount(train[:, 0]), 1); d_i = np.maximum(np.bincount(train[:, 1]), 1)
+    mm.p, mm.m = int(train[:, 0].max()), int(train[:, 1].max())
+    mm._dims = {"n_samples": len(train), "n_user_groups": k, "n_item_groups": l,
+                "n_ratings": int(train[:, 2].max()) + 1}
+    mm.em = ExpectationMaximization(
+        dims=mm._dims, user_indices=None, item_indices=None, rating_indices=None,
+        norm_factors={"user": np.repeat(d_u[:, None], k, 1), "item": np.repeat(d_i[:, None], l, 1)},
+        backend="numpy")
+    mm.train = train
+    return mm, train
+
+
+def long_run(name, n, u, i, r, k, l, snaps, n_pick):
+    """The reference's own EM functions over its DEFAULT run length on one restart (model seed 0, restart 0):
+    at each snapshot the sampled theta / eta entries, column sums, all of p, the likelihood, the argmax prediction
+    of every training row and the bit 'top-2 gap > 1e-9'.  Progress goes to stderr (the big one runs for over an hour)."""
+    import time
+    mm, train = direct_problem(n, u, i, r, k, l)
+    pick = np.random.default_rng(7)
+    ut = pick.integers(0, mm.p + 1, n_pick); kt = pick.integers(0, k, n_pick)
+    ie = pick.integers(0, mm.m + 1, n_pick); le = pick.integers(0, l, n_pick)
+    out = {"n": n, "u": u, "i": i, "r": r, "k": k, "l": l, "gen_seed": 0, "model_seed": 0,
+           "train_sum": train.sum(axis=0), "train_head": train[:64], "ut": ut, "kt": kt, "ie": ie, "le": le,
+           "snapshots": np.array(snaps)}
+    rng = np.random.default_rng(mm.child_states[0])
+    theta = mm.em.normalize_with_d(rng.random((mm.p + 1, k)), "user")
+    eta = mm.em.normalize_with_d(rng.random((mm.m + 1, l)), "item")
+    pr = mm.em.normalize_with_self(rng.random((k, l, mm._dims["n_ratings"])))
+    out["theta_s_0"] = theta[ut, kt]; out["eta_s_0"] = eta[ie, le]; out["pr_0"] = pr
+    liks, t0 = [], time.time()
+    for j in range(max(snaps)):
+        n_theta, n_eta, n_pr = mm.em.update_coefficients(data=train, theta=theta, eta=eta, pr=pr)
+        theta = mm.em.normalize_with_d(n_theta, "user")
+        eta = mm.em.normalize_with_d(n_eta, "item")
+        pr = mm.em.normalize_with_self(n_pr)
+        it = j + 1
+        if it % 10 == 0:
+            print(f"{name}: iteration {it}  {time.time() - t0:.0f} s", file=sys.stderr, flush=True)
+        if it in snaps:
+            out[f"theta_s_{it}"] = theta[ut, kt]; out[f"eta_s_{it}"] = eta[ie, le]; out[f"pr_{it}"] = pr
+            out[f"theta_colsum_{it}"] = theta.sum(axis=0); out[f"eta_colsum_{it}"] = eta.sum(axis=0)
+            pdist = ref_k.prod_dist(train, theta, eta, pr)
+            srt = np.sort(pdist, axis=1)
+            out[f"argmax_{it}"] = np.argmax(pdist, 1).astype(np.int8)
+            out[f"clear_{it}"] = np.packbits((srt[:, -1] - srt[:, -2]) > 1e-9)
+            liks.append(mm.em.compute_likelihood(train, theta, eta, pr))
+            out["likelihood_at"] = np.array(liks)
+            np.savez_compressed(os.path.join(os.environ.get("TMPDIR", "/tmp"), name + "_partial.npz"), **out)
+    out["likelihood_at"] = np.array(liks)
+    save(name, **out)
+
+
+def g8_c3_long():
+    """C3 itself -- BASELINE.json's headline config: 1M ratings, 100k x 20k, R=5, K=L=20, seed 0 -- over the reference's
+    default iterations=400 (src/mmsbm.py:63-72), snapshots at 100 / 200 / 400.  About 11 s per iteration on one core,
+    7 GB resident: ~75 minutes."""
+    long_run("g8_c3_400", 1_000_000, 100_000, 20_000, 5, 20, 20, (100, 200, 400), 4000)
+
+
+def g9_k50_long():
+    """A C5-shaped problem the dense reference can hold: 100k ratings of 10k users x 1k items (C5's 10 ratings per
+    user, 100 per item), R=10, K=L=50 -- the matrix-core kernel family -- 400 iterations, snapshots at 100 / 200 / 400."""
+    long_run("g9_k50_400", 100_000, 10_000, 1_000, 10, 50, 50, (100, 200, 400), 4000)
+
+
+if __name__ == "__main__" and os.environ.get("MMSBM_GOLDEN_ONLY") == "g8":
+    g8_c3_long()
+
+if __name__ == "__main__" and os.environ.get("MMSBM_GOLDEN_ONLY") == "g9":
+    g9_k50_long()
+
+if __name__ == "__main__" and os.environ.get("MMSBM_GOLDEN_ONLY") == "glong_selftest":
+    long_run("glong_selftest", 5_000, 500, 100, 5, 6, 7, (2, 4, 6), 50)
