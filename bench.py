@@ -358,7 +358,9 @@ def main():
     # end-of-job pick go through RCCL on every run is made AFTER the timed region (its barrier kernel and
     # proxy thread cost a 20-step run 2-3 us per step when they sit in front of it; a barrier among one
     # rank has nothing to wait for).
-    rank, world, local, device = restarts.init_from_env(args.dist_backend)
+    # (a generous rendezvous, for bench.py only: with N > 1 its rank 0 times the CPU baseline before it joins)
+    import datetime
+    rank, world, local, device = restarts.init_from_env(args.dist_backend, timeout=datetime.timedelta(minutes=30))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if device.type != "cuda":

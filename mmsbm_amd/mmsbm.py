@@ -239,6 +239,12 @@ class MMSBM:
         running sum over restarts, argmax and the indicators of src/mmsbm.py:488-528 -- is
         evaluated on the device; per restart only six sums come back."""
         self._check_is_fitted()
+        if len(self._restart_ids) != self.sampling:
+            # restarts.fit_distributed(gather=False) left this rank with ITS share only: a mean over that share
+            # would silently differ from rank to rank (the reference averages over all restarts, src/mmsbm.py:315)
+            raise RuntimeError(
+                f"this model holds {len(self._restart_ids)} of its {self.sampling} restarts (restarts.fit_distributed "
+                "without gather=True): use mmsbm_amd.restarts.predict_distributed(model, data), or fit with gather=True")
         test = self.data_handler.transform(data, self.logger)
         matrix, raw, per_run = self._predict_runs(test)
         self.run_stats = per_run

@@ -31,11 +31,14 @@ def shard_restarts(sampling, rank, world):
     return list(range(rank, sampling, world))
 
 
-def init_from_env(backend=None, force_init=False):
+def init_from_env(backend=None, force_init=False, timeout=None):
     """Initialise torch.distributed from RANK/WORLD_SIZE/MASTER_* (torchrun); returns
     (rank, world, local_rank, device).  Single process when WORLD_SIZE is unset or 1: no process
     group is made then, unless ``force_init`` asks for a one-rank group (so that the collective
-    backend -- RCCL for ``nccl`` -- really runs even on one GPU)."""
+    backend -- RCCL for ``nccl`` -- really runs even on one GPU).  ``timeout``: a ``datetime.timedelta`` for the
+    group's rendezvous and collectives; None keeps torch's default, so that a dead rank or mismatched
+    collectives surface after minutes, not half an hour (bench.py passes a long one: its rank 0 times the CPU
+    baseline before it joins)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -53,9 +56,8 @@ def init_from_env(backend=None, force_init=False):
                 with socket.socket() as sock:
                     sock.bind(("127.0.0.1", 0))
                     os.environ["MASTER_PORT"] = str(sock.getsockname()[1])
-        # (a generous rendezvous: with N > 1 rank 0 of bench.py times the CPU baseline before it joins)
-        import datetime
-        dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(minutes=30))
+        extra = {} if timeout is None else {"timeout": timeout}
+        dist.init_process_group(backend, rank=rank, world_size=world, **extra)
     # tensors for the collectives live where the backend wants them
     coll = torch.device("cuda", local) if (use_gpu and backend == "nccl") else torch.device("cpu")
     init_from_env.collective_device = coll
@@ -120,8 +122,10 @@ def result_shapes(model, train):
     """((U, K), (I, L), (K, L, R)) of a restart's theta / eta / pr -- every rank can tell them from the training
     triples and the model, so no collective has to carry them."""
     train = np.asarray(train)
-    n_r = len(np.flatnonzero(np.bincount(train[:, 2]))) if len(train) else 0
     k, l = int(model.user_groups), int(model.item_groups)
+    if train.ndim != 2 or len(train) == 0:
+        return (0, k), (0, l), (k, l, 0)
+    n_r = len(np.flatnonzero(np.bincount(train[:, 2])))
     return (int(train[:, 0].max()) + 1, k), (int(train[:, 1].max()) + 1, l), (k, l, n_r)
 
 
@@ -154,11 +158,25 @@ def broadcast_result(res, src, shapes, likelihood, device=None):
         return res
     dev = _collective_device(device)
     me = dist.get_rank()
+    # the owner says what it is about to send (2 + 2 + 3 integers): every rank allocates from THAT and every rank
+    # sees a disagreement with what it expected at the same point -- before the big broadcasts, so that a runner
+    # returning other shapes fails everywhere together instead of leaving the receivers blocked in a collective
+    expected = [int(x) for sh in shapes for x in sh]
+    if me == src:
+        sent = [int(x) for key in ("theta", "eta", "pr") for x in np.shape(res[key])]
+        if len(sent) != len(expected):
+            sent = [-1] * len(expected)
+    else:
+        sent = [0] * len(expected)
+    head = torch.tensor(sent, dtype=torch.int64, device=dev)
+    dist.broadcast(head, src=src)
+    sent = [int(x) for x in head.cpu().tolist()]
+    if sent != expected:
+        raise ValueError(f"broadcast_result: rank {src} holds theta / eta / pr of shapes {sent}, expected {expected}")
     out = {"likelihood": float(likelihood)}
     for key, sh in zip(("theta", "eta", "pr"), shapes):
         if me == src:
             t = torch.from_numpy(np.ascontiguousarray(res[key], dtype=np.float64)).to(dev)
-            assert tuple(t.shape) == tuple(sh), (key, tuple(t.shape), sh)
         else:
             t = torch.empty(sh, dtype=torch.float64, device=dev)
         dist.broadcast(t, src=src)

@@ -169,6 +169,17 @@ WORKER = textwrap.dedent("""
     # without the broadcast only the rank that ran the winner has it
     restarts.fit_distributed(model, train, runner=runner, device=device, share_best=False)
     assert (model.best_result is not None) == (best in mine)
+    # a runner that returns other shapes than the training set implies: EVERY rank raises, at the same point (the
+    # owner's shapes travel first), nobody is left waiting in a broadcast
+    def odd_runner(i, seed):
+        res = dict(runner(i, seed))
+        res["theta"] = res["theta"][:, :1]
+        return res
+    try:
+        restarts.fit_distributed(model, train, runner=odd_runner, device=device)
+        raise SystemExit("mismatched shapes went through")
+    except ValueError as exc:
+        assert "broadcast_result" in str(exc)
     # gather=True (explicit): every rank gets every restart, through tensor all_gathers
     best2, _, liks2 = restarts.fit_distributed(model, train, runner=runner, gather=True, device=device)
     assert best2 == best and np.array_equal(liks2, liks)
@@ -206,6 +217,13 @@ PREDICT_WORKER = textwrap.dedent("""
     else:
         assert [r for r in model._restart_ids] == ([0, 2] if rank == 0 else [1])
         assert len(model.results) == len(model._restart_ids)      # nobody holds the other rank's parameters
+        model.data_handler = type("Enc", (), dict(transform=staticmethod(lambda d, log: d)))()
+        try:      # a mean over this rank's share would differ from rank to rank: predict() says so instead
+            model.predict(test)
+            raise SystemExit("predict() on a partial model went through")
+        except RuntimeError as exc:
+            assert "predict_distributed" in str(exc)
+        model.data_handler = None
     matrix = restarts.predict_distributed(model, test, device=device)
     # the same three restarts in ONE process
     solo = host.MMSBM(2, 2, iterations=10, sampling=3, seed=1)
