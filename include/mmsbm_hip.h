@@ -190,21 +190,21 @@ int mmsbm_hip_kernel_bytes(const mmsbm_hip_ctx *ctx, int index, int64_t *bytes_r
  * stage's outputs overwrite scratch/next buffers: call set_params again before trusting the
  * context's state. */
 int mmsbm_hip_time_stage(mmsbm_hip_ctx *ctx, int stage, int reps, float *mean_us);
-/* Named tuning knobs (defaults are right for normal use): "graph" 0/1 (the same switch as
- * mmsbm_hip_set_graph_mode), "direct" 0/1 (pair stage: output rows stored from registers),
- * "quad" 0/1 (long rows: the A launch as a persistent four-unit pipeline), "lik_fast" 0/1
- * (likelihood through logarithm tables), "lik_g" 0/1/2/4/8 (its lanes per triple, 0 = automatic),
- * "slot_waves" 0/1 (several restart slots: one super-group of lanes walks a segment for all slots
- * -- the default -- or every slot in workgroups of its own), "mfma" 0/1/2 (the pair stage on the
- * matrix cores, v_mfma_f64_16x16x4_f64: 0 off, 1 on -- the one-block kernel for K, L <= 64, else the
- * blocked kernels --, 2 the blocked kernels whatever the shape; create() turns it on for K x L > 1024
- * unless a side has fewer than 16 groups; environment MMSBM_HIP_NO_MFMA=1 keeps it off), "mfma_threads" 256/512
- * (workgroup size of its T+S launch), "predict_fast" 0/1 (prod_dist / predict through the table of
- * p_r eta_i over every (item, rating) combination -- the default where the rows are not far fewer than
- * the items -- or always through the one-thread-per-row kernels), "seg_batch" 4/8 (row gathers a group of
- * lanes of the triple passes keeps in flight; create() picks 8 for small problems). */
+/* The library chooses its kernels from the shape and the data; these few switches exist because the tests compare
+ * forms with each other (none is needed for normal use, and nothing that was measured and rejected is kept behind a
+ * switch -- EXPERIMENTS.md has those): "graph" 0/1 (the same switch as mmsbm_hip_set_graph_mode), "fused" 0/1 (two
+ * launches per iteration instead of four: small problems; 1 is refused where the form does not exist), "mfma" 0/1/2
+ * (the pair stage on the matrix cores, v_mfma_f64_16x16x4_f64: 0 the vector-ALU form, 1 on -- the one-block kernel for
+ * K, L <= 64, else the blocked kernels --, 2 the blocked kernels whatever the shape; create() turns it on for
+ * K x L > 1024; environment MMSBM_HIP_NO_MFMA=1 keeps it off), "quad" 0/1 (vector-ALU form of long rows: the A launch
+ * as a persistent four-unit pipeline), "lik_fast" 0/1/2 (likelihood: a logarithm per element / logarithm tables, a
+ * group of lanes per triple / 2 = the default: a wave per pair or a lane per triple where those apply), "lik_g"
+ * 0/1/2/4/8 (lanes per triple of the table form, 0 = automatic), "predict_fast" 0/1 (prod_dist / predict through the
+ * table of p_r eta_i over every (item, rating) combination -- the default where the rows are not far fewer than the
+ * items -- or through the one-thread-per-row kernels), "nt_out" 0..15 (bits: non-temporal stores of the T / A rows,
+ * of the theta' rows, non-temporal loads of the segments' own rows; 8: whatever the data; results are bitwise the same). */
 int mmsbm_hip_set_option(mmsbm_hip_ctx *ctx, const char *name, double value);
-/* Reads a knob back; also the read-only "ranges_pairs" / "ranges_users" (ranges the XCD-local work
+/* Reads a switch back; also the read-only "launches" (2 or 4: what the next iteration takes), "ranges_pairs" / "ranges_users" (ranges the XCD-local work
  * list of that pass uses, 1 = off), "items_pairs" / "items_users" (work items, 0 = segments as
  * they are) and "wide" (1: K, L beyond the 64-pair LDS stage -- the vector form of the pair stage is then the plain
  * wide-row kernels; they run when "mfma" reads 0, the blocked matrix-core kernels when it reads 2). */

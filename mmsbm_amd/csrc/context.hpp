@@ -139,11 +139,6 @@ struct mmsbm_hip_ctx {
   hipStream_t stream = nullptr;
   hipStream_t copy_stream = nullptr;  // parameter downloads that overlap kernels of `stream` (mmsbm_hip_result)
   hipStream_t xfer = nullptr;         // when set: the stream copy_rows / fetch_params use instead of `stream`
-  // Experiment (round 4, option "fork" = 1; slower at every size measured, stages.hpp: use_fork): the user pass of an
-  // iteration needs nothing of its dense chain (T + S, eta_p, the A launch) and can run beside it on a second stream.
-  hipStream_t side_stream = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  int fork = 0;
   bool swapped = false;
   // external dims
   int64_t n_obs = 0;
@@ -181,12 +176,9 @@ struct mmsbm_hip_ctx {
                                // the start of an iteration, so after a committed fused iteration it does not)
   bool mfma = false;    // both pair-stage launches run pair_mfma_kernel (tiles beyond the scalar cache, K, L <= 64)
   size_t lds_mt = 0, lds_ma = 0;
-  int mfma_threads = kPairBlockMax;  // T+S launch: 512 (eight waves) or 256
-  int mfma_blocks = 1;  // option "mfma_blocks": 4- and 8-wide remainders of a tile side as 4 x 4 blocks (v_mfma_f64_4x4x4_4b_f64): 1 in the A launch, 2 in the T + S launch too (slower: registers), 0: padded 16-tiles
   bool mfma_big = false;  // K or L beyond 64: the blocked forms (mfma_rows_kernel + mfma_slab_kernel)
   bool wide = false;    // K, L beyond the LDS stage: wide_matvec / wide_slab kernels (any size)
   int nt_out = 7;          // option "nt_out" (bits: 1 T and A rows, 2 theta' rows as non-temporal stores, 4 the segments' own rows as non-temporal loads) where that pays (nt_on, stages.hpp)
-  bool slot_waves = true;  // several slots: one super-group of lanes walks a segment for all of them
   int ranges_pairs = 1, ranges_users = 1;  // XCD-local work lists: ranges the gathered table is cut into
   int n_cus = 256;
   size_t lds_qa = 0;
@@ -236,9 +228,6 @@ struct mmsbm_hip_ctx {
       (void)hipEventDestroy(pe.second.first);
       (void)hipEventDestroy(pe.second.second);
     }
-    if (ev_fork) (void)hipEventDestroy(ev_fork);
-    if (ev_join) (void)hipEventDestroy(ev_join);
-    if (side_stream) (void)hipStreamDestroy(side_stream);
     if (copy_stream) (void)hipStreamDestroy(copy_stream);
     if (stream) (void)hipStreamDestroy(stream);
   }

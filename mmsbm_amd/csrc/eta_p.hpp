@@ -149,6 +149,25 @@ __device__ __forceinline__ void p_update_block(
 // item_sum -- eta_new[i,:] = eta[i,:] * sum_{q in item i} T[q,:] / d_i  (src/mmsbm.py:249).
 // One group of G lanes per item.
 // ======================================================================================
+// NB rows of T by the pair ids at row[0 .. NB) (-1: no such pair), all loads in flight together, added in order
+template <int VEC, int NB>
+__device__ __forceinline__ void grid_rows(const int32_t *__restrict__ row, const double *__restrict__ ttab, int lp,
+                                          int lane_off, double (&acc)[VEC]) {
+  int id[NB];
+  double t[NB][VEC];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) id[b] = row[b];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) load_vec<VEC>(ttab + static_cast<size_t>(max(id[b], 0)) * lp + lane_off, t[b]);
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    if (id[b] >= 0) {
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) acc[v] += t[b][v];
+    }
+  }
+}
+
 template <int G, int VEC>
 __device__ __forceinline__ void item_sum_block(
     int block, const double *__restrict__ ttab, const int32_t *__restrict__ item_off,
@@ -166,26 +185,35 @@ __device__ __forceinline__ void item_sum_block(
   double acc[VEC], e[VEC];
 #pragma unroll
   for (int v = 0; v < VEC; ++v) acc[v] = 0.0;
-  load_vec<VEC>(eta + static_cast<size_t>(it) * lp + lane_off, e);
+  // (the item's own row: asked for up front where the registers allow it -- it is needed last; with 16 doubles per lane
+  // it would sit beside two T rows in flight and the sums, 128 registers, and spill: fetched after the sums there)
+  if (VEC <= 8) load_vec<VEC>(eta + static_cast<size_t>(it) * lp + lane_off, e);
   if (item_grid) {
     // dense data (most (item, rating) combinations occur): the item's pairs sit in a fixed-width
     // grid row (-1: no such pair; ascending rating like the CSR list, so the sums are the same), one
     // dependent load level less than offsets -> pair ids -> rows
     const int32_t *row = item_grid + static_cast<size_t>(it) * n_ratings;
-    for (int j = 0; j < n_ratings; j += B) {
+    if (n_ratings <= B) {   // one round of loads (a rating beyond the last repeats the last one and is not added)
       int id[B];
       double t[B][VEC];
 #pragma unroll
-      for (int b = 0; b < B; ++b) id[b] = row[min(j + b, n_ratings - 1)];
+      for (int b = 0; b < B; ++b) id[b] = row[min(b, n_ratings - 1)];
 #pragma unroll
       for (int b = 0; b < B; ++b) load_vec<VEC>(ttab + static_cast<size_t>(max(id[b], 0)) * lp + lane_off, t[b]);
 #pragma unroll
       for (int b = 0; b < B; ++b) {
-        if (j + b < n_ratings && id[b] >= 0) {
+        if (b < n_ratings && id[b] >= 0) {
 #pragma unroll
           for (int v = 0; v < VEC; ++v) acc[v] += t[b][v];
         }
       }
+    } else {                // full rounds, then the rest in rounds of 4, 2, 1: no row is asked for twice (R = 10: 8 + 2)
+      int j = 0;
+      for (; j + B <= n_ratings; j += B) grid_rows<VEC, B>(row + j, ttab, lp, lane_off, acc);
+      const int rem = n_ratings - j;
+      if (B > 4 && (rem & 4)) { grid_rows<VEC, 4>(row + j, ttab, lp, lane_off, acc); j += 4; }
+      if (B > 2 && (rem & 2)) { grid_rows<VEC, 2>(row + j, ttab, lp, lane_off, acc); j += 2; }
+      if (rem & 1) grid_rows<VEC, 1>(row + j, ttab, lp, lane_off, acc);
     }
   }
   const int beg = item_grid ? 0 : item_off[it], end = item_grid ? 0 : item_off[it + 1];
@@ -204,6 +232,7 @@ __device__ __forceinline__ void item_sum_block(
       }
     }
   }
+  if (VEC > 8) load_vec<VEC>(eta + static_cast<size_t>(it) * lp + lane_off, e);
   const double d = static_cast<double>(max(item_deg[it], 1));
 #pragma unroll
   for (int v = 0; v < VEC; ++v) e[v] = normalize ? (e[v] * acc[v]) / d : e[v] * acc[v];

@@ -153,7 +153,9 @@ __device__ __forceinline__ double lik_wave_chunk(const double2 *__restrict__ tl,
 #define MMSBM_LIK_WPE 4  // waves per SIMD the kernel is compiled for
 #endif
 template <int LW>  // columns per lane: lane, lane + 64, ...
-__global__ __launch_bounds__(kLikWaveThreads) __attribute__((amdgpu_waves_per_eu(MMSBM_LIK_WPE, 8))) void lik_wave_kernel(
+// (three columns per lane -- rows of 129 to 192 groups -- hold 12 more doubles per lane than two: compiled for one wave
+// per SIMD fewer, it keeps them in registers instead of 28 bytes of scratch)
+__global__ __launch_bounds__(kLikWaveThreads) __attribute__((amdgpu_waves_per_eu(LW == 3 ? MMSBM_LIK_WPE - 1 : MMSBM_LIK_WPE, 8))) void lik_wave_kernel(
     const mmsbm::Chunk *__restrict__ units, const int32_t *__restrict__ pair_off,
     const int32_t *__restrict__ pair_user, const int32_t *__restrict__ pair_item, const double2 *__restrict__ tl,
     RowTab a_tab, const double *__restrict__ eta, const double *__restrict__ leta, const double *__restrict__ p,

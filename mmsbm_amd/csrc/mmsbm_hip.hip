@@ -288,7 +288,7 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
     c->lds_qa = (static_cast<size_t>(kQuadUnits) * c->lp * (kUnitPairs + 1) + static_cast<size_t>(c->lp) * c->kp) *
                 sizeof(double);
     c->quad_a = !c->wide && c->kp * c->lp > 1024 && c->tl_a && c->pb_threads_a == kPairBlockMax &&
-                c->lds_qa <= kLdsMax - 2048 && c->lp <= 64 && big_chunk == 4 * mmsbm::kMvChunkPairs;
+                c->lds_qa <= kLdsMax - 2048 && c->lp <= kQuadMaxL && big_chunk == 4 * mmsbm::kMvChunkPairs;
     c->n_pairs = c->lay.n_pairs;
     c->n_chunks = static_cast<int>(c->lay.mv_chunks.size());
     // dense data: XCD-local work lists (layout.hpp) -- every segment cut at fixed borders of the
@@ -341,8 +341,11 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
       const int lanes = group_lanes(c->code_k);
       if (!c->lay.pair_work.splits.empty()) {
         const mmsbm::SegPieces sp = mmsbm::segment_pieces(c->lay.pair_off, c->lay.pair_work);
+        // (the capped unit list REPLACES the plain one -- both forms of the iteration then run it, so that their S sums
+        // associate the same way -- but only once it is certain that the two-launch form can use it: kept aside until then)
+        const std::vector<mmsbm::Chunk> plain_chunks = c->lay.mv_chunks;
+        const std::vector<int32_t> plain_off = c->lay.mv_chunk_off;
         if (mmsbm::build_mv_chunks_capped(c->lay, sp, mmsbm::kMvChunkPairs, kUnitPairs)) {
-          c->n_chunks = static_cast<int>(c->lay.mv_chunks.size());
           const mmsbm::FusedLists fl = mmsbm::build_fused_pairs(c->lay, sp);
           if (pairs_fused_lds(c->kp, c->lp, fl.max_parts) <= kLdsMax) {
             c->fp_units.upload(fl.units, c->stream); c->fp_items.upload(fl.items, c->stream);
@@ -352,6 +355,8 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
             c->fs_pairs = true;
           }
         }
+        if (!c->fs_pairs) { c->lay.mv_chunks = plain_chunks; c->lay.mv_chunk_off = plain_off; }
+        c->n_chunks = static_cast<int>(c->lay.mv_chunks.size());
       }
       if (!c->lay.user_work.splits.empty()) {
         const mmsbm::SegPieces sp = mmsbm::segment_pieces(c->lay.user_off, c->lay.user_work);
@@ -640,6 +645,7 @@ bool lik_fast_usable(const mmsbm_hip_ctx *c) {
 }
 // likelihood of the selected slot through the logarithm tables; returns the number of partial sums
 int likelihood_fast(mmsbm_hip_ctx *c) {
+  ensure_a(c);  // (s_n = theta_n . A[q_n])
   const int cur = c->cur, sl = c->sel;
   const size_t nt = static_cast<size_t>(c->n_users) * c->kp, ne = static_cast<size_t>(c->n_items) * c->lp;
   const size_t np = static_cast<size_t>(c->n_ratings) * c->kp * c->lp;
@@ -670,7 +676,7 @@ int likelihood_fast(mmsbm_hip_ctx *c) {
 #define LIK_GO(LW_, G_, TL_)                                                                      \
   allow_big_lds(likelihood_fast_kernel<LW_, G_, TL_>, lds);                                       \
   likelihood_fast_kernel<LW_, G_, TL_><<<nb, kLikThreads, lds, c->stream>>>(                      \
-      c->lik_units.ptr, c->pair_off.ptr, c->pair_user.ptr, c->pair_item.ptr, th, lth,            \
+      c->lik_units.ptr, c->pair_off.ptr, c->pair_user.ptr, c->pair_item.ptr, th, lth, a_tab(c, cur), \
       c->eta[cur].at(sl), c->lg_eta.ptr, c->p[cur].at(sl), c->lg_p.ptr, c->lik_part.ptr, c->k,    \
       c->l, c->kp, c->lp)
 #define LIK_LW(G_, TL_)                                                                           \
@@ -1221,9 +1227,6 @@ int mmsbm_hip_set_option(mmsbm_hip_ctx *ctx, const char *name, double value) {
     const std::string key(name);
     if (key == "graph") {
       ctx->graph_mode = value != 0.0;
-
-    } else if (key == "slot_waves") {  // 0: restart slots as separate workgroups (blockIdx.y) in the triple passes
-      ctx->slot_waves = value != 0.0;
     } else if (key == "lik_fast") {  // 0: a logarithm per element; 1: logarithm tables, a group of lanes per triple
                                      // (round 2); 2: where it applies a wave per pair (lik_fact.hpp), else as 1
       if (value != 0.0 && value != 1.0 && value != 2.0) throw std::invalid_argument("lik_fast: 0, 1 or 2");
@@ -1232,11 +1235,9 @@ int mmsbm_hip_set_option(mmsbm_hip_ctx *ctx, const char *name, double value) {
       const int g = static_cast<int>(value);
       if (g != 0 && g != 1 && g != 2 && g != 4 && g != 8) throw std::invalid_argument("lik_g: 0, 1, 2, 4 or 8");
       ctx->lik_g = g;
-    } else if (key == "direct") {
-      ctx->direct_out = value != 0.0;
     } else if (key == "quad") {  // 0: the A launch through pair_block like every other shape
       ctx->quad_a = value != 0.0 && !ctx->wide && ctx->kp * ctx->lp > 1024 && ctx->tl_a &&
-                    ctx->pb_threads_a == kPairBlockMax && ctx->lds_qa <= kLdsMax - 2048 && ctx->lp <= 64;
+                    ctx->pb_threads_a == kPairBlockMax && ctx->lds_qa <= kLdsMax - 2048 && ctx->lp <= kQuadMaxL;
     } else if (key == "fused") {  // two launches per iteration (small tiles, unsplit segments); any problem size
       if (value != 0.0 && !fused_possible(ctx)) throw std::invalid_argument("fused: not available for this shape / data");
       ctx->fused = value != 0.0;
@@ -1244,20 +1245,8 @@ int mmsbm_hip_set_option(mmsbm_hip_ctx *ctx, const char *name, double value) {
     } else if (key == "nt_out") {  // 0: plain stores for every output row; bits: 1 T and A rows, 2 theta' rows, 4 own-row loads
       if (value < 0 || value > 15) throw std::invalid_argument("nt_out: 0 .. 15");
       ctx->nt_out = static_cast<int>(value);
-    } else if (key == "seg_batch") {
-      if (value != 4 && value != 8) throw std::invalid_argument("seg_batch: 4 or 8");
-      ctx->seg_batch = static_cast<int>(value);
     } else if (key == "predict_fast") {  // 0: prod_dist / predict through the per-row kernels (R K L multiply-adds per row)
       ctx->predict_fast = value != 0.0;
-    } else if (key == "mfma_threads") {
-      if (value != kBlock && value != kPairBlockMax) throw std::invalid_argument("mfma_threads: 256 or 512");
-      ctx->mfma_threads = static_cast<int>(value);
-    } else if (key == "fork") {  // experiment: the user pass beside the dense chain on a second stream (0 / 1)
-      if (value != 0.0 && value != 1.0) throw std::invalid_argument("fork: 0 or 1");
-      ctx->fork = static_cast<int>(value);
-    } else if (key == "mfma_blocks") {  // 0: remainders of 4 or 8 groups as padded 16-tiles (the form before round 4)
-      if (value != 0.0 && value != 1.0 && value != 2.0) throw std::invalid_argument("mfma_blocks: 0, 1 or 2");
-      ctx->mfma_blocks = static_cast<int>(value);
     } else if (key == "mfma") {  // the pair stage on the matrix cores: 0 off, 1 on (one-block form if K, L <= 64,
                                  // else the blocked form), 2 the blocked form whatever the shape
       ctx->mfma = value == 1.0 && mfma_possible(ctx);
@@ -1274,20 +1263,13 @@ int mmsbm_hip_get_option(const mmsbm_hip_ctx *ctx, const char *name, double *val
     if (!ctx || !name || !value) throw std::invalid_argument("null argument");
     const std::string key(name);
     if (key == "graph") *value = ctx->graph_mode;
-    else if (key == "direct") *value = ctx->direct_out;
     else if (key == "quad") *value = ctx->quad_a;
     else if (key == "mfma") *value = ctx->mfma ? 1.0 : (ctx->mfma_big ? 2.0 : 0.0);
-    else if (key == "mfma_threads") *value = ctx->mfma_threads;
-    else if (key == "mfma_blocks") *value = ctx->mfma_blocks;
-    else if (key == "fork") *value = ctx->fork;
-    else if (key == "forked") *value = use_fork(ctx) && !use_fused(ctx) ? 1.0 : 0.0;  // read-only: what the next iteration does
     else if (key == "predict_fast") *value = ctx->predict_fast;
-    else if (key == "seg_batch") *value = ctx->seg_batch;
     else if (key == "fused") *value = ctx->fused;
     else if (key == "nt_out") *value = nt_on(ctx);
     else if (key == "launches") *value = use_fused(ctx) ? 2 : 4;  // read-only: launches per iteration at the current slot count
     else if (key == "wide") *value = ctx->wide;
-    else if (key == "slot_waves") *value = ctx->slot_waves;
     else if (key == "lik_fast") *value = ctx->lik_mode;
     else if (key == "lik_g") *value = ctx->lik_g;
     else if (key == "ranges_pairs") *value = ctx->ranges_pairs;   // read-only: XCD-local work lists,

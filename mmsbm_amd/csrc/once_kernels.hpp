@@ -151,7 +151,7 @@ template <int LW, int G, bool TLDS>
 __global__ __launch_bounds__(kLikThreads) void likelihood_fast_kernel(
     const mmsbm::Chunk *__restrict__ units, const int32_t *__restrict__ pair_off,
     const int32_t *__restrict__ pair_user, const int32_t *__restrict__ pair_item, RowTab theta,
-    RowTab ltheta, const double *__restrict__ eta, const double *__restrict__ leta,
+    RowTab ltheta, RowTab atab, const double *__restrict__ eta, const double *__restrict__ leta,
     const double *__restrict__ p, const double *__restrict__ logp, double *__restrict__ block_out,
     int k_groups, int l_groups, int kp, int lp) {
   extern __shared__ double lds[];  // TLDS: [kp*lp] tile, [kp*lp] its logarithms
@@ -206,9 +206,19 @@ __global__ __launch_bounds__(kLikThreads) void likelihood_fast_kernel(
       le[j] = r0 ? lv.x : -INFINITY; le[j + 1] = r1 ? lv.y : -INFINITY;
       n_fake += (r0 ? 0 : 1) + (r1 ? 0 : 1);
     }
+    // s_n = theta_n . A[q_n] from the iteration's own table (K multiply-adds), so that log s~ is known BEFORE the
+    // elements are visited and every element is subtracted by itself, w (log w - log s~), as the reference does
+    // (src/expectation_maximization.py:163-167).  Forming sum w log w and log s~ sum w separately cancels where one
+    // element carries the row (one group on a side: 1.6e-10 of the small difference, found by scripts/fuzz_parity.py).
+    double s = 0.0;
+    {
+      const size_t qrow = static_cast<size_t>(ch.q_begin + lo);
+      for (int k = 0; k < k_groups; ++k) s = fma(*rowtab_ptr(theta, urow, k), *rowtab_ptr(atab, qrow, k), s);
+    }
+    const double ls = log(fmax(s, kEps));
     // The clamp as two maxima (round 3): log is monotone, so with w = max(omega, eps) the element is
-    // w * max(log omega, log eps) - ls * w -- no compare, no select, no counter of clamped elements.
-    double s = 0.0, a_sum = 0.0, w_sum = 0.0;
+    // w * (max(log omega, log eps) - ls) -- no compare, no select, no counter of clamped elements.
+    double a_sum = 0.0;
     for (int k = 0; k < k_groups; ++k) {
       const double tk = *rowtab_ptr(theta, urow, k);
       const double ltk = *rowtab_ptr(ltheta, urow, k);
@@ -224,18 +234,13 @@ __global__ __launch_bounds__(kLikThreads) void likelihood_fast_kernel(
           lpv = gltile[k * lp + lc];
         }
         const double om = (tk * e[j]) * pv;
-        s += om;
         const double w = fmax(om, kEps);
-        a_sum = fma(w, fmax((ltk + le[j]) + lpv, log_eps), a_sum);
-        w_sum += w;
+        a_sum = fma(w, fmax((ltk + le[j]) + lpv, log_eps) - ls, a_sum);
       }
     }
-    s = group_sum<G>(s);
     a_sum = group_sum<G>(a_sum);
-    w_sum = group_sum<G>(w_sum);
     const double fake = static_cast<double>(group_sum<G>(static_cast<double>(n_fake * k_groups)));
-    const double ls = log(fmax(s, kEps));
-    if (have && g == 0) total += (a_sum - ls * w_sum) - fake * (kEps * (log_eps - ls));
+    if (have && g == 0) total += a_sum - fake * (kEps * (log_eps - ls));
   }
   red[tid] = total;
   __syncthreads();

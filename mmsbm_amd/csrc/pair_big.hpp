@@ -182,35 +182,23 @@ constexpr int kMfmaMaxDim = 64;       // <= 4 tiles of 16 per side
 constexpr int kMfmaChunkPairs = 1024;  // pairs per workgroup at most (their item ids are parked in LDS)
 static_assert(kMfmaChunkPairs >= 4 * mmsbm::kMvChunkPairs, "pair_mfma_kernel parks a whole chunk's item ids in LDS");
 
-// Tiles and 4 x 4 blocks of a (dinp x doutp) pair-stage product for a workgroup of `nw` waves (4 or 8), packed for
-// PairBlockArgs::mg0 / mg1 (pair_mfma_kernel explains the geometry).  A side of 16 f + 4 r groups: f full 16-tiles; a
-// remainder of 4 or 8 (r = 1, 2) runs as 4 x 4 blocks on v_mfma_f64_4x4x4_4b_f64, a remainder of 12 stays a padded tile.
-constexpr int kMfmaSQ = 4;   // block instructions of S per wave at most: they accumulate in the four doubles of a tile
-                             // accumulator the wave has no tile for (no register of their own)
-inline void mfma_geometry(int dinp, int doutp, bool do_s, int nw, bool blocks, int *mg0, int *mg1) {
-  const int fo = doutp >> 4, ro0 = (doutp & 15) >> 2, fi = dinp >> 4, ri0 = (dinp & 15) >> 2;
-  int ro = (blocks && (ro0 == 1 || ro0 == 2)) ? ro0 : 0, ri = (blocks && do_s && (ri0 == 1 || ri0 == 2)) ? ri0 : 0;
-  int nto, mti, rows_t, cols_t, nbr, nb4, strip_waves, extra;
-  for (;;) {  // (at most three trips)
-    nto = fo + ((ro0 && !ro) ? 1 : 0); mti = fi + ((ri0 && !ri) ? 1 : 0);    // (padded) 16-tiles per side
-    rows_t = std::min(16 * mti, dinp); cols_t = std::min(16 * nto, doutp);   // rows / columns the tiles cover
-    // S blocks: right strip (tile rows x the remainder's columns), then bottom strip (the remainder's rows x all columns)
-    nbr = do_s ? (rows_t >> 2) * ro : 0; nb4 = nbr + ri * (doutp >> 2);
-    // S tiles are dealt wave, then (eight waves) 8 + ((wave + 4) & 7): `extra` waves from wave 4 on hold two.  Block
-    // instructions go to waves whose last accumulator is free, the T-light half (waves 4 ..) first
-    extra = nw == 8 ? std::max(mti * nto - 8, 0) : 0;
-    strip_waves = nw == 8 ? (extra < 4 ? 4 - extra : 8 - extra) : (mti * nto <= 12 ? 4 : 0);
-    if ((nb4 + 3) / 4 <= kMfmaSQ * strip_waves) break;
-    if (ri) ri = 0; else ro = 0;   // too many blocks for the free accumulators: that side as padded tiles (as before round 4)
-  }
-  *mg0 = ro | (ri << 2) | (nto << 4) | (mti << 7) | (strip_waves << 10) | (extra << 14);
-  *mg1 = rows_t | (cols_t << 7) | (nbr << 14) | (nb4 << 21);
+// The 4 x 4 blocks of the A launch (the T + S launch keeps padded tiles: its 128 registers do not hold them; measured,
+// EXPERIMENTS.md).  An output side of 16 f + 4 r groups: f full 16-tiles; a remainder of 4 or 8 (r = 1, 2) runs as 4 x 4
+// blocks on v_mfma_f64_4x4x4_4b_f64, a remainder of 12 stays a padded tile.  Packed for PairBlockArgs::mg0 / mg1.
+inline void mfma_geometry(int dinp, int doutp, int *mg0, int *mg1) {
+  const int fo = doutp >> 4, ro0 = (doutp & 15) >> 2;
+  const int ro = (ro0 == 1 || ro0 == 2) ? ro0 : 0;
+  const int nto = fo + ((ro0 && !ro) ? 1 : 0), mti = (dinp + 15) >> 4;      // (padded) 16-tiles per side
+  const int rows_t = std::min(16 * mti, dinp), cols_t = std::min(16 * nto, doutp);   // rows / columns the tiles cover
+  *mg0 = ro | (nto << 4) | (mti << 7);
+  *mg1 = rows_t | (cols_t << 7);
 }
 
 // NT threads: 256 (four waves as described) or 512 -- eight waves, each with half of the column tiles of its
 // T rows and <= 2 slab tiles, so that the accumulators and the prefetched rows of the T+S launch fit
 // 128 registers and two workgroups (16 waves) share a CU.
-// BLK: the 4 x 4 block instructions are compiled in (the launch's geometry may still hold none).
+// BLK (the A launch): an output remainder of 4 or 8 groups as 4 x 4 block instructions (the launch's geometry may still
+// hold none).
 template <bool GATHER, bool DO_S, int NT, bool BLK>
 __global__ __launch_bounds__(NT, NT == 512 ? MMSBM_MFMA_WPE : 2) void pair_mfma_kernel(PairBlockArgs pa,
                                                            const double *__restrict__ tiles0) {
@@ -258,22 +246,13 @@ __global__ __launch_bounds__(NT, NT == 512 ? MMSBM_MFMA_WPE : 2) void pair_mfma_
   // tiles, 3 tiles + 1 per row tile of T instead of 4.  Lane map of the 4 x 4 x 4 form (probed, same file): lane =
   // 16 kk + 4 blk + i holds A_blk[i][kk], lane = 16 kk + 4 blk + j holds B_blk[kk][j], lane = 16 i + 4 blk + j gets
   // D_blk[i][j] -- the A operand of a row tile's four 4-row blocks is the register the 16 x 16 x 4 form takes.
-  constexpr int SQ = kMfmaSQ;
-  // (worked out on the host -- mfma_geometry below -- and packed into two kernel arguments: a dozen more uniform
-  // values kept alive across the unit loop cost scalar registers this kernel does not have)
   const unsigned mg0 = static_cast<unsigned>(pa.mg0), mg1 = static_cast<unsigned>(pa.mg1);
 #define MG_RO static_cast<int>(mg0 & 3u)
 #define MG_NTO static_cast<int>((mg0 >> 4) & 7u)
 #define MG_MTI static_cast<int>((mg0 >> 7) & 7u)
-#define MG_SW static_cast<int>((mg0 >> 10) & 15u)
-#define MG_EXTRA static_cast<int>((mg0 >> 14) & 15u)
-#define MG_ROWS_T static_cast<int>(mg1 & 127u)
 #define MG_COLS_T static_cast<int>((mg1 >> 7) & 127u)
-#define MG_NBR static_cast<int>((mg1 >> 14) & 127u)
-#define MG_NB4 static_cast<int>((mg1 >> 21) & 255u)
   // (without the blocks: the plain padded geometry, worked out here as before round 4 -- the kernel's registers are counted)
   const int nto = BLK ? MG_NTO : (doutp + 15) >> 4, mti = BLK ? MG_MTI : (dinp + 15) >> 4, ro = BLK ? MG_RO : 0;
-  const int n4 = BLK ? (MG_NB4 + 3) >> 2 : 0;
   // T: wave = 16 rows x its share of the column work.  Eight waves: the two halves split the tiles, the second half
   // takes the blocks (it is the lighter one: it also gets more of S)
   const int trow0 = 16 * (wave & 3);
@@ -285,33 +264,18 @@ __global__ __launch_bounds__(NT, NT == 512 ? MMSBM_MFMA_WPE : 2) void pair_mfma_
 #pragma unroll
   for (int n = 0; n < TC; ++n) bcol[n] = min(16 * (tlo + n) + li, doutp - 1);
   const int bq = MG_COLS_T + (lane & 3);                    // + 4 c: this lane's column of block instruction c
-  mfma_d4 acc_s[SA];  // (the last one: four block accumulators on a wave that has block instructions)
+  mfma_d4 acc_s[SA];
   int s_a[SA], s_b[SA];
   bool s_on[SA];
 #pragma unroll
   for (int a = 0; a < SA; ++a) {
-    const int t = (BLK && NW == 8 && a == 1) ? 8 + ((wave + 4) & 7) : wave + NW * a;
+    const int t = wave + NW * a;
     s_on[a] = DO_S && t < mti * nto;
     const int m = s_on[a] ? t / nto : 0, n = s_on[a] ? t - m * nto : 0;
     s_a[a] = min(16 * m + li, dinp - 1) * CS + lk;         // + 4 s           : X[pair 4s + lk][k]
     s_b[a] = lk * doutp + min(16 * n + li, doutp - 1);     // + 4 s * doutp   : E[pair 4s + lk][l]
     acc_s[a] = mfma_d4{0.0, 0.0, 0.0, 0.0};
   }
-  // S block instructions q = 0 .. n4 - 1, four blocks each: instruction j of this wave is q = q0w + strip_waves j; per
-  // lane the block 4 q + blk.  (What a lane needs of its blocks is recomputed where it is used -- per unit in front of
-  // the block products, once for the slab store: registers decide how many workgroups share a CU.)
-  const int q0w = NW == 8 ? ((wave - 4 - MG_EXTRA) & 7) : wave;   // this wave's number among the strip waves
-  const bool q_any = BLK && DO_S && n4 > 0 && q0w < MG_SW && q0w < n4;   // (then s_on[SA - 1] is false)
-  // (row block << 8 | column block) of block 4 q + blk; a block that does not exist: -1 (its lanes repeat block 0)
-  auto s_block = [&](int j) -> int {
-    const int q = q0w + MG_SW * j;
-    const int b4 = 4 * q + ((lane >> 2) & 3);
-    if (q >= n4 || b4 >= MG_NB4) return -1;
-    const int rr = MG_RO;
-    if (b4 < MG_NBR) return ((b4 / rr) << 8) | ((MG_COLS_T >> 2) + b4 % rr);
-    const int bb = b4 - MG_NBR, cw = doutp >> 2;
-    return (((MG_ROWS_T >> 2) + bb / cw) << 8) | (bb % cw);
-  };
   __syncthreads();  // ids (and the tile) are in LDS
 
   // rows of the unit at q0 into registers: every load of the unit is in flight at once
@@ -371,37 +335,12 @@ __global__ __launch_bounds__(NT, NT == 512 ? MMSBM_MFMA_WPE : 2) void pair_mfma_
     // workgroup's loads and stores -- C5's T + S launch 356 -> 351 us, variants side by side on one box, round 4)
     __builtin_amdgcn_s_setprio(1);
     if (DO_S) {  // S += X^T E : the 64 pairs are the summed index, four per instruction
-      if (!BLK || s_on[SA - 1]) {
 #pragma unroll 4
-        for (int s = 0; s < kUnitPairs / 4; ++s) {
+      for (int s = 0; s < kUnitPairs / 4; ++s) {
 #pragma unroll
-          for (int a = 0; a < SA; ++a)  // (unconditional: a tile beyond the grid repeats tile 0 and is never stored)
-            acc_s[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(cst[s_a[a] + 4 * s], es[s_b[a] + 4 * s * doutp],
-                                                            acc_s[a], 0, 0, 0);
-        }
-      } else if (s_on[0]) {  // (fewer tiles than accumulators: nothing is multiplied for the ones that do not exist)
-#pragma unroll 4
-        for (int s = 0; s < kUnitPairs / 4; ++s) {
-#pragma unroll
-          for (int a = 0; a < SA - 1; ++a)
-            acc_s[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(cst[s_a[a] + 4 * s], es[s_b[a] + 4 * s * doutp],
-                                                            acc_s[a], 0, 0, 0);
-        }
-      }
-      if (BLK && q_any) {  // the remainders' 4 x 4 blocks (uniform per wave)
-        int q_a[SQ], q_b[SQ];
-#pragma unroll
-        for (int j = 0; j < SQ; ++j) {  // (an instruction this wave does not have repeats block 0 and is never stored)
-          const int rc = max(s_block(j), 0);
-          q_a[j] = (4 * (rc >> 8) + (lane & 3)) * CS + lk;          // + 4 s           : X[pair 4s + lk][row 4 rb + i]
-          q_b[j] = lk * doutp + 4 * (rc & 255) + (lane & 3);        // + 4 s * doutp   : E[pair 4s + lk][col 4 cb + j]
-        }
-#pragma unroll 2
-        for (int s = 0; s < kUnitPairs / 4; ++s) {
-#pragma unroll
-          for (int j = 0; j < SQ; ++j)
-            acc_s[SA - 1][j] = __builtin_amdgcn_mfma_f64_4x4x4f64(cst[q_a[j] + 4 * s], es[q_b[j] + 4 * s * doutp], acc_s[SA - 1][j], 0, 0, 0);
-        }
+        for (int a = 0; a < SA; ++a)  // (unconditional: a tile beyond the grid repeats tile 0 and is never stored)
+          acc_s[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(cst[s_a[a] + 4 * s], es[s_b[a] + 4 * s * doutp],
+                                                          acc_s[a], 0, 0, 0);
       }
     }
     STAMP(5);
@@ -465,14 +404,9 @@ __global__ __launch_bounds__(NT, NT == 512 ? MMSBM_MFMA_WPE : 2) void pair_mfma_
   if (DO_S) {
     double *dst = partial + static_cast<size_t>(blockIdx.x) * dinp * doutp;
 #pragma unroll
-    for (int j = 0; j < SQ; ++j) {  // block results: lane = 16 i + 4 blk + j' holds row i, column j' of its block
-      const int rc = (BLK && q_any) ? s_block(j) : -1;
-      if (rc >= 0) dst[static_cast<size_t>(4 * (rc >> 8) + lk) * doutp + 4 * (rc & 255) + (lane & 3)] = acc_s[SA - 1][j];
-    }
-#pragma unroll
     for (int a = 0; a < SA; ++a) {
       if (!s_on[a]) continue;
-      const int t = (BLK && NW == 8 && a == 1) ? 8 + ((wave + 4) & 7) : wave + NW * a, m = t / nto, n = t - m * nto;
+      const int t = wave + NW * a, m = t / nto, n = t - m * nto;
       const int col = 16 * n + li;
       if (col < doutp) {
 #pragma unroll
@@ -495,12 +429,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? MMSBM_MFMA_WPE : 2) void pair_mfma_
 #undef MG_RO
 #undef MG_NTO
 #undef MG_MTI
-#undef MG_SW
-#undef MG_EXTRA
-#undef MG_ROWS_T
 #undef MG_COLS_T
-#undef MG_NBR
-#undef MG_NB4
 // ======================================================================================
 // The same two products for K or L beyond 64, in 64 x 64 blocks (round 2).  Before, these shapes ran the
 // lane-per-pair stage with the tile through scalar loads (K, L up to ~150) or the plain wide-row kernels

@@ -308,6 +308,7 @@ __device__ __forceinline__ void pair_block_body(const PairBlockArgs &pa,
 constexpr int kPairBlockMax = 512;
 
 constexpr int kQuadUnits = 4;  // 64-pair units a workgroup of pair_quad_a_kernel multiplies jointly
+constexpr int kQuadMaxL = 56;  // its input rows at most (14 double2 per thread and chunk; beyond: pair_block like every other shape)
 
 // (amdgpu_num_sgpr: a 256-thread workgroup is admitted floor(800 / (ceil(sgpr/16)*16 + 16)) times per
 // CU -- 106 SGPRs: 6, 96: 7 (MI355X_MICROARCH.md, residency).  At C3 the stage has 1,565 workgroups:

@@ -119,7 +119,7 @@ PairBlockArgs pair_block_t_args(const mmsbm_hip_ctx *c) {
   pa.out_mw = c->lp; pa.out_rs_m = c->lp; pa.out_rs_t = 0; pa.out_tail = c->ttab.at(s);
   pa.bs_tiles = c->p[0].stride; pa.bs_in = c->ctab.stride; pa.bs_e = c->eta[0].stride;
   pa.bs_out = c->ttab.stride; pa.bs_out_t = 0; pa.bs_partial = c->partial.stride;
-  mfma_geometry(pa.dinp, pa.doutp, true, c->mfma_threads / 64, c->mfma_blocks == 2, &pa.mg0, &pa.mg1);
+  pa.mg0 = pa.mg1 = 0;  // (the T + S launch runs padded 16-tiles: its 128 registers do not hold the 4 x 4 blocks)
   return pa;
 }
 PairBlockArgs pair_block_a_args(const mmsbm_hip_ctx *c, int param_slot, int a_slot) {
@@ -134,7 +134,7 @@ PairBlockArgs pair_block_a_args(const mmsbm_hip_ctx *c, int param_slot, int a_sl
   pa.out_mw = at.mw; pa.out_rs_m = at.rs_m; pa.out_rs_t = at.rs_t; pa.out_tail = at.tail;
   pa.bs_tiles = c->pt[0].stride; pa.bs_in = c->eta[0].stride; pa.bs_e = 0;
   pa.bs_out = at.so_m; pa.bs_out_t = at.so_t; pa.bs_partial = 0;
-  mfma_geometry(pa.dinp, pa.doutp, false, 4, c->mfma_blocks != 0, &pa.mg0, &pa.mg1);
+  mfma_geometry(pa.dinp, pa.doutp, &pa.mg0, &pa.mg1);
   return pa;
 }
 EtaPArgs eta_p_args(const mmsbm_hip_ctx *c, bool commit, int cols_per_block) {
@@ -176,7 +176,7 @@ void stage_seg(mmsbm_hip_ctx *c, bool commit, bool with_pairs, bool with_users, 
   }
   // several restart slots: a super-group of SW x G lanes per segment (seg_pass_slots_kernel)
   int sw = 1;
-  if (c->launch_slots > 1 && c->slot_waves) {
+  if (c->launch_slots > 1) {
     const int room = 64 / group_lanes(c->code_k);
     while (sw * 2 <= room && sw < c->launch_slots) sw *= 2;
   }
@@ -292,17 +292,10 @@ void stage_dense(mmsbm_hip_ctx *c) {  // T = P^T C  and the K x L slabs for p
     LaunchScope ls(c, K_DENSE, true);
     const int nb = static_cast<int>(c->lay.mv_chunks.size());
     const PairBlockArgs pa = pair_block_t_args(c);
-    // (4 x 4 blocks in the T + S launch only on request, option mfma_blocks = 2: its 128-register budget does not hold
-    // them -- C5 355 -> 390 us -- so its remainders stay padded tiles; the A launch has the room, see stage_matvec_a)
-#define MF_TS(NT_, BLK_)                                                                          \
-  do {                                                                                            \
-    allow_big_lds(pair_mfma_kernel<false, true, NT_, BLK_>, c->lds_mt);                           \
-    LAUNCH_IN(ls, (pair_mfma_kernel<false, true, NT_, BLK_>), slot_grid(c, nb), NT_, c->lds_mt, c->stream, pa, pa.tiles); \
-  } while (0)
-    const bool blk = c->mfma_blocks == 2;
-    if (c->mfma_threads == kBlock) { if (blk) MF_TS(kBlock, true); else MF_TS(kBlock, false); }
-    else { if (blk) MF_TS(kPairBlockMax, true); else MF_TS(kPairBlockMax, false); }
-#undef MF_TS
+    // (padded 16-tiles, eight waves: the 4 x 4 blocks of the A launch do not fit this launch's 128 registers -- measured,
+    // EXPERIMENTS.md -- and four waves leave one workgroup per CU)
+    allow_big_lds(pair_mfma_kernel<false, true, kPairBlockMax, false>, c->lds_mt);
+    LAUNCH_IN(ls, (pair_mfma_kernel<false, true, kPairBlockMax, false>), slot_grid(c, nb), kPairBlockMax, c->lds_mt, c->stream, pa, pa.tiles);
     ls.done();
     return;
   }
@@ -378,13 +371,8 @@ void stage_matvec_a(mmsbm_hip_ctx *c, int slot, int a_slot, bool grid = false) {
     allow_big_lds(wide_matvec_kernel<true>, lds);
     LAUNCH_IN(ls, (wide_matvec_kernel<true>), slot_grid(c, nb * subs), kBlock, lds, c->stream, pa, subs);
   } else if (c->mfma) {
-    if (c->mfma_blocks) {
-      allow_big_lds(pair_mfma_kernel<true, false, kBlock, true>, c->lds_ma);
-      LAUNCH_IN(ls, (pair_mfma_kernel<true, false, kBlock, true>), slot_grid(c, nb), kBlock, c->lds_ma, c->stream, pa, pa.tiles);
-    } else {
-      allow_big_lds(pair_mfma_kernel<true, false, kBlock, false>, c->lds_ma);
-      LAUNCH_IN(ls, (pair_mfma_kernel<true, false, kBlock, false>), slot_grid(c, nb), kBlock, c->lds_ma, c->stream, pa, pa.tiles);
-    }
+    allow_big_lds(pair_mfma_kernel<true, false, kBlock, true>, c->lds_ma);
+    LAUNCH_IN(ls, (pair_mfma_kernel<true, false, kBlock, true>), slot_grid(c, nb), kBlock, c->lds_ma, c->stream, pa, pa.tiles);
   } else if (c->quad_a) {
     const dim3 grid = slot_grid(c, std::min(nb, c->n_cus));
 #define QA(NL)                                                                                    \
@@ -394,7 +382,7 @@ void stage_matvec_a(mmsbm_hip_ctx *c, int slot, int a_slot, bool grid = false) {
   } while (0)
     const int nl = (c->lp + 3) / 4;  // dinp of the A launch = lp
     if (nl <= 8) QA(8); else if (nl <= 10) QA(10); else if (nl <= 12) QA(12);
-    else if (nl <= 13) QA(13); else if (nl <= 14) QA(14); else QA(16);
+    else if (nl <= 13) QA(13); else QA(14);   // (kQuadMaxL: 15 or 16 double2 per thread spill at 256 registers)
 #undef QA
   } else {
 #define PA_D(TL, NT, D)                                                                     \
@@ -521,15 +509,6 @@ bool use_fused(const mmsbm_hip_ctx *c) {
          (c->fused_forced || c->n_obs * c->launch_slots * (c->kp + c->lp) <= (cut ? kFusedWorkMaxSplit : kFusedWorkMax));
 }
 
-// The user pass beside the dense chain (second stream) -- an experiment that lost at every size (round 4, per iteration,
-// serial / forked, scripts/fork_time.py: C3 94.4 / 107.7 us, 3M ratings K = L = 20 296.9 / 316.0, 4M K = L = 50 910.7 /
-// 928.6, 10M K = L = 20 554.4 / 677.8, 20M x 138k x 27k 878 / 1,059, C5 2,228 / 2,328): two gather launches instead of
-// one (each with its ramp and drain, and the XCD-local lists of the two passes no longer share a grid), and a dense
-// chain that is slower, not faster, with gathers beside it.  Off unless option "fork" = 1 asks for it.
-bool use_fork(const mmsbm_hip_ctx *c) {
-  return c->fork == 1 && !c->profiling && !c->graph_mode;
-}
-
 void launch_iteration(mmsbm_hip_ctx *c, bool commit) {
   if (use_fused(c)) {
     stage_fused_pairs(c);  // (writes A of the current parameters on its way)
@@ -539,28 +518,6 @@ void launch_iteration(mmsbm_hip_ctx *c, bool commit) {
     return;
   }
   ensure_a(c);
-  if (commit && use_fork(c)) {
-    // pair pass -> T + S -> eta_p -> A on the context's stream; the user pass (theta' from theta, A of the CURRENT
-    // parameters: nothing the chain writes) on the side stream, between two events.  The next iteration -- or whatever
-    // the caller enqueues next -- waits for both.
-    if (!c->side_stream) {
-      HIP_CHECK(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
-      HIP_CHECK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-      HIP_CHECK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
-    }
-    HIP_CHECK(hipEventRecord(c->ev_fork, c->stream));       // everything before this iteration is done
-    HIP_CHECK(hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
-    stage_seg(c, commit, true, false, c->stream);
-    stage_seg(c, commit, false, true, c->side_stream);
-    HIP_CHECK(hipEventRecord(c->ev_join, c->side_stream));
-    stage_dense(c);
-    stage_eta_p(c, commit);
-    stage_matvec_a(c, c->cur ^ 1, c->cur ^ 1);
-    HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
-    c->cur ^= 1;
-    mark_a(c, true);
-    return;
-  }
   stage_seg(c, commit, true, true, c->stream);
   stage_dense(c);
   stage_eta_p(c, commit);

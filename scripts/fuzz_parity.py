@@ -66,10 +66,8 @@ while time.time() - t0 < budget:
         for mode in (2, 1, 0):
             em.set_option("lik_fast", mode)
             got = em.likelihood()
-            # (K = L = 1: the likelihood is exactly 0.  One group on a side: sum w log w and log s~ sum w nearly cancel, and the
-            # round-2 table kernel -- mode 1 -- forms the two sums separately: its error relative to the small difference was
-            # 1.6e-10 in one of 22,000 cases, K = 1, L = 8; the forms that subtract per element stay at 1e-12)
-            errs.append(abs(got - lik) / max(abs(lik), 1e-6 * n) * (0.01 if (mode == 1 and min(k, l) == 1) else 1.0))
+            # (K = L = 1: the likelihood is exactly 0; every form subtracts per element, as the reference does)
+            errs.append(abs(got - lik) / max(abs(lik), 1e-6 * n))
         rows = data[: min(n, 200)]
         errs.append(rel(em.prod_dist(rows), orc.prod_dist(rows, t, e, p)))
     bad = max(errs)

@@ -24,7 +24,7 @@ start = mm.init_params(mm.child_states[0], d_u, d_i)
 lib = _lib.load()
 print("library's choice: mfma =", ctx.get_option("mfma"), flush=True)
 outs = []
-for opts in ({"mfma": 0}, {"mfma": 1, "mfma_threads": 512}, {"mfma": 1, "mfma_threads": 256}):
+for opts in ({"mfma": 0}, {"mfma": 1}):
     for key, v in opts.items():
         ctx.set_option(key, v)
     ctx.set_params(*start)
