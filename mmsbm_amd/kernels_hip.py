@@ -12,9 +12,9 @@ the reference keeps working.  There is no CPU path behind these functions.
 
 The reference calls ``update_coefficients`` once per EM iteration with the same ``data``;
 the sorted device layout is therefore cached per training set, keyed on an EXACT digest of
-the three id columns (``core.data_key``: a 128-bit blake2b over every byte -- a few ms per
-million rows, far below the parameter transfers each call already pays), so only
-theta/eta/pr cross PCIe per call and two different training sets can never share a context.
+the three id columns (``core.data_key``: 128-bit XXH3 over every byte, 0.5 ms per million rows;
+computed beside the GPU work, see ``_run``), so only theta/eta/pr cross PCIe per call and two
+different training sets can never share a context.
 """
 from __future__ import annotations
 
@@ -35,33 +35,72 @@ except Exception as _hip_err:  # pragma: no cover - depends on the machine
 __all__ = ["compute_omegas", "update_coefficients", "prod_dist"]
 
 _CACHE_SLOTS = 2
-_cache = []  # [(fingerprint, HipEM)], most recent first
+_cache = []  # [(fingerprint, HipEM, where)], most recent first
+_pool = None  # one helper thread for the digest (made at the first call: importing stays cheap and spawn-safe)
 
 
 def _fingerprint(data, theta, eta, pr):
     return (data_key(data), theta.shape, eta.shape, pr.shape)
 
 
-def _context(data, theta, eta, pr):
+def _where(data):
+    """Which array OBJECT this is and where its bytes live -- NOT an identity of the data (an array can be rewritten in
+    place): only a hint about which cached context to try first while the exact digest is being computed."""
+    d = np.asarray(data)
+    return (id(data), d.__array_interface__["data"][0], d.shape, d.strides, d.dtype.str)
+
+
+def _checked(theta, eta, pr):
     theta, eta, pr = (np.asarray(a, dtype=np.float64) for a in (theta, eta, pr))
     if theta.ndim != 2 or eta.ndim != 2 or pr.ndim != 3:
         raise ValueError("theta (U,K), eta (I,L) and pr (K,L,R) expected")
     if pr.shape[0] != theta.shape[1] or pr.shape[1] != eta.shape[1]:
         raise ValueError("pr must have shape (K, L, R) matching theta (U,K) and eta (I,L)")
-    key = _fingerprint(data, theta, eta, pr)
-    for j, (k, ctx) in enumerate(_cache):
+    return theta, eta, pr
+
+
+def _context(data, theta, eta, pr, key=None):
+    """The context of exactly this training set and these shapes (built if need be), parameters uploaded."""
+    theta, eta, pr = _checked(theta, eta, pr)
+    key = key or _fingerprint(data, theta, eta, pr)
+    for j, (k, ctx, _) in enumerate(_cache):
         if k == key:
             if j:
                 _cache.insert(0, _cache.pop(j))
+            _cache[0] = (key, ctx, _where(data))
             break
     else:
         ctx = HipEM(data, theta.shape[1], eta.shape[1], n_users=theta.shape[0],
                     n_items=eta.shape[0], n_ratings=pr.shape[2])
-        _cache.insert(0, (key, ctx))
+        _cache.insert(0, (key, ctx, _where(data)))
         while len(_cache) > _CACHE_SLOTS:
             _cache.pop()[1].close()
     ctx.set_params(theta, eta, pr)
     return ctx
+
+
+def _run(data, theta, eta, pr, op):
+    """``op(context)`` on the context of ``data``.  The reference passes the SAME array on every iteration
+    (src/mmsbm.py:244): when the most recent context was built for an array object at this address and of this shape,
+    the call goes ahead on it at once -- upload, kernels, download; ctypes releases the GIL -- while a helper thread
+    computes the exact digest of the id columns (0.5 ms per million rows, a fifth of the call); the result is handed
+    out only if the digest confirms the context, otherwise it is dropped and the call is repeated on the right one.
+    Two different training sets still never share a context; the digest just no longer waits in front of the GPU."""
+    global _pool
+    theta, eta, pr = _checked(theta, eta, pr)
+    if _cache and _cache[0][2] == _where(data) and _cache[0][0][1:] == (theta.shape, eta.shape, pr.shape):
+        if _pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            _pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="mmsbm-digest")
+        digest = _pool.submit(data_key, data)
+        key0, ctx = _cache[0][0], _cache[0][1]
+        ctx.set_params(theta, eta, pr)
+        out = op(ctx)
+        key = (digest.result(), theta.shape, eta.shape, pr.shape)
+        if key == key0:
+            return out
+        return op(_context(data, theta, eta, pr, key))   # (the array was rewritten in place: another training set)
+    return op(_context(data, theta, eta, pr))
 
 
 def clear_cache():
@@ -72,12 +111,12 @@ def clear_cache():
 
 def compute_omegas(data, theta, eta, pr):
     """Unnormalised responsibilities, shape (N, K, L); src/kernels_numpy.py:21-36."""
-    return _context(data, theta, eta, pr).compute_omegas()
+    return _run(data, theta, eta, pr, lambda ctx: ctx.compute_omegas())
 
 
 def update_coefficients(data, theta, eta, pr):
     """(n_theta, n_eta, n_pr) unnormalised numerators; src/kernels_numpy.py:43-79."""
-    return _context(data, theta, eta, pr).update_coefficients()
+    return _run(data, theta, eta, pr, lambda ctx: ctx.update_coefficients())
 
 
 def prod_dist(data, theta, eta, pr):
@@ -88,5 +127,4 @@ def prod_dist(data, theta, eta, pr):
     d = np.asarray(data)
     fake = np.zeros((d.shape[0], 3), dtype=np.int64)
     fake[:, :2] = d[:, :2]
-    ctx = _context(fake, theta, eta, pr)
-    return ctx.prod_dist(d)
+    return _context(fake, theta, eta, pr).prod_dist(d)

@@ -267,3 +267,64 @@ def test_host_class_sampling8_c5_shape_batches_by_free_memory(hip):
             assert np.array_equal(solo.results[j][nm], mm.results[i][nm]), (i, nm)
     assert mm.best_by_likelihood == int(np.argmax([r["likelihood"] for r in mm.results]))
     mm._release(); solo._release()
+
+
+# ---- the reference's DEFAULT run length (iterations=400, src/mmsbm.py:63-72) on north_star's own config and on the
+# ---- matrix-core kernel family: fixtures made by RUNNING THE REFERENCE (tests/golden/make_golden.py: g8, g9) ----------
+def _long_run_against_the_reference(hip, name, expect):
+    """Restart 0 of MMSBM(k, l, seed=0) from the reference's own start through the library's own kernel choice, against
+    the reference's snapshots after 100, 200 and 400 iterations: sampled theta / eta entries and ALL of p element-wise
+    (1e-6; north_star's bar is 1e-5) and in max-norm (1e-9), the column sums, the likelihood (1e-9) and the argmax
+    prediction of every training row whose top-2 gap in the reference exceeds 1e-9.  Returns the worst element-wise
+    error per snapshot (printed with -s; quoted in DESIGN.md)."""
+    from conftest import elem_rel_err, load_golden
+    g = load_golden(name)
+    n, u, i, r, k, l = (int(g[x]) for x in ("n", "u", "i", "r", "k", "l"))
+    train = orc.synthetic_triples(n, u, i, r, int(g["gen_seed"]))
+    assert np.array_equal(train.sum(0), g["train_sum"]) and np.array_equal(train[:64], g["train_head"])
+    mm = hip.MMSBM(k, l, iterations=400, seed=int(g["model_seed"]))
+    mm._prepare_objects(train)
+    ctx = mm._ctx(0)
+    for option, value in expect.items():            # the library's OWN choice of kernels, not a forced one
+        assert ctx.get_option(option) == value, (option, ctx.get_option(option))
+    d_u, d_i = ctx.degrees()
+    theta0, eta0, pr0 = mm.init_params(mm.child_states[0], d_u, d_i)
+    assert np.array_equal(theta0[g["ut"], g["kt"]], g["theta_s_0"]) and np.array_equal(eta0[g["ie"], g["le"]], g["eta_s_0"])
+    assert np.array_equal(pr0, g["pr_0"])             # the reference's own start, bit for bit
+    ctx.set_params(theta0, eta0, pr0)
+    snaps = [int(x) for x in g["snapshots"]]
+    assert snaps == [100, 200, 400]
+    done, worst = 0, {}
+    for j, it in enumerate(snaps):
+        ctx.iterate(it - done)
+        done = it
+        t, e, p = ctx.get_params()
+        errs = []
+        for got, want, nm in ((t[g["ut"], g["kt"]], g[f"theta_s_{it}"], "theta entries"),
+                              (e[g["ie"], g["le"]], g[f"eta_s_{it}"], "eta entries"), (p, g[f"pr_{it}"], "p")):
+            assert rel_err(got, want) < 1e-9, (nm, it, rel_err(got, want))
+            assert_elementwise(got, want, f"{name}: {nm} after {it} iterations", rtol=1e-6)
+            errs.append(elem_rel_err(got, want))
+        assert rel_err(t.sum(0), g[f"theta_colsum_{it}"]) < 1e-9 and rel_err(e.sum(0), g[f"eta_colsum_{it}"]) < 1e-9
+        assert ctx.likelihood() == pytest.approx(float(g["likelihood_at"][j]), rel=1e-9)
+        clear = np.unpackbits(g[f"clear_{it}"])[:len(train)].astype(bool)
+        assert clear.mean() > 0.99
+        assert np.array_equal(np.argmax(ctx.prod_dist(train), 1)[clear], g[f"argmax_{it}"][clear]), it
+        worst[it] = max(errs)
+    print(f"{name}: worst element-wise relative error vs the reference after 100 / 200 / 400 iterations: "
+          + " / ".join(f"{worst[it]:.1e}" for it in snaps))
+    return worst
+
+
+def test_c3_400_iterations_against_the_reference_on_the_headline_kernels(hip):
+    """north_star's parity clause on north_star's own config at the reference's own default: C3 (1M ratings, 100k x 20k,
+    R = 5, K = L = 20, seed 0), 400 iterations, the four-launch kernels the bench line measures (seg_pass_kernel<8,4,4>,
+    pair_block_kernel, eta_p_kernel<8,4>) -- against the REAL reference's run (fixture g8_c3_400: 95 minutes of it)."""
+    _long_run_against_the_reference(hip, "g8_c3_400", {"launches": 4.0, "mfma": 0.0})
+
+
+def test_k50_400_iterations_against_the_reference_on_the_matrix_cores(hip):
+    """The same for the kernel family BASELINE's config 5 runs (K = L = 50, R = 10: pair_mfma_kernel on both pair-stage
+    launches, seg_pass_kernel<16,4,4>, lik_wave_kernel) on a C5-shaped problem the dense reference can hold (100k ratings
+    of 10k users x 1k items; fixture g9_k50_400)."""
+    _long_run_against_the_reference(hip, "g9_k50_400", {"launches": 4.0, "mfma": 1.0})

@@ -1678,6 +1678,19 @@ def test_level1_cache_never_serves_another_training_set(hip):
     assert len(kernels_hip._cache) == 2                    # two contexts: a miss, not a stale hit
     kernels_hip.update_coefficients(a, theta, eta, pr)
     assert len(kernels_hip._cache) == 2                    # ... and the same data again is a hit
+    # Round 5: a call on the array object of the most recent context goes ahead on that context while the digest is
+    # computed beside it -- so an array REWRITTEN IN PLACE (same object, same address, another training set) is the
+    # case the digest has to catch: the speculative result is dropped, the call repeated on the right context
+    want_a = orc.update_coefficients(a, theta, eta, pr)
+    for got, w in zip(kernels_hip.update_coefficients(a, theta, eta, pr), want_a):   # (the fast path itself)
+        assert rel_err(got, w) < TOL_STEP
+    a[[1, 2]] = a[[2, 1]]                                  # now `a` holds what `b` holds
+    a[7] = a[9]
+    want_new = orc.update_coefficients(a, theta, eta, pr)
+    assert rel_err(want_new[0], want_a[0]) > 1e-6          # (a training set with other numerators)
+    for got, w in zip(kernels_hip.update_coefficients(a, theta, eta, pr), want_new):
+        assert rel_err(got, w) < TOL_STEP
+    assert np.array_equal(kernels_hip.compute_omegas(a, theta, eta, pr), orc.compute_omegas(a, theta, eta, pr))
     kernels_hip.clear_cache()
 
 
