@@ -20,7 +20,8 @@ constexpr int kRedThreads = kRedCols * kRedRows, kRedBatch = 5;  // 64 x 5 = 320
 // ROWS = rows of the reduction pattern (which fixes the association order of the sum over slabs); NTY = rows of
 // threads that carry it out, ROWS / NTY pattern rows each.  eta_p_kernel: 64 / 64.  tail_fused_kernel
 // (fused_small.hpp) has 256 threads: 64 / 16 -- the same sums in the same order, four rounds of loads per thread.
-template <int ROWS, int NTY = ROWS, int BATCH = kRedBatch>
+// RG = ratings per pass (every rating's sum is its own: the grouping does not touch the arithmetic).
+template <int ROWS, int NTY = ROWS, int BATCH = kRedBatch, int RG = kRedGroup>
 __device__ __forceinline__ void p_update_block(
     double (*red)[ROWS][kRedCols], int block, const double *__restrict__ partial,
     const int32_t *__restrict__ chunk_off, const double *__restrict__ p_old,
@@ -32,16 +33,16 @@ __device__ __forceinline__ void p_update_block(
   const int col = block * kRedCols + tx;
   const bool ok = col < kl;
   double tot_all = 0.0;  // meaningful for ty == 0
-  for (int r0 = 0; r0 < n_ratings; r0 += kRedGroup) {
-    const int nr = min(kRedGroup, n_ratings - r0);
-    int c0[kRedGroup], c1[kRedGroup];
-    double s[kRedGroup], pold[kRedGroup];
+  for (int r0 = 0; r0 < n_ratings; r0 += RG) {
+    const int nr = min(RG, n_ratings - r0);
+    int c0[RG], c1[RG];
+    double s[RG], pold[RG];
     int longest = 0;
 #pragma unroll
-    for (int j = 0; j < kRedGroup; ++j)  // (needed at the very end: fetched up front, off the tail of the chain)
+    for (int j = 0; j < RG; ++j)  // (needed at the very end: fetched up front, off the tail of the chain)
       pold[j] = (ty == 0 && ok && j < nr) ? p_old[static_cast<size_t>(r0 + j) * kl + col] : 0.0;
 #pragma unroll
-    for (int j = 0; j < kRedGroup; ++j) {
+    for (int j = 0; j < RG; ++j) {
       const int r = min(r0 + j, n_ratings - 1);
       c0[j] = chunk_off[r];
       c1[j] = (j < nr) ? chunk_off[r + 1] : c0[j];
@@ -52,18 +53,18 @@ __device__ __forceinline__ void p_update_block(
     // (a pattern row adds its slabs c0 + vty, + ROWS, + 2 ROWS, ... one after the other: BATCH only says how many
     // of those loads are in flight together, it does not touch the order of the sum)
     constexpr int VR = ROWS / NTY;  // pattern rows per thread row: their loads share a round too
-    double sv[VR][kRedGroup];
+    double sv[VR][RG];
 #pragma unroll
     for (int m = 0; m < VR; ++m)
 #pragma unroll
-      for (int j = 0; j < kRedGroup; ++j) sv[m][j] = 0.0;
+      for (int j = 0; j < RG; ++j) sv[m][j] = 0.0;
     if (ok) {
       for (int off = 0; off < longest; off += ROWS * BATCH) {
-        double v[VR][kRedGroup][BATCH];
+        double v[VR][RG][BATCH];
 #pragma unroll
         for (int m = 0; m < VR; ++m)
 #pragma unroll
-          for (int j = 0; j < kRedGroup; ++j)
+          for (int j = 0; j < RG; ++j)
 #pragma unroll
             for (int i = 0; i < BATCH; ++i) {  // every rating's slab loads issued together
               const int c = c0[j] + off + (ty + m * NTY) + i * ROWS;
@@ -72,7 +73,7 @@ __device__ __forceinline__ void p_update_block(
 #pragma unroll
         for (int m = 0; m < VR; ++m)
 #pragma unroll
-          for (int j = 0; j < kRedGroup; ++j)
+          for (int j = 0; j < RG; ++j)
 #pragma unroll
             for (int i = 0; i < BATCH; ++i) sv[m][j] += v[m][j][i];
       }
@@ -80,13 +81,13 @@ __device__ __forceinline__ void p_update_block(
 #pragma unroll
     for (int m = 0; m < VR; ++m)
 #pragma unroll
-      for (int j = 0; j < kRedGroup; ++j) red[j][ty + m * NTY][tx] = sv[m][j];
+      for (int j = 0; j < RG; ++j) red[j][ty + m * NTY][tx] = sv[m][j];
     STAMP(2);
     __syncthreads();
     STAMP(3);
     if (ty < 8) {  // ROWS rows -> 8 partial sums (fixed order)
 #pragma unroll
-      for (int j = 0; j < kRedGroup; ++j) {
+      for (int j = 0; j < RG; ++j) {
         double t = 0.0;
 #pragma unroll
         for (int i = 0; i < ROWS / 8; ++i) t += red[j][ty * (ROWS / 8) + i][tx];
@@ -96,12 +97,12 @@ __device__ __forceinline__ void p_update_block(
     __syncthreads();
     if (ty < 8) {
 #pragma unroll
-      for (int j = 0; j < kRedGroup; ++j) red[j][ty][tx] = s[j];
+      for (int j = 0; j < RG; ++j) red[j][ty][tx] = s[j];
     }
     __syncthreads();
     if (ty == 0 && ok) {
 #pragma unroll
-      for (int j = 0; j < kRedGroup; ++j) {
+      for (int j = 0; j < RG; ++j) {
         if (j < nr) {
           double tot = red[j][0][tx];
 #pragma unroll
@@ -117,12 +118,12 @@ __device__ __forceinline__ void p_update_block(
     STAMP(4);
     __syncthreads();
     STAMP(5);
-    if (n_ratings <= kRedGroup) {  // common case: normalise straight from registers
+    if (n_ratings <= RG) {  // common case: normalise straight from registers
       if (ty == 0 && ok && normalize) {
         const double den = (tot_all == 0.0) ? 1.0 : tot_all;
         const int k = col / lp, l = col % lp;
 #pragma unroll
-        for (int j = 0; j < kRedGroup; ++j) {
+        for (int j = 0; j < RG; ++j) {
           if (j < nr) {
             const double v = s[j] / den;
             p_new[static_cast<size_t>(j) * kl + col] = v;
@@ -251,6 +252,29 @@ struct EtaPArgs {
   size_t bs_partial, bs_p, bs_t, bs_eta;  // restart slots (blockIdx.y): table strides
   const int32_t *item_grid;               // [n_items][n_ratings] pair id or -1 (dense data), else null
 };
+
+// The same two roles in workgroups of 256 threads, for launches of many rounds (BASELINE's config 5: 100,000 items).
+// With 1,024 threads and 126 registers a CU holds ONE workgroup: 1,563 item_sum workgroups are 6.1 rounds, paid as 7, and
+// the p_update workgroups take a CU each while they wait out their slab loads.  Four waves per workgroup are dealt
+// wave by wave: the last round is a 24th of the launch, not a 7th.  p_update as tail_fused_kernel runs it (the
+// 64-row pattern carried by 16 rows of threads: the same sums in the same order), two ratings per pass so that its
+// registers and the 16 KB of LDS leave room for seven workgroups beside it.  Results are bitwise those of eta_p_kernel.
+constexpr int kRedGroupW4 = 2;
+template <int G, int VEC>
+__global__ __launch_bounds__(kBlock) void eta_p_w4_kernel(EtaPArgs a) {
+  __shared__ double red[kRedGroupW4][kRedRows][kRedCols];
+  const size_t slot = blockIdx.y;
+  if (a.abl & (static_cast<int>(blockIdx.x) < a.nb_p ? 64 : 128)) return;  // tuning aid: skip a role
+  if (static_cast<int>(blockIdx.x) < a.nb_p)
+    p_update_block<kRedRows, kBlock / kRedCols, 2, kRedGroupW4>(red, blockIdx.x, a.partial + slot * a.bs_partial, a.chunk_off,
+                                                                a.p_old + slot * a.bs_p, a.p_new + slot * a.bs_p,
+                                                                a.pt_new + slot * a.bs_p, a.npr + slot * a.bs_p, a.n_ratings,
+                                                                a.kp, a.lp, a.normalize);
+  else
+    item_sum_block<G, VEC>(blockIdx.x - a.nb_p, a.ttab + slot * a.bs_t, a.item_off, a.item_pairs,
+                           a.item_deg, a.eta + slot * a.bs_eta, a.eta_new + slot * a.bs_eta,
+                           a.n_items, a.lp, a.normalize, a.item_grid, a.n_ratings);
+}
 
 template <int G, int VEC>
 __global__ __launch_bounds__(kRedThreads) void eta_p_kernel(EtaPArgs a) {
