@@ -117,6 +117,86 @@ void run(const char *name, const double *x, const double *e, const int *ids, dou
          name, ROWS, NT, lds / 1024, per_cu, grid, mf, tout ? "stored" : "-     ", us, bytes / us / 1e6);
 }
 
+
+// A ring of NB LDS buffers filled by LDS-DMA DIST units ahead, one workgroup per CU: a unit's rows were asked for DIST
+// units ago, so the wait in front of a unit is a COUNTED s_waitcnt (everything but the younger DMA and T-store
+// instructions) and normally finds them there; the T rows of a unit are stored without anyone waiting for them.
+template <int ROWS, int NT, int NB>
+__global__ __launch_bounds__(NT) void ring(const double *__restrict__ xtab, const double *__restrict__ etab,
+                                           const int *__restrict__ ids, double *__restrict__ out, int n_units, int mf,
+                                           double *__restrict__ tout) {
+  extern __shared__ double lds[];
+  constexpr int TAB = ROWS * kW, BUF = 2 * TAB, CH = ROWS * kRowChunks, NW = NT / 64, DIST = NB - 1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  d4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+  const int u0 = blockIdx.x, ustep = gridDim.x;
+  auto fetch_dma = [xtab, etab, ids, wave, lane](int u, double *buf) {
+    for (int i = wave; i * 64 < CH; i += NW) {
+      const int c = i * 64 + lane;
+      const int r = c / kRowChunks, cc = c - r * kRowChunks;
+      __builtin_amdgcn_global_load_lds(GPTR(xtab + (size_t(u) * ROWS + r) * kW + 2 * cc), LPTR(buf + i * 128), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(GPTR(etab + size_t((size_t(u) * ROWS + r) % 100000) * kW + 2 * cc   /* (the real kernel has its item ids in LDS: no vector-memory load in front of the DMA) */), LPTR(buf + TAB + i * 128), 16, 0, 0);
+    }
+  };
+  // vector-memory instructions this wave issues per unit: D loads (LDS-DMA) and S stores (T rows)
+  const int D = 2 * ((CH / 64 - wave + NW - 1) / NW), S = tout ? (ROWS * kW - wave * 64 + NT - 1) / NT : 0;
+  const int younger = (DIST - 1) * D + DIST * S;   // issued after the DMA of the unit about to be used
+  static_assert(CH % 64 == 0, "whole wave-instructions");
+  for (int d = 0; d < DIST; ++d)
+    if (u0 + d * ustep < n_units) fetch_dma(u0 + d * ustep, lds + d * BUF);
+  int k = 0;
+  for (int u = u0; u < n_units; u += ustep, ++k) {
+    double *buf = lds + (k % NB) * BUF;
+    if (k >= DIST && u + DIST * ustep < n_units) {   // steady state: a counted wait (the immediate must be a constant)
+      switch (younger) {
+#define WCASE(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+        WCASE(0) WCASE(1) WCASE(2) WCASE(3) WCASE(4) WCASE(5) WCASE(6) WCASE(7) WCASE(8) WCASE(9) WCASE(10) WCASE(11) WCASE(12)
+        WCASE(13) WCASE(14) WCASE(15) WCASE(16) WCASE(17) WCASE(18) WCASE(19) WCASE(20) WCASE(21) WCASE(22) WCASE(23) WCASE(24)
+#undef WCASE
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      }
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // a workgroup's first and last units: the count of younger instructions is another
+    }
+    // every wave's share of this unit has arrived; the buffer of the unit before is free.  (A bare s_barrier:
+    // __syncthreads() carries a fence for which the compiler waits out EVERY vector-memory instruction -- the younger
+    // DMA too -- which is exactly the serialisation the ring is there to avoid.)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (u + DIST * ustep < n_units) fetch_dma(u + DIST * ustep, lds + ((k + DIST) % NB) * BUF);
+    const int li = lane & 15, lk = lane >> 4;
+    for (int s = 0; s < mf; s += 2) {
+      const int row = (4 * (s >> 1) + lk) % ROWS;
+      const double a = buf[row * kW + li + 16 * (wave & 1)], b = buf[TAB + row * kW + li + 16 * ((wave >> 1) & 1)];
+      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(b, a, acc1, 0, 0, 0);
+    }
+    if (tout) {
+      for (int e = tid; e < ROWS * kW; e += NT) tout[size_t(u) * ROWS * kW + e] = acc0[e & 3];
+    }
+  }
+  out[size_t(blockIdx.x) * NT + tid] = acc0[0] + acc0[1] + acc0[2] + acc0[3] + acc1[0] + acc1[1] + acc1[2] + acc1[3];
+}
+
+template <int ROWS, int NT, int NB>
+void run_ring(const char *name, const double *x, const double *e, const int *ids, double *out, int n_units, int mfma_pct, size_t lds, int grid,
+              double *tout) {
+  const int mf = 464 * ROWS / 64 / (NT / 64) * mfma_pct / 100 / 2 * 2;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void *>(ring<ROWS, NT, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+  int per_cu = 0;
+  CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ring<ROWS, NT, NB>, NT, lds));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int i = 0; i < 2; ++i) ring<ROWS, NT, NB><<<grid, NT, lds>>>(x, e, ids, out, n_units, mf, tout);
+  CK(hipEventRecord(e0));
+  const int reps = 5;
+  for (int i = 0; i < reps; ++i) ring<ROWS, NT, NB><<<grid, NT, lds>>>(x, e, ids, out, n_units, mf, tout);
+  CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+  const double us = ms * 1000 / reps, bytes = double(n_units) * ROWS * kW * 8 * (tout ? 3 : 2);
+  printf("%-28s %2d rows/unit, %3d threads, %3zu KB LDS (%d per CU), grid %5d, %3d mfma per wave and unit, T rows %s: %7.1f us  %5.2f TB/s\n",
+         name, ROWS, NT, lds / 1024, per_cu, grid, mf, tout ? "stored" : "-     ", us, bytes / us / 1e6);
+}
+
 int main() {
   // ---- A
   {
@@ -165,6 +245,15 @@ int main() {
     run<true, 32, 256>("LDS-DMA, two buffers", x, e, ids, out, 2 * n_units64, mfma, 2 * b32 + tile, 2 * cus, t);
     run<true, 32, 512>("LDS-DMA, two, no tile", x, e, ids, out, 2 * n_units64, mfma, 2 * b32, 3 * cus, t);
     run<true, 32, 256>("LDS-DMA, two, no tile", x, e, ids, out, 2 * n_units64, mfma, 2 * b32, 3 * cus, t);
+    // rings: one workgroup per CU, rows asked for two (three) units ahead, counted waits
+    run_ring<32, 512, 3>("LDS-DMA ring of 3", x, e, ids, out, 2 * n_units64, mfma ? 100 : 0, 3 * b32 + tile, cus, t);
+    run_ring<32, 512, 4>("LDS-DMA ring of 4", x, e, ids, out, 2 * n_units64, mfma ? 100 : 0, 4 * b32 + tile, cus, t);
+    run_ring<32, 1024, 4>("LDS-DMA ring of 4", x, e, ids, out, 2 * n_units64, mfma ? 100 : 0, 4 * b32 + tile, cus, t);
+    run_ring<64, 512, 2>("LDS-DMA ring of 2 (counted)", x, e, ids, out, n_units64, mfma ? 100 : 0, 2 * b64 + tile, cus, t);
+    if (mfma) {   // ... and with the matrix work of unpadded tiles (the 4 x 4 blocks fit 256 registers): 77 %
+      run_ring<32, 512, 3>("ring of 3, unpadded tiles", x, e, ids, out, 2 * n_units64, 77, 3 * b32 + tile, cus, t);
+      run_ring<32, 512, 4>("ring of 4, unpadded tiles", x, e, ids, out, 2 * n_units64, 77, 4 * b32 + tile, cus, t);
+    }
   }
   return 0;
 }
