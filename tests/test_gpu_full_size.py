@@ -271,7 +271,7 @@ def test_host_class_sampling8_c5_shape_batches_by_free_memory(hip):
 
 # ---- the reference's DEFAULT run length (iterations=400, src/mmsbm.py:63-72) on north_star's own config and on the
 # ---- matrix-core kernel family: fixtures made by RUNNING THE REFERENCE (tests/golden/make_golden.py: g8, g9) ----------
-def _long_run_against_the_reference(hip, name, expect):
+def _long_run_against_the_reference(hip, name, expect, min_clear=0.99):
     """Restart 0 of MMSBM(k, l, seed=0) from the reference's own start through the library's own kernel choice, against
     the reference's snapshots after 100, 200 and 400 iterations: sampled theta / eta entries and ALL of p element-wise
     (1e-6; north_star's bar is 1e-5) and in max-norm (1e-9), the column sums, the likelihood (1e-9) and the argmax
@@ -308,7 +308,7 @@ def _long_run_against_the_reference(hip, name, expect):
         assert rel_err(t.sum(0), g[f"theta_colsum_{it}"]) < 1e-9 and rel_err(e.sum(0), g[f"eta_colsum_{it}"]) < 1e-9
         assert ctx.likelihood() == pytest.approx(float(g["likelihood_at"][j]), rel=1e-9)
         clear = np.unpackbits(g[f"clear_{it}"])[:len(train)].astype(bool)
-        assert clear.mean() > 0.99
+        assert clear.mean() > min_clear, clear.mean()
         assert np.array_equal(np.argmax(ctx.prod_dist(train), 1)[clear], g[f"argmax_{it}"][clear]), it
         worst[it] = max(errs)
     print(f"{name}: worst element-wise relative error vs the reference after 100 / 200 / 400 iterations: "
@@ -327,4 +327,5 @@ def test_k50_400_iterations_against_the_reference_on_the_matrix_cores(hip):
     """The same for the kernel family BASELINE's config 5 runs (K = L = 50, R = 10: pair_mfma_kernel on both pair-stage
     launches, seg_pass_kernel<16,4,4>, lik_wave_kernel) on a C5-shaped problem the dense reference can hold (100k ratings
     of 10k users x 1k items; fixture g9_k50_400)."""
-    _long_run_against_the_reference(hip, "g9_k50_400", {"launches": 4.0, "mfma": 1.0})
+    # (50 x 50 groups on 100k ratings: 3 % of the rows end in an exact tie of their two best ratings in the reference itself)
+    _long_run_against_the_reference(hip, "g9_k50_400", {"launches": 4.0, "mfma": 1.0}, min_clear=0.95)
