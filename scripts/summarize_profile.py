@@ -19,7 +19,8 @@ def short(name):
                     ("pair_block_kernel<true", "pair_block_kernel(A)"), ("pair_quad_a_kernel", "pair_block_kernel(A)"),
                     # (K x L > 1024: the same two launches run pair_mfma_kernel; full_name keeps the kernel's own name)
                     ("pair_mfma_kernel<false", "pair_block_kernel(T+S)"), ("pair_mfma_kernel<true", "pair_block_kernel(A)"),
-                    ("eta_p_kernel", "eta_p_kernel"), ("pairs_fused_kernel", "pairs_fused_kernel"), ("tail_fused_kernel", "tail_fused_kernel"),
+                    ("eta_p_kernel", "eta_p_kernel"), ("eta_p_w4_kernel", "eta_p_kernel"),   # (many rounds: the 256-thread form of the same stage)
+                    ("pairs_fused_kernel", "pairs_fused_kernel"), ("tail_fused_kernel", "tail_fused_kernel"),
                     ("lik_wave_kernel", "lik_wave_kernel"), ("lik_lane_kernel", "lik_lane_kernel"),
                     ("seg_combine_both_kernel", "seg_combine_both_kernel"), ("theta_log_pairs_kernel", "theta_log_pairs_kernel"),
                     ("seg_combine_small_kernel", "seg_combine_small_kernel"),

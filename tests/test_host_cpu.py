@@ -392,3 +392,13 @@ def test_encoder_threaded_columns_match_the_sequential_path():
     for j in range(3):
         ids, labels = enc_mod._factorize_as_str(df.iloc[:, j].to_numpy())
         assert np.array_equal(got[:, j], ids) and enc.labels[j].tolist() == labels.tolist()
+
+
+def test_result_shapes_from_the_training_set_also_an_empty_one():
+    """restarts.result_shapes: every rank derives the shapes of a restart's theta / eta / pr from the training triples
+    (no collective carries them); an empty training set gives empty tables instead of an exception."""
+    from mmsbm_amd import restarts
+    model = MMSBM(3, 4, iterations=1, sampling=1, seed=0)
+    train = np.array([[0, 0, 0], [2, 1, 2], [1, 4, 2]], dtype=np.int64)
+    assert restarts.result_shapes(model, train) == ((3, 3), (5, 4), (3, 4, 2))    # (rating 1 never occurs: two rating values)
+    assert restarts.result_shapes(model, np.zeros((0, 3), dtype=np.int64)) == ((0, 3), (0, 4), (3, 4, 0))
