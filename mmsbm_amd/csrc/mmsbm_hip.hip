@@ -399,6 +399,26 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
       HIP_CHECK(hipStreamSynchronize(s));  // `grid` is a local
     }
     c->mv_chunks.upload(c->lay.mv_chunks, s);
+    // The A launch of the matrix-core pair stage writes rows only -- nothing ties its workgroups to the T + S launch's
+    // slabs -- so it walks the same units in runs of its own length, chosen so that its last round of workgroups is
+    // (nearly) full (balanced_run_units; C5: runs of 7 instead of 8 units).  Same rows, bit for bit.
+    std::vector<mmsbm::Chunk> a_runs;
+    if (c->mfma && c->n_pairs > 0) {
+      int per_cu = 0;
+      allow_big_lds(pair_mfma_kernel<true, false, kBlock, true>, c->lds_ma);
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pair_mfma_kernel<true, false, kBlock, true>, kBlock, c->lds_ma) != hipSuccess || per_cu < 1) per_cu = 1;
+      const int now = c->mv_chunk_pairs / kUnitPairs;
+      int a_units = balanced_run_units(c->lay.rating_off, per_cu * c->n_cus, std::max(2, now / 2), std::min(2 * now, kMfmaChunkPairs / kUnitPairs));
+      if (const char *e = std::getenv("MMSBM_HIP_A_UNITS")) a_units = std::min(std::max(1, std::atoi(e)), kMfmaChunkPairs / kUnitPairs);  // (tests)
+      if (a_units != now) {
+        mmsbm::Layout tmp;   // (only the fields build_mv_chunks reads and writes)
+        tmp.n_ratings = c->lay.n_ratings; tmp.rating_off = c->lay.rating_off;
+        mmsbm::build_mv_chunks(tmp, a_units * kUnitPairs);
+        a_runs = tmp.mv_chunks;
+        c->a_chunks.upload(a_runs, s);
+        c->n_a_chunks = static_cast<int>(a_runs.size());
+      }
+    }
     c->lik_units.upload(units64, s);
     c->mv_chunk_off.upload(c->lay.mv_chunk_off, s);
     c->pair_items.upload(c->lay.pair_work.items, s);
@@ -1276,6 +1296,7 @@ int mmsbm_hip_get_option(const mmsbm_hip_ctx *ctx, const char *name, double *val
     else if (key == "ranges_users") *value = ctx->ranges_users;   // ranges per pass (1 = off)
     else if (key == "chunk_pairs") *value = ctx->mv_chunk_pairs;   // read-only: pairs per pair-stage workgroup at most
     else if (key == "n_chunks") *value = ctx->n_chunks;            // read-only: pair-stage workgroups (= slabs), padding included
+    else if (key == "a_chunks") *value = ctx->n_a_chunks;   // read-only: workgroups of the matrix-core A launch when it walks runs of its own (0: the T + S launch's)
     else if (key == "items_pairs") *value = static_cast<double>(ctx->lay.pair_work.items.size());
     else if (key == "items_users") *value = static_cast<double>(ctx->lay.user_work.items.size());
     else if (key == "splits_pairs") *value = static_cast<double>(ctx->lay.pair_work.splits.size());  // read-only: segments cut into pieces

@@ -256,6 +256,27 @@ void stage_seg(mmsbm_hip_ctx *c, bool commit, bool with_pairs, bool with_users, 
   ls.done();
 }
 
+// Units per workgroup for a launch whose workgroups each walk a run of 64-pair units of one rating, `slots` of them
+// resident at a time: the launch lasts rounds x (units + a prologue of ~0.6 unit-times: the tile into LDS, the item ids,
+// the first rows' latency -- measured at C5, EXPERIMENTS.md), and rounds is an INTEGER: C5's 15,616 units in runs of 8
+// are 1,952 workgroups = 2.54 rounds of 768, paid as 3 (24 unit-times); in runs of 7 they are 2.92 rounds, also 3 (21).
+// Every rating's run count is rounded up to a multiple of 8 as in build_mv_chunks.
+inline int balanced_run_units(const std::vector<int32_t> &rating_off, int slots, int lo, int hi) {
+  int best = hi;
+  double best_cost = 1e300;
+  for (int u = hi; u >= lo; --u) {
+    long long wgs = 0;
+    for (size_t r = 0; r + 1 < rating_off.size(); ++r) {
+      const long long units = (rating_off[r + 1] - rating_off[r] + kUnitPairs - 1) / kUnitPairs;
+      const long long runs = (units + u - 1) / u;
+      wgs += rating_off.size() > 2 ? (runs + 7) / 8 * 8 : runs;
+    }
+    const double cost = static_cast<double>((wgs + slots - 1) / std::max(slots, 1)) * (u + 0.6);
+    if (cost < best_cost * 0.97) { best_cost = cost; best = u; }   // (longer runs win ties: fewer prologues)
+  }
+  return best;
+}
+
 bool mfma_possible(const mmsbm_hip_ctx *c) {
   return !c->wide && c->kp <= kMfmaMaxDim && c->lp <= kMfmaMaxDim && c->lds_mt <= kLdsMax && c->lds_ma <= kLdsMax;
 }
@@ -362,10 +383,14 @@ void stage_eta_p(mmsbm_hip_ctx *c, bool commit) {  // eta_new ; p_new, pT_new, r
 // A[q,:] from (eta, pT) of parameter slot `slot` into atab[a_slot] -- or, with `grid` set, the same
 // mat-vec over every (item, rating) combination into the plain table btab (prod_dist / predict)
 void stage_matvec_a(mmsbm_hip_ctx *c, int slot, int a_slot, bool grid = false) {
-  const int nb = grid ? c->grid_n_chunks : static_cast<int>(c->lay.mv_chunks.size());
+  int nb = grid ? c->grid_n_chunks : static_cast<int>(c->lay.mv_chunks.size());
   if (nb == 0) return;
   LaunchScope ls(c, K_MATVEC_A, true);
   PairBlockArgs pa = pair_block_a_args(c, slot, a_slot);
+  if (!grid && c->mfma && c->n_a_chunks > 0) {  // the same units in runs of its own (create(): balanced_run_units)
+    pa.chunks = c->a_chunks.ptr;
+    nb = c->n_a_chunks;
+  }
   if (grid) {
     pa.pair_item = c->grid_item.ptr; pa.chunks = c->grid_chunks.ptr;
     pa.out = c->btab.ptr; pa.out_tail = nullptr;

@@ -139,6 +139,34 @@ def test_c5_shape_with_the_chunk_sizes_full_size_c5_runs(hip, c5_shape, chunk, m
     assert info["n_chunks"] == 10 * 8          # ceil(1200 / chunk) = 3 or 2 real chunks per rating, padded to 8
 
 
+def test_the_a_launch_walks_runs_of_its_own_and_gives_the_same_rows(hip, c5_shape, monkeypatch):
+    """The matrix-core A launch writes rows only, so it walks the units in runs of its own length, chosen so that its last
+    round of workgroups is (nearly) full (stages.hpp: balanced_run_units; C5: 11 units where the T + S launch takes 8).
+    A rows do not depend on which workgroup computes them: theta / eta / p after three iterations are BITWISE the same
+    for runs of 1, 3 and 16 units (ragged last runs, empty padding runs) as for the T + S launch's own 4-unit chunks --
+    and every entry agrees with the dense oracle as in the tests above."""
+    train, case = c5_shape
+    outs = {}
+    for units in (4, 1, 3, 16):
+        monkeypatch.setenv("MMSBM_HIP_A_UNITS", str(units))
+        mm = hip.MMSBM(case["k"], case["l"], iterations=3, seed=case["seed"])
+        mm._prepare_objects(train)
+        ctx = mm._ctx(0)
+        assert ctx.get_option("mfma") == 1.0 and ctx.get_option("chunk_pairs") == 256
+        # 1,200 pairs per rating = 19 units: ceil(19 / units) runs, padded to a multiple of 8 per rating (0: the T + S launch's list)
+        runs = -(-19 // units)
+        assert ctx.get_option("a_chunks") == (0 if units == 4 else 10 * (-(-runs // 8) * 8))
+        ctx.set_params(*case["start"])
+        ctx.iterate(3)
+        outs[units] = ctx.get_params()
+        mm._release()
+    for units in (1, 3, 16):
+        for a, b, nm in zip(outs[units], outs[4], ("theta", "eta", "pr")):
+            assert np.array_equal(a, b), (units, nm)
+    for got, want, nm in zip(outs[4], case["params"], ("theta", "eta", "pr")):
+        assert rel_err(got, want) < TOL_FEW, nm
+
+
 def test_c5_shape_on_the_vector_alus_with_the_persistent_a_pipeline(hip, c5_shape):
     """The same problem with the matrix cores off: pair_block_kernel (tile in LDS) for T + S and the
     persistent four-unit pipeline pair_quad_a_kernel for A -- what C5 ran before round 2 and what
