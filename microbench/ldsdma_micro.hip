@@ -100,8 +100,8 @@ __global__ __launch_bounds__(NT) void stream(const double *__restrict__ xtab, co
 
 template <bool DMA, int ROWS, int NT>
 void run(const char *name, const double *x, const double *e, const int *ids, double *out, int n_units, bool mfma, size_t lds, int grid,
-         double *tout) {
-  const int mf = mfma ? 464 * ROWS / 64 / (NT / 64) : 0;   // the T + S launch: 464 matrix instructions per 64 pairs, dealt to the waves
+         double *tout, int mfma_pct = 100) {
+  const int mf = mfma ? 464 * ROWS / 64 / (NT / 64) * mfma_pct / 100 / 2 * 2 : 0;   // the T + S launch: 464 matrix instructions per 64 pairs, dealt to the waves
   CK(hipFuncSetAttribute(reinterpret_cast<const void *>(stream<DMA, ROWS, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
   int per_cu = 0;
   CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, stream<DMA, ROWS, NT>, NT, lds));
@@ -240,6 +240,12 @@ int main() {
     run<false, 32, 256>("registers", x, e, ids, out, 2 * n_units64, mfma, b32 + tile + idsb, 3 * cus, t);
     run<false, 32, 256>("registers", x, e, ids, out, 2 * n_units64, mfma, b32 + tile + idsb, 3904, t);
     run<false, 32, 512>("registers", x, e, ids, out, 2 * n_units64, mfma, b32 + tile + idsb, 3 * cus, t);
+    if (mfma) {   // ... with the matrix work of unpadded tiles (77 %)
+      run<false, 64, 512>("registers, unpadded tiles", x, e, ids, out, n_units64, mfma, b64 + tile + idsb, 2 * cus, t, 77);
+      run<false, 32, 256>("registers, unpadded tiles", x, e, ids, out, 2 * n_units64, mfma, b32 + tile + idsb, 3 * cus, t, 77);
+      run<false, 32, 256>("registers, unpadded tiles", x, e, ids, out, 2 * n_units64, mfma, b32 + tile + idsb, 3904, t, 77);
+      run<false, 32, 512>("registers, unpadded tiles", x, e, ids, out, 2 * n_units64, mfma, b32 + tile + idsb, 3 * cus, t, 77);
+    }
     run<true, 64, 512>("LDS-DMA, two buffers", x, e, ids, out, n_units64, mfma, 2 * b64 + tile, cus, t);
     run<true, 32, 512>("LDS-DMA, two buffers", x, e, ids, out, 2 * n_units64, mfma, 2 * b32 + tile, 2 * cus, t);
     run<true, 32, 256>("LDS-DMA, two buffers", x, e, ids, out, 2 * n_units64, mfma, 2 * b32 + tile, 2 * cus, t);

@@ -431,6 +431,15 @@ def g9_k50_long():
     long_run("g9_k50_400", 100_000, 10_000, 1_000, 10, 50, 50, (100, 200, 400), 4000)
 
 
+def g10_k80_long():
+    """The BLOCKED matrix-core kernels (a side beyond 64 groups: mfma_rows_kernel + mfma_slab_kernel): 40k ratings of 4k users
+    x 400 items, R = 8, K = L = 80, 200 iterations, snapshots at 50 / 100 / 200.  About 20 minutes."""
+    long_run("g10_k80_200", 40_000, 4_000, 400, 8, 80, 80, (50, 100, 200), 4000)
+
+
+if __name__ == "__main__" and os.environ.get("MMSBM_GOLDEN_ONLY") == "g10":
+    g10_k80_long()
+
 if __name__ == "__main__" and os.environ.get("MMSBM_GOLDEN_ONLY") == "g8":
     g8_c3_long()
 

@@ -169,7 +169,7 @@ def test_g5_long_run_first_snapshot():
     assert np.array_equal(np.argmax(pd_, 1).astype(np.int8), g["argmax_100"])
 
 
-@pytest.mark.parametrize("name", ["g8_c3_400", "g9_k50_400"])
+@pytest.mark.parametrize("name", ["g8_c3_400", "g9_k50_400", "g10_k80_200"])
 def test_long_fixtures_of_the_big_kernel_families_start_where_the_oracle_starts(name):
     """g8 (C3 itself, 400 iterations of the real reference) and g9 (K = L = 50): the problem is the one the generator
     recipe gives and the oracle's random start is the reference's, bit for bit.  (The 100-iteration pin of the oracle
@@ -183,23 +183,25 @@ def test_long_fixtures_of_the_big_kernel_families_start_where_the_oracle_starts(
     t, e, p = orc.init_params(orc.child_seeds(int(g["model_seed"]), 1)[0], n_u, n_i, n_r, k, l, d_u, d_i)
     assert np.array_equal(t[g["ut"], g["kt"]], g["theta_s_0"]) and np.array_equal(e[g["ie"], g["le"]], g["eta_s_0"])
     assert np.array_equal(p, g["pr_0"])
-    assert [int(x) for x in g["snapshots"]] == [100, 200, 400] and len(g["likelihood_at"]) == 3
-    for it in (100, 200, 400):
+    snaps = [int(x) for x in g["snapshots"]]
+    assert snaps == ([50, 100, 200] if name.startswith("g10") else [100, 200, 400]) and len(g["likelihood_at"]) == 3
+    for it in snaps:
         assert g[f"argmax_{it}"].shape == (n,) and np.isfinite(g[f"pr_{it}"]).all()
 
 
 @pytest.mark.slow
 @pytest.mark.skipif(not os.environ.get("MMSBM_LONG_ORACLE"), reason="opt-in (MMSBM_LONG_ORACLE=1): 11 + 25 minutes of dense CPU work")
-@pytest.mark.parametrize("name", ["g9_k50_400", "g8_c3_400"])
+@pytest.mark.parametrize("name", ["g10_k80_200", "g9_k50_400", "g8_c3_400"])
 def test_long_fixtures_first_snapshot(name):
-    """The oracle reproduces the reference's first snapshot (100 iterations) of g9 / g8 BIT FOR BIT."""
+    """The oracle reproduces the reference's first snapshot (50 resp. 100 iterations) of g10 / g9 / g8 BIT FOR BIT."""
     g = load_golden(name)
     n, u, i, r, k, l = (int(g[x]) for x in ("n", "u", "i", "r", "k", "l"))
+    first = int(g["snapshots"][0])
     train = orc.synthetic_triples(n, u, i, r, int(g["gen_seed"]))
-    out = orc.run_one_sampling(train, orc.child_seeds(int(g["model_seed"]), 1)[0], k, l, 100, snapshots=(100,))
-    t, e, p = out["snapshots"][100]
-    assert np.array_equal(t[g["ut"], g["kt"]], g["theta_s_100"]) and np.array_equal(e[g["ie"], g["le"]], g["eta_s_100"])
-    assert np.array_equal(p, g["pr_100"]) and np.array_equal(t.sum(0), g["theta_colsum_100"])
+    out = orc.run_one_sampling(train, orc.child_seeds(int(g["model_seed"]), 1)[0], k, l, first, snapshots=(first,))
+    t, e, p = out["snapshots"][first]
+    assert np.array_equal(t[g["ut"], g["kt"]], g[f"theta_s_{first}"]) and np.array_equal(e[g["ie"], g["le"]], g[f"eta_s_{first}"])
+    assert np.array_equal(p, g[f"pr_{first}"]) and np.array_equal(t.sum(0), g[f"theta_colsum_{first}"])
     assert float(out["likelihood"]) == float(g["likelihood_at"][0])
 
 
