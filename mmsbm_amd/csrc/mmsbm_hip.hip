@@ -401,12 +401,12 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
     c->mv_chunks.upload(c->lay.mv_chunks, s);
     // The A launch of the matrix-core pair stage writes rows only -- nothing ties its workgroups to the T + S launch's
     // slabs -- so it walks the same units in runs of its own length, chosen so that its last round of workgroups is
-    // (nearly) full (balanced_run_units; C5: runs of 7 instead of 8 units).  Same rows, bit for bit.
+    // (nearly) full (balanced_run_units; C5: runs of 11 units where the T + S launch takes 8).  Same rows, bit for bit.
     std::vector<mmsbm::Chunk> a_runs;
     if (c->mfma && c->n_pairs > 0) {
       int per_cu = 0;
-      allow_big_lds(pair_mfma_kernel<true, false, kBlock, true>, c->lds_ma);
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pair_mfma_kernel<true, false, kBlock, true>, kBlock, c->lds_ma) != hipSuccess || per_cu < 1) per_cu = 1;
+      allow_big_lds(pair_mfma_kernel<true, false, kPairBlockMax, true>, c->lds_ma);
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pair_mfma_kernel<true, false, kPairBlockMax, true>, kPairBlockMax, c->lds_ma) != hipSuccess || per_cu < 1) per_cu = 1;
       const int now = c->mv_chunk_pairs / kUnitPairs;
       int a_units = balanced_run_units(c->lay.rating_off, per_cu * c->n_cus, std::max(2, now / 2), std::min(2 * now, kMfmaChunkPairs / kUnitPairs));
       if (const char *e = std::getenv("MMSBM_HIP_A_UNITS")) a_units = std::min(std::max(1, std::atoi(e)), kMfmaChunkPairs / kUnitPairs);  // (tests)

@@ -258,8 +258,8 @@ void stage_seg(mmsbm_hip_ctx *c, bool commit, bool with_pairs, bool with_users, 
 
 // Units per workgroup for a launch whose workgroups each walk a run of 64-pair units of one rating, `slots` of them
 // resident at a time: the launch lasts rounds x (units + a prologue of ~0.6 unit-times: the tile into LDS, the item ids,
-// the first rows' latency -- measured at C5, EXPERIMENTS.md), and rounds is an INTEGER: C5's 15,616 units in runs of 8
-// are 1,952 workgroups = 2.54 rounds of 768, paid as 3 (24 unit-times); in runs of 7 they are 2.92 rounds, also 3 (21).
+// the first rows' latency -- measured at C5, EXPERIMENTS.md), and rounds is an INTEGER (with 768 slots C5's 15,616 units in
+// runs of 8 are 1,952 workgroups = 2.54 rounds, paid as 3 = 24 unit-times; in runs of 11 they are 1.9 rounds, paid as 2 = 22).
 // Every rating's run count is rounded up to a multiple of 8 as in build_mv_chunks.
 inline int balanced_run_units(const std::vector<int32_t> &rating_off, int slots, int lo, int hi) {
   int best = hi;
@@ -407,8 +407,10 @@ void stage_matvec_a(mmsbm_hip_ctx *c, int slot, int a_slot, bool grid = false) {
     allow_big_lds(wide_matvec_kernel<true>, lds);
     LAUNCH_IN(ls, (wide_matvec_kernel<true>), slot_grid(c, nb * subs), kBlock, lds, c->stream, pa, subs);
   } else if (c->mfma) {
-    allow_big_lds(pair_mfma_kernel<true, false, kBlock, true>, c->lds_ma);
-    LAUNCH_IN(ls, (pair_mfma_kernel<true, false, kBlock, true>), slot_grid(c, nb), kBlock, c->lds_ma, c->stream, pa, pa.tiles);
+    // (eight waves like the T + S launch: 84 registers against the four-wave form's 148, so that two to three
+    // workgroups = 16 to 24 waves share a CU instead of 12 -- C5 150 -> 139-146 us, 4M ratings at K = L = 50 unchanged)
+    allow_big_lds(pair_mfma_kernel<true, false, kPairBlockMax, true>, c->lds_ma);
+    LAUNCH_IN(ls, (pair_mfma_kernel<true, false, kPairBlockMax, true>), slot_grid(c, nb), kPairBlockMax, c->lds_ma, c->stream, pa, pa.tiles);
   } else if (c->quad_a) {
     const dim3 grid = slot_grid(c, std::min(nb, c->n_cus));
 #define QA(NL)                                                                                    \
