@@ -58,6 +58,12 @@ def parse_args():
                     help="after the timed region, every rank also times this many iterations with HIP events "
                          "(`steady_state`: a 20-step region sits inside the ~1.7 ms clock ramp that follows an idle "
                          "period, DESIGN.md section 5); 0 = skip")
+    ap.add_argument("--groups", type=int, default=0,
+                    help="K = L override for the config's data (scripts/grid_report.py: the K sweep at C3's size); "
+                         "one GPU only; 0 = the config's own")
+    ap.add_argument("--mfma", type=int, default=-1, choices=[-1, 0, 1],
+                    help="pair stage of big rating tiles: 1 matrix cores, 0 vector ALUs, -1 the library's choice "
+                         "(scripts/grid_report.py: both forms of C5 from one run of the script)")
     ap.add_argument("--graph", action="store_true", help="replay a captured hipGraph instead of eager launches")
     ap.add_argument("--dist-backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
     ap.add_argument("--share-gpu", action="store_true",
@@ -304,7 +310,8 @@ def roofline_object(args, ctx, prof, n, k, l):
                           "HBM: the resident set (%.0f MB) exceeds the 256 MiB Infinity Cache" % (resident / 1e6),
            "traffic": None, "traffic_source": None}
     pmc_path = os.path.join(ROOT, "profiles", "pmc_summary.json")
-    if os.path.exists(pmc_path):  # rocprofv3 passes of this same command (scripts/profile_round.sh)
+    same_command = getattr(args, "groups", 0) in (0, k) and getattr(args, "mfma", -1) < 0   # (the profiles are of the configs themselves)
+    if os.path.exists(pmc_path) and same_command:  # rocprofv3 passes of this same command (scripts/profile_round.sh)
         with open(pmc_path) as fh:
             pmc = json.load(fh)
         ent = pmc.get(args.config, {}).get(dom)
@@ -327,6 +334,8 @@ def main():
     args = parse_args()
     if args.cpu_worker:
         return cpu_worker(args.cpu_worker)
+    # (before anything can make this process's first HIP call: mmsbm_amd/restarts.py says why)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     from mmsbm_amd.build import ensure_library   # (no HIP, no torch: safe before the ranks are started)
     ensure_library()                             # a fresh clone has no libmmsbm_hip.so yet
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -354,6 +363,9 @@ def main():
 
     if args.share_gpu:
         os.environ["LOCAL_RANK"] = "0"
+    elif args.gpus > 1 and "LOCAL_RANK" not in os.environ:
+        raise SystemExit("bench.py --gpus N under a launcher that does not set LOCAL_RANK: every rank would use GPU 0 "
+                         "(torch.distributed.run sets it; --share-gpu allows it for a rehearsal)")
     # N > 1: the launcher's process group (RCCL).  N = 1: no group yet -- the one-rank group that lets the
     # end-of-job pick go through RCCL on every run is made AFTER the timed region (its barrier kernel and
     # proxy thread cost a 20-step run 2-3 us per step when they sit in front of it; a barrier among one
@@ -365,8 +377,27 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if device.type != "cuda":
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if world > 1:
+        # N ranks must sit on N different GPUs BEFORE anything is timed: one all_gather of (hostname, PCI bus id).
+        # Every rank sees the same records, so every rank leaves together (no rank waits in a collective for one that
+        # has gone); nothing is printed on stdout.
+        from mmsbm_amd import _lib as _l
+        here = gather_ranks({"rank": rank, "hostname": socket.gethostname(),
+                             "pci_bus_id": _l.device_identity(local)["pci_bus_id"]}, world,
+                            restarts._collective_device(device))
+        err = restarts.distinct_device_error(here, world, args.share_gpu)
+        if err is None and restarts.collective_info()["world_size"] != args.gpus:
+            err = f"process group of {restarts.collective_info()['world_size']} rank(s) for --gpus {args.gpus}"
+        if err:
+            if dist.is_initialized():
+                dist.destroy_process_group()
+            raise SystemExit(f"bench.py: {err}")
 
     cfg = CONFIGS[args.config]
+    if args.groups > 0:
+        if world > 1:
+            raise SystemExit("--groups is a one-GPU option")
+        cfg = cfg[:4] + (args.groups, args.groups)
     n, u, i, r, k, l = cfg
     train = synthetic_triples(n, u, i, r, seed=0)
     model = MMSBM(k, l, iterations=args.steps, sampling=world, seed=0, backend="hip")
@@ -377,6 +408,8 @@ def main():
     restarts.check_single_hip_runtime()
     ctx = model._ctx(local)
     ctx.set_graph_mode(1 if args.graph else 0)
+    if args.mfma >= 0:
+        ctx.set_option("mfma", args.mfma)
     ctx.synchronize()
     job_t["context_s"] = time.perf_counter() - t_job
     t_job = time.perf_counter()
@@ -460,6 +493,16 @@ def main():
                           "steady_ms_per_step": steady_ms, "likelihood": float(lik), "build_id": build_id}, world,
                          restarts._collective_device(device))
 
+    # the line must not be able to lie about the hardware it ran on: N ranks, N distinct GPUs, one group of N
+    lie = restarts.distinct_device_error(ranks, world, args.share_gpu)
+    if lie is None and world > 1 and restarts.collective_info()["world_size"] != args.gpus:
+        lie = f"process group of {restarts.collective_info()['world_size']} rank(s) for --gpus {args.gpus}"
+    if lie:
+        os.close(json_fd)
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        raise SystemExit(f"bench.py: {lie}")
+
     out = None
     if rank == 0:
         its = world * args.steps / elapsed_max
@@ -470,8 +513,8 @@ def main():
         if coll_error:
             coll["error"] = coll_error
         out = {
-            "metric": "EM iterations/sec (1M ratings, K=L=20)" if args.config == "c3"
-                      else f"EM iterations/sec ({args.config})",
+            "metric": "EM iterations/sec (1M ratings, K=L=20)" if (args.config == "c3" and args.groups in (0, 20))
+                      else f"EM iterations/sec ({args.config}" + (f", K=L={args.groups})" if args.groups else ")"),
             "value": its, "unit": "it/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed_max / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

@@ -34,7 +34,12 @@ def main():
     args = ap.parse_args()
     if args.share_gpu:
         os.environ["LOCAL_RANK"] = "0"
+    elif int(os.environ.get("WORLD_SIZE", "1")) > 1 and "LOCAL_RANK" not in os.environ:
+        raise SystemExit("WORLD_SIZE > 1 but LOCAL_RANK is not set: every rank would use GPU 0 (start the ranks with "
+                         "torch.distributed.run; --share-gpu allows it for a rehearsal)")
     rank, world, local, device = restarts.init_from_env(args.dist_backend)
+    if world > 1 and device.type == "cuda" and not args.share_gpu:   # W ranks, W different GPUs -- or stop here
+        restarts.require_distinct_devices(local, device)
     train = synthetic_triples(args.ratings, args.ratings // 10, args.ratings // 50, 5, seed=0)
     model = MMSBM(args.groups, args.groups, iterations=args.iterations, sampling=args.sampling, seed=0)
     best, best_lik, liks = restarts.fit_distributed(model, train, device=device)   # (gather=False is the default)

@@ -129,6 +129,41 @@ def device_count() -> int:
     return int(n.value) if code == OK else 0
 
 
+def device_mem(device: int):
+    """(free, total) bytes of a HIP device as its driver reports them now."""
+    free, total = C.c_int64(0), C.c_int64(0)
+    call("mmsbm_hip_device_mem", int(device), C.byref(free), C.byref(total))
+    return int(free.value), int(total.value)
+
+
+def worker_device(n_devices: int, env=None, identity=None) -> int:
+    """The GPU a level-1 process (``kernels_hip``) works on.
+
+    The reference runs every restart in its own spawned worker (``Pool(processes=sampling)``, src/mmsbm.py:182-185)
+    and gives a backend no say in where (its own cupy backend puts every worker on GPU 0: README.md:186).  Rule:
+
+    * ``MMSBM_HIP_DEVICE`` if set (an index; must be below the device count);
+    * else, inside a ``multiprocessing`` child, (worker number - 1) mod device count -- Pool workers are numbered
+      1, 2, ... in the order the parent started them, so ``sampling`` workers land on ``sampling`` GPUs round robin;
+    * else (the main process) device 0.
+    """
+    env = os.environ if env is None else env
+    n = max(int(n_devices), 1)
+    forced = env.get("MMSBM_HIP_DEVICE", "").strip()
+    if forced:
+        try:
+            d = int(forced)
+        except ValueError:
+            raise ValueError(f"MMSBM_HIP_DEVICE={forced!r}: an integer device index expected") from None
+        if not 0 <= d < n:
+            raise ValueError(f"MMSBM_HIP_DEVICE={d}: this machine shows {n} HIP device(s)")
+        return d
+    if identity is None:
+        import multiprocessing
+        identity = getattr(multiprocessing.current_process(), "_identity", ())
+    return (int(identity[-1]) - 1) % n if identity else 0
+
+
 def loaded_hip_runtimes():
     """Paths of every libamdhip64 mapped into this process (two == trouble)."""
     out = set()

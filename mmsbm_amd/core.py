@@ -61,10 +61,22 @@ def split_triples(data):
     return _i32(d[:, 0]), _i32(d[:, 1]), _i32(d[:, 2])
 
 
-try:  # 128-bit XXH3: ~10 GB/s (2 ms per million (N,3) int64 rows); blake2b does ~1 GB/s
+try:  # 128-bit XXH3: ~10 GB/s (about 2.4 ms per million (N,3) int64 rows); blake2b does ~1 GB/s
     from xxhash import xxh3_128 as _digest128
+    DIGEST = "xxh3_128"
 except ImportError:  # pragma: no cover - depends on the environment
+    DIGEST = "blake2b"
+    _warned = []
+
     def _digest128(buf):
+        # `xxhash` is an optional dependency (requirements.txt lists it): without it the digest of a level-1 call is
+        # ten times slower and no longer hides behind the GPU work (level 1) -- say so, once
+        if not _warned:
+            _warned.append(True)
+            import warnings
+            warnings.warn("mmsbm_amd: the `xxhash` module is not installed; the training-set digest of the level-1 "
+                          "backend (kernels_hip) falls back to blake2b, about ten times slower per call",
+                          RuntimeWarning, stacklevel=3)
         return hashlib.blake2b(buf, digest_size=16)
 
 

@@ -1,19 +1,22 @@
 // common.hpp -- error plumbing and the device helpers every kernel uses (DPP moves, group sums, vector loads)
-// Part of the single translation unit mmsbm_hip.hip (included there, in order; not a stand-alone header).
+// Included first by every translation unit of the library (prelude.hpp).
 #pragma once
 
-namespace {
-
+// Types that cross translation units (exceptions thrown in one and caught at the C ABI in another, members of the
+// context) live in this named namespace; kernels, device helpers and small host helpers stay in each unit's own
+// unnamed namespace.
+namespace mmsbm_hip_impl {
 
 // ======================================================================================
 // errors
 // ======================================================================================
-thread_local std::string g_last_error;
-
 struct ApiError : std::runtime_error {
   int code;
   ApiError(int c, const std::string &m) : std::runtime_error(m), code(c) {}
 };
+
+}  // namespace mmsbm_hip_impl
+using namespace mmsbm_hip_impl;
 
 #define HIP_CHECK(expr)                                                                 \
   do {                                                                                  \
@@ -22,29 +25,7 @@ struct ApiError : std::runtime_error {
       throw ApiError(MMSBM_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));   \
   } while (0)
 
-template <class F>
-int guarded(F &&f) {
-  try {
-    f();
-    return MMSBM_OK;
-  } catch (const ApiError &e) {
-    g_last_error = e.what();
-    return e.code;
-  } catch (const std::invalid_argument &e) {
-    g_last_error = e.what();
-    return MMSBM_E_INVALID;
-  } catch (const std::bad_alloc &) {
-    g_last_error = "host allocation failed";
-    return MMSBM_E_INTERNAL;
-  } catch (const std::exception &e) {
-    g_last_error = e.what();
-    return MMSBM_E_INTERNAL;
-  } catch (...) {  // anything that is not a std::exception (a library's own type, a thrown int): a status, never a
-                   // process death across the C ABI
-    g_last_error = "unknown exception (not derived from std::exception)";
-    return MMSBM_E_INTERNAL;
-  }
-}
+namespace {
 
 constexpr double kEps = 2.220446049250313e-16;  // np.finfo(float).eps, src/kernels_numpy.py:51
 constexpr int64_t kGpuLayoutMin = 100'000;       // triples from which the layout's sorts run on the device

@@ -1,5 +1,5 @@
 // context.hpp -- host side: padding rules, device buffers, the context (mmsbm_hip_ctx), launch bookkeeping
-// Part of the single translation unit mmsbm_hip.hip (included there, in order; not a stand-alone header).
+// Included by every translation unit of the library (prelude.hpp).
 #pragma once
 
 namespace {
@@ -42,6 +42,10 @@ int group_lanes(int code) {
     case 5: CALL(64, 8); break;                                   \
     default: CALL(64, 16); break;                                 \
   }
+
+}  // namespace
+
+namespace mmsbm_hip_impl {  // (members of mmsbm_hip_ctx: one type in every translation unit)
 
 template <class T>
 struct DevBuf {
@@ -107,6 +111,10 @@ struct PinBuf {
   }
 };
 
+}  // namespace mmsbm_hip_impl
+
+namespace {
+
 // fn(first_row, last_row) over [0, rows), on up to 8 host threads when the table is large
 template <class F>
 void for_row_blocks(int rows, size_t row_doubles, F &&fn) {
@@ -148,7 +156,9 @@ struct mmsbm_hip_ctx {
   int n_pairs = 0, n_chunks = 0;
   int code_k = 0, code_l = 0;
   bool direct_out = false;  // pair_block: output rows stored straight from registers (no LDS transpose)
-  int ablate = 0;           // tuning aid (mmsbm_hip_time_stage): phases pair_block skips
+#ifdef MMSBM_ABLATE
+  int ablate = 0;           // diagnostic build (-DMMSBM_ABLATE): phases the pair stage / eta_p skip, set by mmsbm_hip_time_stage
+#endif
   bool split_rows = false;  // theta and A kept as 128-byte main lines + tail rows (RowTab)
   int pb_threads_t = kBlock, pb_threads_a = kBlock;  // pair_block workgroup sizes (T+S mode, A mode)
   int pb_kt = 4;  // pair_block S phase: k-rows per register tile (2 when K x L is small)

@@ -1,5 +1,5 @@
 // eta_p.hpp -- p_update and item_sum, the two roles of eta_p_kernel
-// Part of the single translation unit mmsbm_hip.hip (included there, in order; not a stand-alone header).
+// Included by the translation units that launch these kernels (see prelude.hpp for the order); not a stand-alone header.
 #pragma once
 
 namespace {
@@ -248,7 +248,10 @@ struct EtaPArgs {
   double *p_new; double *pt_new; double *npr;
   const double *ttab; const int32_t *item_off; const int32_t *item_pairs; const int32_t *item_deg;
   const double *eta; double *eta_new;
-  int n_ratings, kp, lp, n_items, normalize, nb_p, abl;
+  int n_ratings, kp, lp, n_items, normalize, nb_p;
+#ifdef MMSBM_ABLATE
+  int abl;  // diagnostic build only: 64 skips p_update, 128 item_sum (mmsbm_hip_time_stage, stage >> 8)
+#endif
   size_t bs_partial, bs_p, bs_t, bs_eta;  // restart slots (blockIdx.y): table strides
   const int32_t *item_grid;               // [n_items][n_ratings] pair id or -1 (dense data), else null
 };
@@ -264,7 +267,9 @@ template <int G, int VEC>
 __global__ __launch_bounds__(kBlock) void eta_p_w4_kernel(EtaPArgs a) {
   __shared__ double red[kRedGroupW4][kRedRows][kRedCols];
   const size_t slot = blockIdx.y;
-  if (a.abl & (static_cast<int>(blockIdx.x) < a.nb_p ? 64 : 128)) return;  // tuning aid: skip a role
+#ifdef MMSBM_ABLATE
+  if (a.abl & (static_cast<int>(blockIdx.x) < a.nb_p ? 64 : 128)) return;  // skip a role
+#endif
   if (static_cast<int>(blockIdx.x) < a.nb_p)
     p_update_block<kRedRows, kBlock / kRedCols, 2, kRedGroupW4>(red, blockIdx.x, a.partial + slot * a.bs_partial, a.chunk_off,
                                                                 a.p_old + slot * a.bs_p, a.p_new + slot * a.bs_p,
@@ -280,7 +285,9 @@ template <int G, int VEC>
 __global__ __launch_bounds__(kRedThreads) void eta_p_kernel(EtaPArgs a) {
   __shared__ double red[kRedGroup][kRedRows][kRedCols];
   const size_t slot = blockIdx.y;
-  if (a.abl & (static_cast<int>(blockIdx.x) < a.nb_p ? 64 : 128)) return;  // tuning aid: skip a role
+#ifdef MMSBM_ABLATE
+  if (a.abl & (static_cast<int>(blockIdx.x) < a.nb_p ? 64 : 128)) return;  // skip a role
+#endif
   if (static_cast<int>(blockIdx.x) < a.nb_p)
     p_update_block<kRedRows>(red, blockIdx.x, a.partial + slot * a.bs_partial, a.chunk_off,
                              a.p_old + slot * a.bs_p, a.p_new + slot * a.bs_p,
@@ -292,5 +299,27 @@ __global__ __launch_bounds__(kRedThreads) void eta_p_kernel(EtaPArgs a) {
                            a.n_items, a.lp, a.normalize, a.item_grid, a.n_ratings);
 }
 
+// ---- host side: the argument blocks of these kernels from the context ----
+EtaPArgs eta_p_args(const mmsbm_hip_ctx *c, bool commit, int cols_per_block) {
+  const int cur = c->cur, nxt = cur ^ 1;
+  EtaPArgs a;
+  const int s = c->base_slot;
+  a.partial = c->partial.at(s);
+  a.chunk_off = c->mv_chunk_off.ptr;
+  a.p_old = c->p[cur].at(s); a.p_new = c->p[nxt].at(s); a.pt_new = c->pt[nxt].at(s);
+  a.npr = c->npr.at(s);
+  a.ttab = c->ttab.at(s); a.item_off = c->item_off.ptr; a.item_pairs = c->item_pairs.ptr;
+  a.item_deg = c->item_deg.ptr; a.eta = c->eta[cur].at(s); a.eta_new = c->eta[nxt].at(s);
+  a.bs_partial = c->partial.stride; a.bs_p = c->p[0].stride; a.bs_t = c->ttab.stride;
+  a.bs_eta = c->eta[0].stride;
+  a.n_ratings = c->n_ratings; a.kp = c->kp; a.lp = c->lp; a.n_items = c->n_items;
+  a.normalize = commit ? 1 : 0;
+#ifdef MMSBM_ABLATE
+  a.abl = c->ablate;
+#endif
+  a.nb_p = (c->kp * c->lp + cols_per_block - 1) / cols_per_block;
+  a.item_grid = c->item_grid.count ? c->item_grid.ptr : nullptr;
+  return a;
+}
 
 }  // namespace

@@ -1,5 +1,5 @@
 // fused_small.hpp -- small problems: the EM iteration in TWO launches instead of four (round 3)
-// Part of the single translation unit mmsbm_hip.hip (included there, in order; not a stand-alone header).
+// Included by the translation units that launch these kernels (see prelude.hpp for the order); not a stand-alone header.
 #pragma once
 
 namespace {
@@ -74,12 +74,6 @@ __device__ __forceinline__ void combine_lds(const double *parts, const mmsbm::Fu
 #pragma unroll
     for (int v = 0; v < VEC; ++v) tot[v] += a[v];
   }
-}
-
-size_t pairs_fused_lds(int kp, int lp, int split_parts = 0) {  // split_parts: partial rows of a unit's split pairs
-  return (static_cast<size_t>(lp) * (kUnitPairs + 1) + static_cast<size_t>(kUnitPairs) * lp +
-          static_cast<size_t>(kUnitPairs) * kp + static_cast<size_t>(kp) * (kUnitPairs + 1) +
-          static_cast<size_t>(split_parts) * kp) * sizeof(double);
 }
 
 template <int G, int VEC, bool SPLIT>

@@ -1,5 +1,5 @@
 // lik_fact.hpp -- the likelihood pair by pair (round 3): one wave per (item, rating) pair, theta through scalar loads
-// Part of the single translation unit mmsbm_hip.hip (included there, in order; not a stand-alone header).
+// Included by the translation units that launch these kernels (see prelude.hpp for the order); not a stand-alone header.
 #pragma once
 
 namespace {

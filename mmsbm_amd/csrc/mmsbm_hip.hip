@@ -27,38 +27,431 @@
 // Written for gfx950 only: 64-wide wavefronts, DPP cross-lane reductions, LDS-staged
 // rating tiles.
 
-#include <hip/hip_runtime.h>
-#include <hip/hip_ext.h>
-
-#include <algorithm>
-#include <chrono>
-#include <cmath>
-#include <cstdint>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <memory>
-#include <stdexcept>
-#include <string>
-#include <thread>
-#include <vector>
-
-#include "../../include/mmsbm_hip.h"
-#include "layout.hpp"
+#include "prelude.hpp"
 #include "layout_gpu.hpp"
 #include "pcg64.hpp"
 
-// The kernels and their host side, in dependency order (one translation unit):
-#include "common.hpp"
-#include "seg_pass.hpp"
-#include "pair_block.hpp"
-#include "eta_p.hpp"
-#include "fused_small.hpp"
-#include "once_kernels.hpp"
-#include "lik_fact.hpp"
-#include "context.hpp"
-#include "pair_big.hpp"
-#include "stages.hpp"
+#include <unistd.h>
+
+#include <map>
+#include <mutex>
+
+namespace {
+
+thread_local std::string g_last_error;
+
+template <class F>
+int guarded(F &&f) {
+  try {
+    f();
+    return MMSBM_OK;
+  } catch (const ApiError &e) {
+    g_last_error = e.what();
+    return e.code;
+  } catch (const std::invalid_argument &e) {
+    g_last_error = e.what();
+    return MMSBM_E_INVALID;
+  } catch (const std::bad_alloc &) {
+    g_last_error = "host allocation failed";
+    return MMSBM_E_INTERNAL;
+  } catch (const std::exception &e) {
+    g_last_error = e.what();
+    return MMSBM_E_INTERNAL;
+  } catch (...) {  // anything that is not a std::exception (a library's own type, a thrown int): a status, never a
+                   // process death across the C ABI
+    g_last_error = "unknown exception (not derived from std::exception)";
+    return MMSBM_E_INTERNAL;
+  }
+}
+
+}  // namespace
+
+// ---- launch log (launch.hpp) -------------------------------------------------------------------------------------------
+namespace mmsbm_hip_impl {
+
+bool g_launch_log_on = std::getenv("MMSBM_HIP_LAUNCH_LOG") != nullptr && std::getenv("MMSBM_HIP_LAUNCH_LOG")[0] != 0;
+
+namespace {
+struct LaunchLog {
+  struct Rec { long long count = 0; std::string tag; };
+  std::mutex mu;
+  std::map<const void *, Rec> seen;   // host-side kernel handle -> launches since the last flush, tag of the first one
+  void note(const void *fn) {
+    std::lock_guard<std::mutex> lock(mu);
+    Rec &r = seen[fn];
+    if (r.count++ == 0 && r.tag.empty()) {
+      const char *t = std::getenv("MMSBM_HIP_LAUNCH_TAG");
+      r.tag = t ? t : "-";
+    }
+  }
+  // one line per kernel: pid <tab> launches <tab> mangled name <tab> tag; appended in ONE write, so that the lines of
+  // several processes sharing the file do not interleave.  Counts restart from zero, names and tags are kept.
+  void flush() {
+    std::lock_guard<std::mutex> lock(mu);
+    const char *path = std::getenv("MMSBM_HIP_LAUNCH_LOG");
+    if (!path || !path[0]) return;
+    std::string out;
+    for (auto &kv : seen) {
+      if (kv.second.count == 0) continue;
+      const char *name = hipKernelNameRefByPtr(kv.first, nullptr);
+      char buf[64];
+      std::snprintf(buf, sizeof buf, "%p", kv.first);
+      out += std::to_string(static_cast<long long>(getpid())) + "\t" + std::to_string(kv.second.count) + "\t" +
+             (name && name[0] ? name : buf) + "\t" + kv.second.tag + "\n";
+      kv.second.count = 0;
+    }
+    if (out.empty()) return;
+    if (FILE *f = std::fopen(path, "a")) {
+      std::fwrite(out.data(), 1, out.size(), f);
+      std::fclose(f);
+    }
+  }
+  ~LaunchLog() { flush(); }
+};
+LaunchLog &launch_log() {
+  static LaunchLog log;   // (flushed once more when the library is unloaded / the process exits)
+  return log;
+}
+}  // namespace
+
+void launch_log_note(const void *host_fn) { launch_log().note(host_fn); }
+
+// ---- the form of the pair stage the context's shape and options select ------------------------------------------------
+void stage_dense(mmsbm_hip_ctx *c) {  // T = P^T C  and the K x L slabs for p
+  if (c->n_chunks == 0) return;
+  if (c->mfma_big || (!c->wide && c->mfma)) stage_dense_mfma(c);
+  else stage_dense_valu(c);
+}
+void stage_matvec_a(mmsbm_hip_ctx *c, int slot, int a_slot, bool grid) {
+  if (c->mfma_big || (!c->wide && c->mfma)) stage_matvec_a_mfma(c, slot, a_slot, grid);
+  else stage_matvec_a_valu(c, slot, a_slot, grid);
+}
+
+// atab[cur] = A of the current parameters, for every slot the next launches cover (see mmsbm_hip_ctx::a_ok)
+void ensure_a(mmsbm_hip_ctx *c) {
+  bool ok = true;
+  for (int s = c->base_slot; s < c->base_slot + c->launch_slots; ++s) ok = ok && c->a_ok[static_cast<size_t>(s)];
+  if (ok) return;
+  const bool prof = c->profiling;  // (not a launch of the iteration being profiled)
+  c->profiling = false;
+  stage_matvec_a(c, c->cur, c->cur);
+  c->profiling = prof;
+  for (int s = c->base_slot; s < c->base_slot + c->launch_slots; ++s) c->a_ok[static_cast<size_t>(s)] = 1;
+}
+
+}  // namespace mmsbm_hip_impl
+
+namespace {
+
+// Units per workgroup for a launch whose workgroups each walk a run of 64-pair units of one rating, `slots` of them
+// resident at a time: the launch lasts rounds x (units + a prologue of ~0.6 unit-times: the tile into LDS, the item ids,
+// the first rows' latency -- measured at C5, EXPERIMENTS.md), and rounds is an INTEGER (with 768 slots C5's 15,616 units in
+// runs of 8 are 1,952 workgroups = 2.54 rounds, paid as 3 = 24 unit-times; in runs of 11 they are 1.9 rounds, paid as 2 = 22).
+// Every rating's run count is rounded up to a multiple of 8 as in build_mv_chunks.
+inline int balanced_run_units(const std::vector<int32_t> &rating_off, int slots, int lo, int hi) {
+  int best = hi;
+  double best_cost = 1e300;
+  for (int u = hi; u >= lo; --u) {
+    long long wgs = 0;
+    for (size_t r = 0; r + 1 < rating_off.size(); ++r) {
+      const long long units = (rating_off[r + 1] - rating_off[r] + kUnitPairs - 1) / kUnitPairs;
+      const long long runs = (units + u - 1) / u;
+      wgs += rating_off.size() > 2 ? (runs + 7) / 8 * 8 : runs;
+    }
+    const double cost = static_cast<double>((wgs + slots - 1) / std::max(slots, 1)) * (u + 0.6);
+    if (cost < best_cost * 0.97) { best_cost = cost; best = u; }   // (longer runs win ties: fewer prologues)
+  }
+  return best;
+}
+
+// ---- small problems: the iteration in two launches (fused_small.hpp) -------------------------------------
+bool fused_shape_ok(const mmsbm_hip_ctx *c) {  // (everything but the data: the kernels exist for this shape)
+  // (rows of up to 24 groups: beyond that the four-launch pair stage runs 512-thread workgroups, whose split of a
+  // unit's pairs among the copies of the slab grid -- hence the association order of S -- 256 threads cannot mirror)
+  return c->code_k <= 1 && c->code_l <= 1 && c->pb_threads_t == kBlock && c->pb_threads_a == kBlock && !c->tl_t &&
+         !c->tl_a && c->pb_nacc == 1 && c->pb_kt == 2 && c->pb_spb * c->pb_nsub <= kBlock && !c->wide &&
+         !c->mfma && !c->mfma_big && !c->direct_out && c->mv_chunk_pairs == mmsbm::kMvChunkPairs && c->n_chunks > 0 &&
+         pairs_fused_lds(c->kp, c->lp) <= kLdsBudget;
+}
+bool fused_possible(const mmsbm_hip_ctx *c) {
+  // A work list that only ORDERS whole segments is fine (the pair units ignore it -- every segment's result is its
+  // own -- and the user pass follows it as before); segments cut into pieces need all pieces of a segment inside one
+  // workgroup: the lists create() builds for small problems (fs_pairs / fs_users; round 4)
+  return fused_shape_ok(c) && (c->lay.pair_work.splits.empty() || c->fs_pairs) &&
+         (c->lay.user_work.splits.empty() || c->fs_users);
+}
+
+void mark_a(mmsbm_hip_ctx *c, bool ok) {
+  for (int s = c->base_slot; s < c->base_slot + c->launch_slots; ++s) c->a_ok[static_cast<size_t>(s)] = ok ? 1 : 0;
+}
+
+// Two launches while the launches' work is small: ratings x restart slots x (K + L, padded) <= 14M (measured per
+// iteration, two / four launches.  One slot, K = L = 10: 100k ratings 20.2 / 29.3 us, 300k 28.7 / 37.0, 500k 37.8 /
+// 43.5; K = L = 16: 400k 36.0 / 41.7; K = L = 20: 100k 28.4 / 37.6, 300k 50.1 / 50.1, 600k 69.4 / 67.5, 1M 105.0 / 95.6.  100k ratings at K = L = 10
+// with 2 / 4 / 8 / 16 slots: 26.5 / 32.4, 40.9 / 42.8, 68.0 / 64.9, 119.9 / 115.9 -- with several slots the four-launch
+// form shares the index stream among them)
+// Data whose segments are cut into pieces pays a combine launch in the separate form (five launches): there the two
+// launches win a little further out (log-normal popularity, separate / two, scripts/fused_split_sweep.py: 400k ratings
+// K = L = 10 38.4 / 31.3 us, 700k 43.8 / 39.8; 300k K = L = 20 45.1 / 41.4, 600k 54.0 / 65.5; 1M x 100k x 20k K = L = 10
+// 77.3 / 92.6) -- up to 18M.
+constexpr long long kFusedWorkMax = 14000000, kFusedWorkMaxSplit = 18000000, kFusedRatingsMax = 1500000;
+bool use_fused(const mmsbm_hip_ctx *c) {
+  // (fused_possible again: options set after create() -- "mfma", "direct" ... -- change what it depends on)
+  const bool cut = !c->lay.pair_work.splits.empty() || !c->lay.user_work.splits.empty();
+  return c->fused && fused_possible(c) &&
+         (c->fused_forced || c->n_obs * c->launch_slots * (c->kp + c->lp) <= (cut ? kFusedWorkMaxSplit : kFusedWorkMax));
+}
+
+void launch_iteration(mmsbm_hip_ctx *c, bool commit) {
+  if (use_fused(c)) {
+    stage_fused_pairs(c);  // (writes A of the current parameters on its way)
+    stage_fused_tail(c, commit);
+    if (commit) c->cur ^= 1;
+    mark_a(c, !commit);
+    return;
+  }
+  ensure_a(c);
+  stage_seg(c, commit, true, true, c->stream);
+  stage_dense(c);
+  stage_eta_p(c, commit);
+  if (commit) {
+    stage_matvec_a(c, c->cur ^ 1, c->cur ^ 1);
+    c->cur ^= 1;
+    mark_a(c, true);
+  }
+}
+
+// n committed iterations: graph replays of two iterations each when enabled, the rest eager
+void run_iterations(mmsbm_hip_ctx *c, int n) {
+  if (c->graph_mode && !c->profiling) {
+    while (n >= 2) {
+      const int slot = c->cur;
+      if (!c->graph_exec[slot]) {
+        if (!use_fused(c)) ensure_a(c);  // (outside the capture: a replay must not repeat it)
+        hipGraph_t graph = nullptr;
+        HIP_CHECK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        try {
+          launch_iteration(c, true);
+          launch_iteration(c, true);
+        } catch (...) {
+          (void)hipStreamEndCapture(c->stream, &graph);
+          if (graph) (void)hipGraphDestroy(graph);
+          c->cur = slot;
+          throw;
+        }
+        HIP_CHECK(hipStreamEndCapture(c->stream, &graph));
+        hipError_t e = hipGraphInstantiate(&c->graph_exec[slot], graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (e != hipSuccess)
+          throw ApiError(MMSBM_E_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+        // capture only records: cur is back where it started and nothing has run yet
+      }
+      HIP_CHECK(hipGraphLaunch(c->graph_exec[slot], c->stream));
+      // (a replay runs none of launch_iteration's host code: the bookkeeping of "atab[cur] holds A of the current
+      // parameters" has to be repeated here -- true after the four-launch form, false after the two-launch one)
+      mark_a(c, !use_fused(c));
+      n -= 2;
+    }
+  }
+  for (; n > 0; --n) launch_iteration(c, true);
+}
+
+void require_params(const mmsbm_hip_ctx *c) {  // the selected slot
+  if (!c) throw std::invalid_argument("null context");
+  if (!c->have[c->sel]) throw std::invalid_argument("set_params has not been called");
+}
+void require_all_params(const mmsbm_hip_ctx *c) {  // every slot: the iteration advances all of them
+  if (!c) throw std::invalid_argument("null context");
+  for (int s = 0; s < c->n_slots; ++s)
+    if (!c->have[s])
+      throw std::invalid_argument(c->n_slots == 1 ? std::string("set_params has not been called")
+                                                  : "set_params has not been called for slot " +
+                                                        std::to_string(s));
+}
+
+// (Re)allocate the per-restart state for `slots` parameter sets; nothing is kept.
+void alloc_state(mmsbm_hip_ctx *c, int slots) {
+  hipStream_t s = c->stream;
+  HIP_CHECK(hipStreamSynchronize(s));
+  c->drop_graphs();
+  const size_t klr = static_cast<size_t>(c->n_ratings) * c->kp * c->lp;
+  auto zeroed = [&](SlotBuf &b, size_t per_slot) {
+    b.alloc_slots(per_slot, slots);
+    HIP_CHECK(hipMemsetAsync(b.ptr, 0, sizeof(double) * std::max<size_t>(b.count, 1), s));
+  };
+  for (int b = 0; b < 2; ++b) {
+    zeroed(c->theta[b], static_cast<size_t>(c->n_users) * c->kp);
+    zeroed(c->eta[b], static_cast<size_t>(c->n_items) * c->lp);
+    zeroed(c->p[b], klr);
+    zeroed(c->pt[b], klr);
+    zeroed(c->atab[b], static_cast<size_t>(c->n_pairs) * c->kp);
+  }
+  // (the scratch tables too: every entry a kernel reads is written by the launch before it -- audited, EXPERIMENTS.md
+  // -- but padding rows and the slabs of empty units then hold zeros rather than whatever the pages held before)
+  zeroed(c->ctab, static_cast<size_t>(c->n_pairs) * c->kp);
+  zeroed(c->ttab, static_cast<size_t>(c->n_pairs) * c->lp);
+  zeroed(c->partial, c->lay.mv_chunks.size() * c->kp * c->lp);
+  zeroed(c->npr, klr);
+  zeroed(c->pair_parts, static_cast<size_t>(c->lay.pair_work.n_parts) * c->kp);
+  zeroed(c->user_parts, static_cast<size_t>(c->lay.user_work.n_parts) * c->kp);
+  HIP_CHECK(hipStreamSynchronize(s));
+  c->n_slots = slots;
+  c->sel = 0;
+  c->base_slot = 0;
+  c->launch_slots = slots;
+  c->cur = 0;
+  c->have.assign(static_cast<size_t>(slots), 0);
+  c->a_ok.assign(static_cast<size_t>(slots), 0);
+}
+
+// host (rows, d) row-major  <->  device RowTab (rows, dp) zero-padded, main + tail parts, staged
+// through pinned memory in the one-slot layout (main rows, then tail rows): one contiguous copy when
+// the context has one slot, a strided (2-D) copy per part when the slots' rows are interleaved
+bool tab_is_packed(const RowTab &t, int rows) {
+  return t.rs_m == t.mw && t.rs_t == t.tw && (t.tw == 0 || t.tail == t.main + static_cast<size_t>(rows) * t.mw);
+}
+void copy_rows(mmsbm_hip_ctx *c, const RowTab &t, double *stage, int rows, bool to_device) {
+  const size_t e = sizeof(double);
+  hipStream_t xs = c->xfer ? c->xfer : c->stream;
+  if (rows == 0) return;
+  if (tab_is_packed(t, rows)) {
+    if (to_device)
+      HIP_CHECK(hipMemcpyAsync(t.main, stage, e * rows * (t.mw + t.tw), hipMemcpyHostToDevice, xs));
+    else
+      HIP_CHECK(hipMemcpyAsync(stage, t.main, e * rows * (t.mw + t.tw), hipMemcpyDeviceToHost, xs));
+    return;
+  }
+  double *stage_t = stage + static_cast<size_t>(rows) * t.mw;
+  if (to_device) {
+    HIP_CHECK(hipMemcpy2DAsync(t.main, e * t.rs_m, stage, e * t.mw, e * t.mw, rows, hipMemcpyHostToDevice, xs));
+    if (t.tw > 0)
+      HIP_CHECK(hipMemcpy2DAsync(t.tail, e * t.rs_t, stage_t, e * t.tw, e * t.tw, rows, hipMemcpyHostToDevice, xs));
+  } else {
+    HIP_CHECK(hipMemcpy2DAsync(stage, e * t.mw, t.main, e * t.rs_m, e * t.mw, rows, hipMemcpyDeviceToHost, xs));
+    if (t.tw > 0)
+      HIP_CHECK(hipMemcpy2DAsync(stage_t, e * t.tw, t.tail, e * t.rs_t, e * t.tw, rows, hipMemcpyDeviceToHost, xs));
+  }
+}
+void zero_rows(mmsbm_hip_ctx *c, const RowTab &t, int rows) {
+  const size_t e = sizeof(double);
+  if (rows == 0) return;
+  if (tab_is_packed(t, rows)) {
+    HIP_CHECK(hipMemsetAsync(t.main, 0, e * rows * (t.mw + t.tw), c->stream));
+    return;
+  }
+  HIP_CHECK(hipMemset2DAsync(t.main, e * t.rs_m, 0, e * t.mw, rows, c->stream));
+  if (t.tw > 0) HIP_CHECK(hipMemset2DAsync(t.tail, e * t.rs_t, 0, e * t.tw, rows, c->stream));
+}
+void upload_rows(mmsbm_hip_ctx *c, const RowTab &t, const double *host, int rows, int d) {
+  const int dp = t.mw + t.tw, mw = t.mw, tw = t.tw;
+  double *stage = c->pin.take(static_cast<size_t>(rows) * dp);
+  double *tail = stage + static_cast<size_t>(rows) * mw;
+  const int wm = std::min(d, mw), wt = std::max(0, d - mw);
+  for_row_blocks(rows, dp, [=](int a, int b) {
+    for (int r = a; r < b; ++r) {
+      const double *src = host + static_cast<size_t>(r) * d;
+      double *m = stage + static_cast<size_t>(r) * mw;
+      std::memcpy(m, src, sizeof(double) * wm);
+      for (int j = wm; j < mw; ++j) m[j] = 0.0;
+      if (tw > 0) {
+        double *tl = tail + static_cast<size_t>(r) * tw;
+        std::memcpy(tl, src + mw, sizeof(double) * wt);
+        for (int j = wt; j < tw; ++j) tl[j] = 0.0;
+      }
+    }
+  });
+  copy_rows(c, t, stage, rows, true);
+}
+// enqueue the device -> pinned copy; unpack_rows after the stream has been synchronised
+double *download_rows(mmsbm_hip_ctx *c, const RowTab &t, int rows) {
+  const int dp = t.mw + t.tw;
+  double *stage = c->pin.take(static_cast<size_t>(rows) * dp);
+  copy_rows(c, t, stage, rows, false);
+  return stage;
+}
+void unpack_rows(double *host, const double *stage, const RowTab &t, int rows, int d) {
+  const int dp = t.mw + t.tw, mw = t.mw, tw = t.tw;
+  const double *tail = stage + static_cast<size_t>(rows) * mw;
+  const int wm = std::min(d, mw), wt = std::max(0, d - mw);
+  for_row_blocks(rows, dp, [=](int a, int b) {
+    for (int r = a; r < b; ++r) {
+      double *dst = host + static_cast<size_t>(r) * d;
+      std::memcpy(dst, stage + static_cast<size_t>(r) * mw, sizeof(double) * wm);
+      if (tw > 0 && wt > 0) std::memcpy(dst + mw, tail + static_cast<size_t>(r) * tw, sizeof(double) * wt);
+    }
+  });
+}
+size_t rows_doubles(const mmsbm_hip_ctx *c) {  // staging for theta + eta + p + pT of one slot
+  return static_cast<size_t>(c->n_users) * c->kp + static_cast<size_t>(c->n_items) * c->lp +
+         2 * static_cast<size_t>(c->n_ratings) * c->kp * c->lp;
+}
+
+// device p layout [R][kp][lp] (internal k, l)  <->  host pr (K, L, R) external
+void p_host_to_dev(const mmsbm_hip_ctx *c, const double *pr, double *p, double *pt) {
+  const int R = c->n_ratings, K = c->k, L = c->l, kp = c->kp, lp = c->lp;
+  std::fill(p, p + static_cast<size_t>(R) * kp * lp, 0.0);
+  std::fill(pt, pt + static_cast<size_t>(R) * kp * lp, 0.0);
+  for (int k = 0; k < K; ++k)
+    for (int l = 0; l < L; ++l)
+      for (int r = 0; r < R; ++r) {
+        // internal (k,l) == external (l,k) when swapped
+        const size_t h = c->swapped ? (static_cast<size_t>(l) * c->ext_l + k) * R + r
+                                    : (static_cast<size_t>(k) * c->ext_l + l) * R + r;
+        const double v = pr[h];
+        p[(static_cast<size_t>(r) * kp + k) * lp + l] = v;
+        pt[(static_cast<size_t>(r) * lp + l) * kp + k] = v;
+      }
+}
+void p_dev_to_host(const mmsbm_hip_ctx *c, const double *p, double *pr) {
+  const int R = c->n_ratings, K = c->k, L = c->l, kp = c->kp, lp = c->lp;
+  for (int k = 0; k < K; ++k)
+    for (int l = 0; l < L; ++l)
+      for (int r = 0; r < R; ++r) {
+        const size_t h = c->swapped ? (static_cast<size_t>(l) * c->ext_l + k) * R + r
+                                    : (static_cast<size_t>(k) * c->ext_l + l) * R + r;
+        pr[h] = p[(static_cast<size_t>(r) * kp + k) * lp + l];
+      }
+}
+
+// (theta, eta, p) tables of one slot -> host arrays in host layout; any output may be null
+void fetch_params(mmsbm_hip_ctx *c, const RowTab &tt, const RowTab &et, const double *p_dev,
+                  double *theta, double *eta, double *pr) {
+  hipStream_t xs = c->xfer ? c->xfer : c->stream;
+  HIP_CHECK(hipStreamSynchronize(xs));
+  c->pin.reset(rows_doubles(c));
+  const size_t klr = static_cast<size_t>(c->n_ratings) * c->kp * c->lp;
+  const double *st = theta ? download_rows(c, tt, c->n_users) : nullptr;
+  const double *se = eta ? download_rows(c, et, c->n_items) : nullptr;
+  double *sp = nullptr;
+  if (pr) {
+    sp = c->pin.take(klr);
+    HIP_CHECK(hipMemcpyAsync(sp, p_dev, sizeof(double) * klr, hipMemcpyDeviceToHost, xs));
+  }
+  HIP_CHECK(hipStreamSynchronize(xs));
+  if (theta) unpack_rows(theta, st, tt, c->n_users, c->k);
+  if (eta) unpack_rows(eta, se, et, c->n_items, c->l);
+  if (pr) p_dev_to_host(c, sp, pr);
+}
+
+void collect_profile(mmsbm_hip_ctx *c, float *mean_us, int *launches, int n_iters) {
+  std::vector<double> tot(K_COUNT, 0.0);
+  std::vector<int> cnt(K_COUNT, 0);
+  for (auto &pe : c->prof_events) {
+    float ms = 0.f;
+    HIP_CHECK(hipEventElapsedTime(&ms, pe.second.first, pe.second.second));
+    tot[pe.first] += ms * 1000.0;
+    cnt[pe.first]++;
+    (void)hipEventDestroy(pe.second.first);
+    (void)hipEventDestroy(pe.second.second);
+  }
+  c->prof_events.clear();
+  for (int i = 0; i < K_COUNT; ++i) {
+    mean_us[i] = cnt[i] ? static_cast<float>(tot[i] / cnt[i]) : 0.f;
+    if (launches) launches[i] = n_iters > 0 ? cnt[i] / n_iters : 0;
+  }
+}
+
+}  // namespace
 
 
 // ======================================================================================
@@ -404,9 +797,7 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
     // (nearly) full (balanced_run_units; C5: runs of 11 units where the T + S launch takes 8).  Same rows, bit for bit.
     std::vector<mmsbm::Chunk> a_runs;
     if (c->mfma && c->n_pairs > 0) {
-      int per_cu = 0;
-      allow_big_lds(pair_mfma_kernel<true, false, kPairBlockMax, true>, c->lds_ma);
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pair_mfma_kernel<true, false, kPairBlockMax, true>, kPairBlockMax, c->lds_ma) != hipSuccess || per_cu < 1) per_cu = 1;
+      const int per_cu = mfma_a_blocks_per_cu(c.get());
       const int now = c->mv_chunk_pairs / kUnitPairs;
       int a_units = balanced_run_units(c->lay.rating_off, per_cu * c->n_cus, std::max(2, now / 2), std::min(2 * now, kMfmaChunkPairs / kUnitPairs));
       if (const char *e = std::getenv("MMSBM_HIP_A_UNITS")) a_units = std::min(std::max(1, std::atoi(e)), kMfmaChunkPairs / kUnitPairs);  // (tests)
@@ -446,6 +837,7 @@ int mmsbm_hip_destroy(mmsbm_hip_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (g_launch_log_on) launch_log().flush();
     delete ctx;
   });
 }
@@ -513,27 +905,9 @@ int mmsbm_hip_init_params(mmsbm_hip_ctx *ctx, const uint64_t pcg64_state[4], con
     p_host_to_dev(ctx, pr, p, pt);
     HIP_CHECK(hipMemcpyAsync(ctx->p[cur].at(sl), p, sizeof(double) * klr, hipMemcpyHostToDevice, ctx->stream));
     HIP_CHECK(hipMemcpyAsync(ctx->pt[cur].at(sl), pt, sizeof(double) * klr, hipMemcpyHostToDevice, ctx->stream));
-    // the reference draws theta (external users x K) first, then eta; internally the two sides
-    // may be swapped, the stream offsets are not
-    const uint64_t n_theta_ext = static_cast<uint64_t>(ctx->ext_users) * ctx->ext_k;
-    const uint64_t off_users = ctx->swapped ? n_theta_ext : 0;  // internal users' table
-    const uint64_t off_items = ctx->swapped ? 0 : n_theta_ext;
-    const RowTab tt = theta_tab(ctx, cur), et = plain_tab(ctx->eta[cur].at(sl), ctx->lp);
-    zero_rows(ctx, tt, ctx->n_users);  // padding columns
-    zero_rows(ctx, et, ctx->n_items);
-    auto blocks = [](uint64_t total) {
-      return static_cast<unsigned>((total + uint64_t(kBlock) * kDrawsPerThread - 1) / (uint64_t(kBlock) * kDrawsPerThread));
-    };
-    const uint64_t nu = static_cast<uint64_t>(ctx->n_users) * ctx->k, ni = static_cast<uint64_t>(ctx->n_items) * ctx->l;
-    if (nu > 0)
-      init_rows_kernel<<<blocks(nu), kBlock, 0, ctx->stream>>>(tt, ctx->user_off.ptr, nullptr, ctx->n_users, ctx->k,
-                                                               pcg64_state[0], pcg64_state[1], pcg64_state[2],
-                                                               pcg64_state[3], off_users);
-    if (ni > 0)
-      init_rows_kernel<<<blocks(ni), kBlock, 0, ctx->stream>>>(et, nullptr, ctx->item_deg.ptr, ctx->n_items, ctx->l,
-                                                               pcg64_state[0], pcg64_state[1], pcg64_state[2],
-                                                               pcg64_state[3], off_items);
-    HIP_CHECK(hipGetLastError());
+    zero_rows(ctx, theta_tab(ctx, cur), ctx->n_users);  // padding columns
+    zero_rows(ctx, plain_tab(ctx->eta[cur].at(sl), ctx->lp), ctx->n_items);
+    init_rows_launch(ctx, pcg64_state);
     stage_matvec_a(ctx, cur, cur);
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
     ctx->have[sl] = 1;
@@ -654,191 +1028,6 @@ int mmsbm_hip_update_coefficients(mmsbm_hip_ctx *ctx, double *n_theta, double *n
 }
 
 namespace {
-// likelihood_fast_kernel: tile + its logarithms in LDS?  (always with several lanes per triple)
-bool lik_fast_tile_lds(const mmsbm_hip_ctx *c) {
-  return c->lp > 20 || c->lik_g > 1 ||
-         2 * static_cast<size_t>(c->kp) * c->lp * sizeof(double) > kScalarTileBytes;
-}
-bool lik_fast_usable(const mmsbm_hip_ctx *c) {
-  const size_t lds = lik_fast_tile_lds(c) ? 2 * static_cast<size_t>(c->kp) * c->lp * sizeof(double) : 0;
-  return c->lik_mode >= 1 && c->lp <= 160 && c->n_lik_units > 0 && lds <= kLdsMax - 4096;
-}
-// likelihood of the selected slot through the logarithm tables; returns the number of partial sums
-int likelihood_fast(mmsbm_hip_ctx *c) {
-  ensure_a(c);  // (s_n = theta_n . A[q_n])
-  const int cur = c->cur, sl = c->sel;
-  const size_t nt = static_cast<size_t>(c->n_users) * c->kp, ne = static_cast<size_t>(c->n_items) * c->lp;
-  const size_t np = static_cast<size_t>(c->n_ratings) * c->kp * c->lp;
-  if (c->lg_theta.count < nt) c->lg_theta.alloc(nt);
-  if (c->lg_eta.count < ne) c->lg_eta.alloc(ne);
-  if (c->lg_p.count < np) c->lg_p.alloc(np);
-  auto logs = [&](const double *in, double *out, size_t n) {
-    if (n == 0) return;
-    log_table_kernel<<<static_cast<unsigned>((n + kBlock - 1) / kBlock), kBlock, 0, c->stream>>>(in, out, n);
-  };
-  const RowTab th = theta_tab(c, cur);
-  const RowTab lth{c->lg_theta.ptr, c->lg_theta.ptr + static_cast<size_t>(c->n_users) * th.mw, th.mw, th.tw,
-                   th.mw, th.tw, 0, 0};  // main + tail like theta, one slot
-  if (nt > 0)
-    log_rows_kernel<<<static_cast<unsigned>((nt + kBlock - 1) / kBlock), kBlock, 0, c->stream>>>(
-        th, lth, static_cast<size_t>(c->n_users), c->kp);
-  logs(c->eta[cur].at(sl), c->lg_eta.ptr, ne);
-  logs(c->p[cur].at(sl), c->lg_p.ptr, np);
-  const int nb = c->n_lik_units;
-  if (c->lik_part.count < static_cast<size_t>(nb)) c->lik_part.alloc(nb);
-  // lanes per triple and columns per lane: at most ~20 columns (40 + 40 registers) per lane
-  int G = c->lp <= 20 ? 1 : (c->lp <= 40 ? 2 : 4);
-  if (c->lik_g > 0) G = c->lik_g;  // tuning override
-  while (G < 8 && (c->lp + G - 1) / G > 20) G *= 2;
-  const int LW = ((c->lp + G - 1) / G + 3) / 4 * 4;
-  const bool tl = lik_fast_tile_lds(c);
-  const size_t lds = tl ? 2 * static_cast<size_t>(c->kp) * c->lp * sizeof(double) : 0;
-#define LIK_GO(LW_, G_, TL_)                                                                      \
-  allow_big_lds(likelihood_fast_kernel<LW_, G_, TL_>, lds);                                       \
-  likelihood_fast_kernel<LW_, G_, TL_><<<nb, kLikThreads, lds, c->stream>>>(                      \
-      c->lik_units.ptr, c->pair_off.ptr, c->pair_user.ptr, c->pair_item.ptr, th, lth, a_tab(c, cur), \
-      c->eta[cur].at(sl), c->lg_eta.ptr, c->p[cur].at(sl), c->lg_p.ptr, c->lik_part.ptr, c->k,    \
-      c->l, c->kp, c->lp)
-#define LIK_LW(G_, TL_)                                                                           \
-  do {                                                                                            \
-    switch (LW) {                                                                                 \
-      case 4: LIK_GO(4, G_, TL_); break;                                                          \
-      case 8: LIK_GO(8, G_, TL_); break;                                                          \
-      case 12: LIK_GO(12, G_, TL_); break;                                                        \
-      case 16: LIK_GO(16, G_, TL_); break;                                                        \
-      default: LIK_GO(20, G_, TL_); break;                                                        \
-    }                                                                                             \
-  } while (0)
-  if (G == 1) {
-    if (tl) LIK_LW(1, true); else LIK_LW(1, false);
-  } else if (G == 2) {
-    LIK_LW(2, true);
-  } else if (G == 4) {
-    LIK_LW(4, true);
-  } else {
-    LIK_LW(8, true);
-  }
-#undef LIK_LW
-#undef LIK_GO
-  return nb;
-}
-}  // namespace
-
-namespace {
-// ---- the likelihood pair by pair (lik_fact.hpp): logarithm tables, then one wave per (item, rating) pair.
-// For rows of more than 32 groups (one column per lane: narrower rows would leave most of a wave idle), tiles
-// that fit the LDS beside their logarithms, and data with a few triples per pair (the pair's eta p products
-// are shared by four triples at a time).  Returns the number of partial sums.
-bool lik_pairs_usable(const mmsbm_hip_ctx *c) {
-  return c->lik_mode == 2 && c->lp > 32 && c->lp <= 192 && c->kp <= 192 && c->n_lik_units > 0 && c->n_pairs > 0 &&
-         (2 * static_cast<size_t>(c->kp) * c->lp + c->kp) * sizeof(double) <= kLdsMax - 4096 &&
-         c->n_obs * 2 >= static_cast<int64_t>(c->n_pairs) * 5;
-}
-int likelihood_pairs(mmsbm_hip_ctx *c) {
-  ensure_a(c);  // (s_t = theta_t . A[q])
-  const int cur = c->cur, sl = c->sel;
-  hipStream_t st = c->stream;
-  const size_t nt = static_cast<size_t>(c->n_users) * c->kp, ne = static_cast<size_t>(c->n_items) * c->lp;
-  const size_t np = static_cast<size_t>(c->n_ratings) * c->kp * c->lp;
-  if (c->lg_theta.count < 2 * nt) c->lg_theta.alloc(2 * nt);  // here: (theta, log theta) pairs, plain rows
-  if (c->lg_eta.count < ne) c->lg_eta.alloc(ne);
-  if (c->lg_p.count < np) c->lg_p.alloc(np);
-  auto blocks = [](size_t n) { return static_cast<unsigned>((n + kBlock - 1) / kBlock); };
-  const RowTab th = theta_tab(c, cur);
-  double2 *tl = reinterpret_cast<double2 *>(c->lg_theta.ptr);
-  const double *eta = c->eta[cur].at(sl), *p = c->p[cur].at(sl);
-  if (nt > 0) theta_log_pairs_kernel<<<blocks(nt), kBlock, 0, st>>>(th, tl, static_cast<size_t>(c->n_users), c->kp);
-  if (ne > 0) log_table_kernel<<<blocks(ne), kBlock, 0, st>>>(eta, c->lg_eta.ptr, ne);
-  log_table_kernel<<<blocks(np), kBlock, 0, st>>>(p, c->lg_p.ptr, np);
-  const int nb = c->n_lik_units;
-  if (c->lik_part.count < static_cast<size_t>(nb)) c->lik_part.alloc(static_cast<size_t>(nb));
-  const size_t lds = (2 * static_cast<size_t>(c->kp) * c->lp + c->kp) * sizeof(double);
-#define WAVE_GO(LW_)                                                                                 \
-  do {                                                                                               \
-    allow_big_lds(lik_wave_kernel<LW_>, lds);                                                        \
-    lik_wave_kernel<LW_><<<nb, kLikWaveThreads, lds, st>>>(                                          \
-        c->lik_units.ptr, c->pair_off.ptr, c->pair_user.ptr, c->pair_item.ptr, tl, a_tab(c, cur),    \
-        eta, c->lg_eta.ptr, p, c->lg_p.ptr, c->lik_part.ptr, c->k, c->l, c->kp, c->lp);              \
-  } while (0)
-  if (c->lp <= 64) WAVE_GO(1); else if (c->lp <= 128) WAVE_GO(2); else WAVE_GO(3);
-#undef WAVE_GO
-  return nb;
-}
-
-// ---- rows of up to 32 groups: a lane per triple, the tile through scalar loads (lik_fact.hpp: lik_lane_kernel) ----
-constexpr int kLikLaneThreads = 128;
-bool lik_lanes_usable(const mmsbm_hip_ctx *c) {
-  return c->lik_mode == 2 && c->kp <= 32 && c->lp <= 32 && c->n_lik_units > 0 && c->n_pairs > 0;
-}
-int likelihood_lanes(mmsbm_hip_ctx *c) {
-  ensure_a(c);  // (s_n = theta_n . A[q_n])
-  const int cur = c->cur, sl = c->sel;
-  hipStream_t st = c->stream;
-  const size_t nt = static_cast<size_t>(c->n_users) * c->kp, ne = static_cast<size_t>(c->n_items) * c->lp;
-  const size_t np = static_cast<size_t>(c->n_ratings) * c->kp * c->lp;
-  if (c->lg_theta.count < 2 * nt) c->lg_theta.alloc(2 * nt);  // (value, logarithm) pairs, plain rows
-  if (c->lg_eta.count < 2 * ne) c->lg_eta.alloc(2 * ne);
-  if (c->lg_p.count < 2 * np + 16) c->lg_p.alloc(2 * np + 16);   // (+ 16: lik_lane_kernel's scalar loads run one chunk ahead)
-  auto blocks = [](size_t n) { return static_cast<unsigned>((n + kBlock - 1) / kBlock); };
-  double2 *tl = reinterpret_cast<double2 *>(c->lg_theta.ptr), *el = reinterpret_cast<double2 *>(c->lg_eta.ptr);
-  double2 *ptl = reinterpret_cast<double2 *>(c->lg_p.ptr);
-  if (nt > 0) theta_log_pairs_kernel<<<blocks(nt), kBlock, 0, st>>>(theta_tab(c, cur), tl, static_cast<size_t>(c->n_users), c->kp);
-  if (ne > 0) theta_log_pairs_kernel<<<blocks(ne), kBlock, 0, st>>>(plain_tab(c->eta[cur].at(sl), c->lp), el, static_cast<size_t>(c->n_items), c->lp);
-  theta_log_pairs_kernel<<<blocks(np), kBlock, 0, st>>>(plain_tab(c->pt[cur].at(sl), c->kp), ptl,
-                                                         static_cast<size_t>(c->n_ratings) * c->lp, c->kp);   // pT: [R][lp][kp]
-  const int nb = c->n_lik_units;
-  if (c->lik_part.count < static_cast<size_t>(nb)) c->lik_part.alloc(static_cast<size_t>(nb));
-#define LANE_GO(KP_)                                                                                          \
-  lik_lane_kernel<KP_, kLikLaneThreads><<<nb, kLikLaneThreads, 0, st>>>(                                      \
-      c->lik_units.ptr, c->pair_off.ptr, c->pair_user.ptr, c->pair_item.ptr, tl, a_tab(c, cur), el, ptl,     \
-      c->lik_part.ptr, c->k, c->l, c->lp)
-  switch (c->kp) {
-    case 4: LANE_GO(4); break;
-    case 8: LANE_GO(8); break;
-    case 12: LANE_GO(12); break;
-    case 16: LANE_GO(16); break;
-    case 20: LANE_GO(20); break;
-    case 24: LANE_GO(24); break;
-    case 28: LANE_GO(28); break;
-    default: LANE_GO(32); break;
-  }
-#undef LANE_GO
-  return nb;
-}
-
-// likelihood of the selected slot (the caller holds a OneSlot): kernels onto the context's stream, no wait;
-// returns the number of partial sums likelihood_finish adds up
-int likelihood_enqueue(mmsbm_hip_ctx *ctx) {
-  const int cur = ctx->cur, sl = ctx->sel;
-  int nb;
-  if (lik_pairs_usable(ctx)) {
-    nb = likelihood_pairs(ctx);
-  } else if (lik_lanes_usable(ctx)) {
-    nb = likelihood_lanes(ctx);
-  } else if (lik_fast_usable(ctx)) {
-    nb = likelihood_fast(ctx);
-  } else {
-    const size_t lik_lds = static_cast<size_t>(ctx->kp + ctx->lp) * kLikThreads * sizeof(double);
-    if (lik_lds <= kLdsMax - 2048 && ctx->n_lik_units > 0) {
-      nb = ctx->n_lik_units;
-      allow_big_lds(likelihood_units_kernel, lik_lds);
-      if (ctx->lik_part.count < static_cast<size_t>(nb)) ctx->lik_part.alloc(nb);
-      likelihood_units_kernel<<<nb, kLikThreads, lik_lds, ctx->stream>>>(
-          ctx->lik_units.ptr, ctx->pair_off.ptr, ctx->pair_user.ptr, ctx->pair_item.ptr,
-          theta_tab(ctx, cur), ctx->eta[cur].at(sl), ctx->p[cur].at(sl), ctx->lik_part.ptr, ctx->k,
-          ctx->l, ctx->kp, ctx->lp);
-    } else {
-      nb = static_cast<int>(std::min<int64_t>((ctx->n_obs + kBlock - 1) / kBlock, 4096));
-      nb = std::max(nb, 1);
-      likelihood_kernel<<<nb, kBlock, 0, ctx->stream>>>(
-          ctx->orig_u.ptr, ctx->orig_i.ptr, ctx->orig_r.ptr, theta_tab(ctx, cur),
-          ctx->eta[cur].at(sl), ctx->p[cur].at(sl), ctx->lik_part.ptr, ctx->n_obs, ctx->k, ctx->l,
-          ctx->kp, ctx->lp);
-    }
-  }
-  HIP_CHECK(hipGetLastError());
-  return nb;
-}
 double likelihood_finish(mmsbm_hip_ctx *ctx, int nb) {  // workgroup sums added in workgroup order
   std::vector<double> part(nb);
   HIP_CHECK(hipMemcpyAsync(part.data(), ctx->lik_part.ptr, sizeof(double) * nb, hipMemcpyDeviceToHost, ctx->stream));
@@ -898,17 +1087,7 @@ int mmsbm_hip_compute_omegas(mmsbm_hip_ctx *ctx, double *out, int64_t capacity_e
     DevBuf<double> dev;
     dev.alloc(static_cast<size_t>(n_elems));
     OneSlot one(ctx);
-    const int cur = ctx->cur, sl = ctx->sel;
-    // internal (k,l) -> external position: not swapped [k][l] strides (L,1); swapped the
-    // external tensor is [l_int][k_int] so strides are (1, K_int)
-    const int sk = ctx->swapped ? 1 : ctx->l;
-    const int sl_stride = ctx->swapped ? ctx->k : 1;
-    const int64_t nb = (n_elems + kBlock - 1) / kBlock;
-    omegas_kernel<<<static_cast<unsigned>(nb), kBlock, 0, ctx->stream>>>(
-        ctx->orig_u.ptr, ctx->orig_i.ptr, ctx->orig_r.ptr, theta_tab(ctx, cur),
-        ctx->eta[cur].at(sl), ctx->p[cur].at(sl), dev.ptr, n_elems, ctx->k, ctx->l, ctx->kp,
-        ctx->lp, sk, sl_stride);
-    HIP_CHECK(hipGetLastError());
+    omegas_launch(ctx, dev.ptr, n_elems);
     HIP_CHECK(hipMemcpyAsync(out, dev.ptr, sizeof(double) * n_elems, hipMemcpyDeviceToHost,
                              ctx->stream));
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -957,30 +1136,6 @@ bool rows_fast_prepare(mmsbm_hip_ctx *c, int64_t n_rows) {
   }
   return true;
 }
-// B for the selected slot (the caller holds a OneSlot and rows_fast_prepare said yes), then one group of
-// lanes per row.
-// mode 0: dist[m][r] = P[m, r];  mode 1: dist += P, block_out = the restart's six sums per workgroup
-int rows_launch(mmsbm_hip_ctx *c, int mode, const int32_t *pu, const int32_t *pi, const int32_t *preal,
-                const double *weights, double *dist, double *block_out, int64_t n_rows, int first) {
-  stage_matvec_a(c, c->cur, c->cur, true);
-  const int per = kBlock / group_lanes(c->code_k);
-  const int nb = static_cast<int>((n_rows + per - 1) / per);
-  const size_t rstride = static_cast<size_t>(c->n_items) * c->kp;
-#define CALL(G, V)                                                                                           \
-  do {                                                                                                       \
-    if (mode == 0)                                                                                           \
-      predict_rows_kernel<G, V, 0><<<nb, kBlock, 0, c->stream>>>(pu, pi, preal, theta_tab(c, c->cur), c->btab.ptr, \
-          rstride, weights, dist, block_out, n_rows, c->n_ratings, c->kp, first);                            \
-    else                                                                                                     \
-      predict_rows_kernel<G, V, 1><<<nb, kBlock, 0, c->stream>>>(pu, pi, preal, theta_tab(c, c->cur), c->btab.ptr, \
-          rstride, weights, dist, block_out, n_rows, c->n_ratings, c->kp, first);                            \
-  } while (0)
-  DISPATCH_GV(c->code_k, CALL);
-#undef CALL
-  HIP_CHECK(hipGetLastError());
-  return nb;
-}
-
 }  // namespace
 
 int mmsbm_hip_prod_dist(mmsbm_hip_ctx *ctx, int64_t n_pairs, const int32_t *user,
@@ -1005,16 +1160,8 @@ int mmsbm_hip_prod_dist(mmsbm_hip_ctx *ctx, int64_t n_pairs, const int32_t *user
     HIP_CHECK(hipMemcpyAsync(du.ptr, iu, sizeof(int32_t) * n_pairs, hipMemcpyHostToDevice, ctx->stream));
     HIP_CHECK(hipMemcpyAsync(di.ptr, ii, sizeof(int32_t) * n_pairs, hipMemcpyHostToDevice, ctx->stream));
     OneSlot one(ctx);
-    const int cur = ctx->cur, sl = ctx->sel;
-    if (rows_fast_prepare(ctx, n_pairs)) {
-      rows_launch(ctx, 0, du.ptr, di.ptr, nullptr, nullptr, dout.ptr, nullptr, n_pairs, 1);
-    } else {
-      const int64_t nb = (n_elems + kBlock - 1) / kBlock;
-      prod_dist_kernel<<<static_cast<unsigned>(nb), kBlock, 0, ctx->stream>>>(
-          du.ptr, di.ptr, theta_tab(ctx, cur), ctx->eta[cur].at(sl), ctx->p[cur].at(sl), dout.ptr,
-          n_pairs, ctx->n_ratings, ctx->k, ctx->l, ctx->kp, ctx->lp);
-      HIP_CHECK(hipGetLastError());
-    }
+    if (rows_fast_prepare(ctx, n_pairs)) rows_launch(ctx, 0, du.ptr, di.ptr, nullptr, nullptr, dout.ptr, nullptr, n_pairs, 1);
+    else prod_dist_launch(ctx, du.ptr, di.ptr, dout.ptr, n_pairs);
     HIP_CHECK(hipMemcpyAsync(out, dout.ptr, sizeof(double) * n_elems, hipMemcpyDeviceToHost, ctx->stream));
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
     ctx->btab.release();  // (the B table is scratch: restart slots are sized from the free memory)
@@ -1023,36 +1170,25 @@ int mmsbm_hip_prod_dist(mmsbm_hip_ctx *ctx, int64_t n_pairs, const int32_t *user
 
 namespace {
 void score_launch(mmsbm_hip_ctx *ctx, bool finish, double *stats) {
+  const int n_stats = score_stats_count();
   const bool fast = !finish && rows_fast_prepare(ctx, ctx->ps_rows);
   const int per_block = fast ? kBlock / group_lanes(ctx->code_k) : kBlock;
   const int64_t nb64 = (ctx->ps_rows + per_block - 1) / per_block;
   const int nb = static_cast<int>(nb64);
-  if (ctx->ps_part.count < static_cast<size_t>(nb) * kScoreStats) ctx->ps_part.alloc(static_cast<size_t>(nb) * kScoreStats);
-  const int cur = ctx->cur, sl = ctx->sel;
-  if (nb > 0 && fast) {
+  if (ctx->ps_part.count < static_cast<size_t>(nb) * n_stats) ctx->ps_part.alloc(static_cast<size_t>(nb) * n_stats);
+  if (nb > 0 && fast)
     rows_launch(ctx, 1, ctx->ps_u.ptr, ctx->ps_i.ptr, ctx->ps_r.ptr, ctx->ps_w.ptr, ctx->ps_sum.ptr, ctx->ps_part.ptr,
                 ctx->ps_rows, ctx->ps_added == 0 ? 1 : 0);
-  } else if (nb > 0) {
-    if (finish)
-      predict_score_kernel<true><<<nb, kBlock, 0, ctx->stream>>>(
-          ctx->ps_u.ptr, ctx->ps_i.ptr, ctx->ps_r.ptr, theta_tab(ctx, cur), ctx->eta[cur].at(sl),
-          ctx->p[cur].at(sl), ctx->ps_w.ptr, ctx->ps_sum.ptr, ctx->ps_part.ptr, ctx->ps_rows,
-          ctx->n_ratings, ctx->k, ctx->l, ctx->kp, ctx->lp, 0, static_cast<double>(ctx->ps_added));
-    else
-      predict_score_kernel<false><<<nb, kBlock, 0, ctx->stream>>>(
-          ctx->ps_u.ptr, ctx->ps_i.ptr, ctx->ps_r.ptr, theta_tab(ctx, cur), ctx->eta[cur].at(sl),
-          ctx->p[cur].at(sl), ctx->ps_w.ptr, ctx->ps_sum.ptr, ctx->ps_part.ptr, ctx->ps_rows,
-          ctx->n_ratings, ctx->k, ctx->l, ctx->kp, ctx->lp, ctx->ps_added == 0 ? 1 : 0, 1.0);
-    HIP_CHECK(hipGetLastError());
-  }
-  std::vector<double> part(static_cast<size_t>(nb) * kScoreStats);
+  else if (nb > 0)
+    score_rows_launch(ctx, finish);
+  std::vector<double> part(static_cast<size_t>(nb) * n_stats);
   if (nb > 0)
     HIP_CHECK(hipMemcpyAsync(part.data(), ctx->ps_part.ptr, sizeof(double) * part.size(),
                              hipMemcpyDeviceToHost, ctx->stream));
   HIP_CHECK(hipStreamSynchronize(ctx->stream));
-  for (int j = 0; j < kScoreStats; ++j) stats[j] = 0.0;
+  for (int j = 0; j < n_stats; ++j) stats[j] = 0.0;
   for (int b = 0; b < nb; ++b)
-    for (int j = 0; j < kScoreStats; ++j) stats[j] += part[static_cast<size_t>(b) * kScoreStats + j];
+    for (int j = 0; j < n_stats; ++j) stats[j] += part[static_cast<size_t>(b) * n_stats + j];
 }
 }  // namespace
 
@@ -1206,9 +1342,14 @@ int mmsbm_hip_kernel_bytes(const mmsbm_hip_ctx *ctx, int index, int64_t *bytes_r
 int mmsbm_hip_time_stage(mmsbm_hip_ctx *ctx, int stage, int reps, float *mean_us) {
   return guarded([&] {
     require_all_params(ctx);
-    ctx->ablate = stage >> 8;  // bits 8.. : phases to skip (timing experiments only)
+#ifdef MMSBM_ABLATE
+    ctx->ablate = stage >> 8;  // diagnostic build: bits 8.. = phases to skip
     stage &= 0xff;
     struct Reset { mmsbm_hip_ctx *c; ~Reset() { c->ablate = 0; } } reset{ctx};
+#else
+    if (stage >> 8)
+      throw ApiError(MMSBM_E_UNSUPPORTED, "time_stage: phase ablation (stage bits 8+) needs the diagnostic build (-DMMSBM_ABLATE, csrc/unity.hip)");
+#endif
     if (!mean_us || reps <= 0 || stage < 0 || stage >= K_COUNT)
       throw std::invalid_argument("bad argument");
     if ((stage == K_FUSED_PAIRS || stage == K_FUSED_TAIL) && !fused_possible(ctx))

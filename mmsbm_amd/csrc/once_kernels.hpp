@@ -1,5 +1,5 @@
 // once_kernels.hpp -- once-per-run kernels: likelihood, random start, prod_dist / predict / score, compute_omegas
-// Part of the single translation unit mmsbm_hip.hip (included there, in order; not a stand-alone header).
+// Included by the translation units that launch these kernels (see prelude.hpp for the order); not a stand-alone header.
 #pragma once
 
 namespace {

@@ -1,5 +1,5 @@
 // pair_block.hpp -- the pair stage on the vector ALUs: pair_block_kernel (T + S launch, A launch)
-// Part of the single translation unit mmsbm_hip.hip (included there, in order; not a stand-alone header).
+// Included by the translation units that launch these kernels (see prelude.hpp for the order); not a stand-alone header.
 #pragma once
 
 namespace {
@@ -19,35 +19,13 @@ namespace {
 // T-mode: in = C (contiguous), tile = p[r] as [Kp][Lp], out = T, DO_S on.
 // A-mode: in = eta gathered by pair_item, tile = pT[r] as [Lp][Kp], out = A.
 // ======================================================================================
-constexpr int kUnitPairs = 64;
-
-// Diagnostic build only (-DMMSBM_STAMPS): thread 0 of every workgroup of the pair stage records the
-// 100 MHz wall clock at its phase borders; nothing else in the kernels reads the buffer.
-#ifdef MMSBM_STAMPS
-constexpr int kStampSlots = 16, kStampBlocks = 8192;
-__device__ unsigned long long g_stamps[kStampBlocks * kStampSlots];
-#define STAMP(i)                                                                             \
-  do {                                                                                       \
-    if (threadIdx.x == 0 && blockIdx.x < kStampBlocks && blockIdx.y == 0)                    \
-      g_stamps[blockIdx.x * kStampSlots + (i)] = wall_clock64();                             \
-  } while (0)
-// where the workgroup runs: HW_ID (wave, SIMD, CU, SH, SE ...) in the low word, XCC_ID in the high one
-#define STAMP_WHERE(i)                                                                       \
-  do {                                                                                       \
-    if (threadIdx.x == 0 && blockIdx.x < kStampBlocks && blockIdx.y == 0)                    \
-      g_stamps[blockIdx.x * kStampSlots + (i)] =                                             \
-          static_cast<unsigned long long>(__builtin_amdgcn_s_getreg(4 | (31 << 11))) |      \
-          (static_cast<unsigned long long>(__builtin_amdgcn_s_getreg(20 | (31 << 11))) << 32); \
-  } while (0)
-#else
-#define STAMP(i) do {} while (0)
-#define STAMP_WHERE(i) do {} while (0)
-#endif
-
 struct PairBlockArgs {
   const double *tiles; const double *in_tab; const double *e_tab; const int32_t *pair_item;
   const mmsbm::Chunk *chunks; double *out; double *partial;
-  int din, dinp, doutp, spb, nsub, abl, nt;  // nt: output rows as non-temporal stores (bit 0: here, bit 1: pair_mfma_kernel's A rows)
+  int din, dinp, doutp, spb, nsub, nt;  // nt: output rows as non-temporal stores (bit 0: here, bit 1: pair_mfma_kernel's A rows)
+#ifdef MMSBM_ABLATE
+  int abl;  // diagnostic build only: phases to skip (mmsbm_hip_time_stage, stage >> 8)
+#endif
   // output rows: `out` is a plain [rows][doutp] table (T: out_mw == doutp, out_rs == doutp) or the
   // main part of a RowTab whose tail part starts at out_tail (A)
   int out_mw, out_rs_m, out_rs_t;
@@ -72,10 +50,15 @@ __device__ __forceinline__ void pair_block_body(const PairBlockArgs &pa,
   double *__restrict__ out = pa.out + slot * pa.bs_out;
   double *__restrict__ out_tail = pa.out_tail + slot * pa.bs_out_t;
   double *__restrict__ partial = pa.partial + slot * pa.bs_partial;
-  const int dinp = pa.dinp, doutp = pa.doutp, spb = pa.spb, abl = pa.abl;  // (rows >= din are zero)
+  const int dinp = pa.dinp, doutp = pa.doutp, spb = pa.spb;  // (rows >= din are zero)
   const int nsub = pa.nsub;
-  // abl: tuning aid, normally 0 -- bit0 rows, bit1 eta rows, bit2 S, bit3 mat-vec, bit4 output
-  // copy, bit5 slab store, bit6 tile staging are skipped when set
+  // abl: a compile-time 0 in the product.  The diagnostic build (-DMMSBM_ABLATE) takes it from the arguments -- bit0
+  // rows, bit1 eta rows, bit2 S, bit3 mat-vec, bit4 output copy, bit5 slab store are skipped when set
+#ifdef MMSBM_ABLATE
+  const int abl = pa.abl;
+#else
+  constexpr int abl = 0;
+#endif
   extern __shared__ double lds[];
   constexpr int CS = kUnitPairs + 1;  // odd stride: conflict-free column AND row reads
   double *cst = lds;                                  // [dinp][CS]
@@ -305,11 +288,6 @@ __device__ __forceinline__ void pair_block_body(const PairBlockArgs &pa,
 #endif
 }
 
-constexpr int kPairBlockMax = 512;
-
-constexpr int kQuadUnits = 4;  // 64-pair units a workgroup of pair_quad_a_kernel multiplies jointly
-constexpr int kQuadMaxL = 56;  // its input rows at most (14 double2 per thread and chunk; beyond: pair_block like every other shape)
-
 // (amdgpu_num_sgpr: a 256-thread workgroup is admitted floor(800 / (ceil(sgpr/16)*16 + 16)) times per
 // CU -- 106 SGPRs: 6, 96: 7 (MI355X_MICROARCH.md, residency).  At C3 the stage has 1,565 workgroups:
 // with 6 per CU (1,536 slots) 29 of them ran as a second round that doubled the launch's time.)
@@ -322,5 +300,58 @@ __attribute__((amdgpu_num_sgpr(96))) void pair_block_kernel(PairBlockArgs pa,
   pair_block_body<GATHER, DO_S, NACC, TLDS, NT, KT, DIRECT>(pa, tiles, blockIdx.x);
 }
 
+// ---- host side: the argument blocks of these kernels from the context ----
+PairBlockArgs pair_block_t_args(const mmsbm_hip_ctx *c) {
+  const int s = c->base_slot;
+  PairBlockArgs pa{};
+  pa.tiles = c->p[c->cur].at(s); pa.in_tab = c->ctab.at(s); pa.e_tab = c->eta[c->cur].at(s);
+  pa.pair_item = c->pair_item.ptr; pa.chunks = c->mv_chunks.ptr;
+  pa.out = c->ttab.at(s); pa.partial = c->partial.at(s);
+  pa.din = c->k; pa.dinp = c->kp; pa.doutp = c->lp; pa.spb = c->pb_spb; pa.nsub = c->pb_nsub;
+#ifdef MMSBM_ABLATE
+  pa.abl = c->ablate;
+#endif
+  pa.nt = nt_on(c) & 1;
+  pa.out_mw = c->lp; pa.out_rs_m = c->lp; pa.out_rs_t = 0; pa.out_tail = c->ttab.at(s);
+  pa.bs_tiles = c->p[0].stride; pa.bs_in = c->ctab.stride; pa.bs_e = c->eta[0].stride;
+  pa.bs_out = c->ttab.stride; pa.bs_out_t = 0; pa.bs_partial = c->partial.stride;
+  pa.mg0 = pa.mg1 = 0;  // (the T + S launch runs padded 16-tiles: its 128 registers do not hold the 4 x 4 blocks)
+  return pa;
+}
+PairBlockArgs pair_block_a_args(const mmsbm_hip_ctx *c, int param_slot, int a_slot) {
+  const int s = c->base_slot;  // (param_slot / a_slot: ping-pong buffer indices)
+  const RowTab at = a_tab(c, a_slot);
+  PairBlockArgs pa{};
+  pa.tiles = c->pt[param_slot].at(s); pa.in_tab = c->eta[param_slot].at(s); pa.e_tab = nullptr;
+  pa.pair_item = c->pair_item.ptr; pa.chunks = c->mv_chunks.ptr;
+  pa.out = at.main; pa.partial = nullptr;
+  pa.din = c->l; pa.dinp = c->lp; pa.doutp = c->kp; pa.spb = kBlock; pa.nsub = 1;
+#ifdef MMSBM_ABLATE
+  pa.abl = c->ablate;
+#endif
+  pa.nt = (nt_on(c) & 1) | (((c->nt_out & 1) && c->launch_slots == 1 && c->lay.pair_work.items.empty() && c->lay.user_work.items.empty()) ? 2 : 0);  // bit 1: the matrix-core A rows (C5 2,236 -> 2,215 us; T rows there: nothing)
+  pa.out_mw = at.mw; pa.out_rs_m = at.rs_m; pa.out_rs_t = at.rs_t; pa.out_tail = at.tail;
+  pa.bs_tiles = c->pt[0].stride; pa.bs_in = c->eta[0].stride; pa.bs_e = 0;
+  pa.bs_out = at.so_m; pa.bs_out_t = at.so_t; pa.bs_partial = 0;
+  mfma_geometry(pa.dinp, pa.doutp, &pa.mg0, &pa.mg1);
+  return pa;
+}
+// The A launch's arguments and workgroup count: A[q,:] from (eta, pT) of parameter buffer `slot` into atab[a_slot] -- or,
+// with `grid` set, the same mat-vec over every (item, rating) combination into the plain table btab (prod_dist / predict)
+PairBlockArgs matvec_a_args(const mmsbm_hip_ctx *c, int slot, int a_slot, bool grid, int *n_blocks) {
+  int nb = grid ? c->grid_n_chunks : static_cast<int>(c->lay.mv_chunks.size());
+  PairBlockArgs pa = pair_block_a_args(c, slot, a_slot);
+  if (!grid && c->mfma && c->n_a_chunks > 0) {  // the same units in runs of its own (create(): balanced_run_units)
+    pa.chunks = c->a_chunks.ptr;
+    nb = c->n_a_chunks;
+  }
+  if (grid) {
+    pa.pair_item = c->grid_item.ptr; pa.chunks = c->grid_chunks.ptr;
+    pa.out = c->btab.ptr; pa.out_tail = nullptr;
+    pa.out_mw = pa.doutp; pa.out_rs_m = pa.doutp; pa.out_rs_t = 0; pa.bs_out = 0; pa.bs_out_t = 0;
+  }
+  *n_blocks = nb;
+  return pa;
+}
 
 }  // namespace

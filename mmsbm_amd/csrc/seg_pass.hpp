@@ -1,5 +1,5 @@
 // seg_pass.hpp -- kernel 0: the two triple passes (pair segments, user segments) and the combine kernels of split segments
-// Part of the single translation unit mmsbm_hip.hip (included there, in order; not a stand-alone header).
+// Included by the translation units that launch these kernels (see prelude.hpp for the order); not a stand-alone header.
 #pragma once
 
 namespace {
@@ -14,27 +14,6 @@ namespace {
 //   user segments: fixed = theta, gath = A, out = theta * acc / d_u   (src/mmsbm.py:248)
 //   pair segments: fixed = A,     gath = theta, out = C = acc
 // ======================================================================================
-// A table of rows that are GATHERED by index (theta, A).  A 160-byte row (K = 20) straddles two
-// 128-byte cache lines; the table is therefore kept as a "main" part of whole 128-byte lines
-// (mw = 16 * floor(Kp/16) doubles per row, line aligned) plus a compact "tail" part
-// (tw = Kp - mw doubles per row), so a gather misses on one line of the big main part and
-// hits the small, cache-resident tail part.  mw == row width and tw == 0 describes a plain table.
-struct RowTab {
-  double *main;      // row r, off < mw:  main + r * rs_m + off
-  double *tail;      // row r, off >= mw: tail + r * rs_t + (off - mw)
-  int mw, tw;        // widths of the two parts (tw == 0: a plain table)
-  int rs_m, rs_t;    // row strides in doubles
-  size_t so_m, so_t; // distance between the copies of two consecutive restart slots (see below)
-};
-// Restart slots.  The two GATHERED tables (theta, A) keep the slots' copies of a row side by side:
-// row r = [slot 0 | slot 1 | ...], so rs_m = n_slots * mw, so_m = mw (and the same for the tail part).
-// One index then serves every slot and a gather of row r for all slots is ONE contiguous piece of
-// n_slots * 160 bytes at K = 20 -- whole 128-byte lines, no separate 32-byte tail access.  Streamed
-// tables (C, T, eta) are plain per-slot copies: rs_m = width, so_m = the table's size.
-__device__ __forceinline__ double *rowtab_ptr(const RowTab &t, size_t row, int off) {
-  return off < t.mw ? t.main + row * t.rs_m + off : t.tail + row * t.rs_t + (off - t.mw);
-}
-
 struct SegArgs {
   RowTab fixed;
   RowTab gath;
@@ -48,12 +27,6 @@ struct SegArgs {
   size_t bs_parts;               // restart slots: distance in doubles between the slots' partial rows
   int32_t nt_out = 0;            // bit 0: finished rows (mode != 0: theta') as non-temporal stores, bit 1: the segment's own row as a non-temporal load
 };
-__device__ __forceinline__ RowTab slot_tab(RowTab t, size_t slot) {
-  t.main += slot * t.so_m;
-  t.tail += slot * t.so_t;
-  return t;
-}
-
 // One body for both forms.  SW == 1: a group of G lanes per segment, the restart slot is blockIdx.y.
 // SW > 1: a "super-group" of SW x G lanes walks one segment for SW slots (lane = slot * G + gl).  The
 // slots' copies of a gathered row are neighbours in memory (RowTab), so one index load serves all of
@@ -361,6 +334,25 @@ __global__ __launch_bounds__(kBlock) void seg_combine_both_kernel(CombineArgs sa
   const int bx = static_cast<int>(blockIdx.x);
   if (bx < n_small) seg_combine_small<G, VEC>(sa, sb, bx, small_a, dp);
   else seg_combine_big<G, VEC>(ba, bb, bx - n_small, big_a, dp);
+}
+
+// ---- host side: the argument blocks of these kernels from the context ----
+SegArgs seg_pairs_args(const mmsbm_hip_ctx *c) {  // C = sum over a pair's triples
+  const bool it = !c->lay.pair_work.items.empty();
+  return SegArgs{a_tab(c, c->cur), theta_tab(c, c->cur), c->pair_off.ptr, c->pair_user.ptr,
+                 plain_tab(c->ctab.at(c->base_slot), c->kp, c->ctab.stride),
+                 it ? static_cast<int32_t>(c->lay.pair_work.items.size()) : c->n_pairs, 0,
+                 it ? c->pair_items.ptr : nullptr, c->pair_parts.at(c->base_slot), c->pair_parts.stride,
+                 nt_on(c) >> 1};
+}
+SegArgs seg_users_args(const mmsbm_hip_ctx *c, bool commit, int seg_end) {  // theta_new
+  const bool it = !c->lay.user_work.items.empty();
+  return SegArgs{theta_tab(c, c->cur),     a_tab(c, c->cur), c->user_off.ptr, c->user_pair.ptr,
+                 theta_tab(c, c->cur ^ 1),
+                 it ? static_cast<int32_t>(c->lay.user_work.items.size()) : seg_end,
+                 commit ? 1 : 2,
+                 it ? c->user_items.ptr : nullptr, c->user_parts.at(c->base_slot), c->user_parts.stride,
+                 nt_on(c) >> 1};
 }
 
 }  // namespace

@@ -12,11 +12,19 @@ the reference keeps working.  There is no CPU path behind these functions.
 
 The reference calls ``update_coefficients`` once per EM iteration with the same ``data``;
 the sorted device layout is therefore cached per training set, keyed on an EXACT digest of
-the three id columns (``core.data_key``: 128-bit XXH3 over every byte, 0.5 ms per million rows;
-computed beside the GPU work, see ``_run``), so only theta/eta/pr cross PCIe per call and two
+the three id columns (``core.data_key``: 128-bit XXH3 over every byte, about 2.4 ms per million
+(N, 3) int64 rows with the ``xxhash`` module, ten times that with the blake2b fall-back -- a warning says
+so once; computed beside the GPU work, see ``_run``), so only theta/eta/pr cross PCIe per call and two
 different training sets can never share a context.
+
+Which GPU: the reference starts one worker process per restart (src/mmsbm.py:182-185) and every worker imports
+this module afresh.  ``_lib.worker_device`` spreads them: ``MMSBM_HIP_DEVICE`` if set, else (worker number - 1)
+mod device count inside a multiprocessing child, else device 0 -- so ``sampling`` = 8 on an 8-GPU node uses all
+eight (the reference's own cupy backend leaves them all on GPU 0, README.md:186).
 """
 from __future__ import annotations
+
+import os
 
 import numpy as np
 
@@ -27,6 +35,7 @@ try:
     _lib.load()
     if _lib.device_count() < 1:
         raise RuntimeError("no HIP device visible")
+    _lib.worker_device(_lib.device_count())   # (a bad MMSBM_HIP_DEVICE makes the backend unusable: say so at import)
 except Exception as _hip_err:  # pragma: no cover - depends on the machine
     raise ImportError(
         "HIP backend selected, but libmmsbm_hip.so or a usable MI355X is not available: "
@@ -37,6 +46,24 @@ __all__ = ["compute_omegas", "update_coefficients", "prod_dist"]
 _CACHE_SLOTS = 2
 _cache = []  # [(fingerprint, HipEM, where)], most recent first
 _pool = None  # one helper thread for the digest (made at the first call: importing stays cheap and spawn-safe)
+_pool_pid = None  # the process that made it: a forked child inherits the object but not its thread
+
+
+def device():
+    """The GPU this process's level-1 calls run on (``_lib.worker_device``; read again at every call, so that a
+    change of MMSBM_HIP_DEVICE takes effect)."""
+    return _lib.worker_device(_lib.device_count())
+
+
+def _digest_pool():
+    """The helper thread for the digest.  Rebuilt in a process that did not make it: after fork() the executor
+    object is there but its worker thread is not, and ``result()`` would wait for ever."""
+    global _pool, _pool_pid
+    if _pool is None or _pool_pid != os.getpid():
+        from concurrent.futures import ThreadPoolExecutor
+        _pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="mmsbm-digest")
+        _pool_pid = os.getpid()
+    return _pool
 
 
 def _fingerprint(data, theta, eta, pr):
@@ -63,15 +90,16 @@ def _context(data, theta, eta, pr, key=None):
     """The context of exactly this training set and these shapes (built if need be), parameters uploaded."""
     theta, eta, pr = _checked(theta, eta, pr)
     key = key or _fingerprint(data, theta, eta, pr)
+    dev = device()
     for j, (k, ctx, _) in enumerate(_cache):
-        if k == key:
+        if k == key and ctx.device == dev:
             if j:
                 _cache.insert(0, _cache.pop(j))
             _cache[0] = (key, ctx, _where(data))
             break
     else:
         ctx = HipEM(data, theta.shape[1], eta.shape[1], n_users=theta.shape[0],
-                    n_items=eta.shape[0], n_ratings=pr.shape[2])
+                    n_items=eta.shape[0], n_ratings=pr.shape[2], device=dev)
         _cache.insert(0, (key, ctx, _where(data)))
         while len(_cache) > _CACHE_SLOTS:
             _cache.pop()[1].close()
@@ -83,16 +111,14 @@ def _run(data, theta, eta, pr, op):
     """``op(context)`` on the context of ``data``.  The reference passes the SAME array on every iteration
     (src/mmsbm.py:244): when the most recent context was built for an array object at this address and of this shape,
     the call goes ahead on it at once -- upload, kernels, download; ctypes releases the GIL -- while a helper thread
-    computes the exact digest of the id columns (0.5 ms per million rows, a fifth of the call); the result is handed
+    computes the exact digest of the id columns (about 2.4 ms per million (N, 3) int64 rows with xxhash: as long as the
+    GPU side of a C3-sized call, so it hides behind it; the blake2b fall-back does not); the result is handed
     out only if the digest confirms the context, otherwise it is dropped and the call is repeated on the right one.
     Two different training sets still never share a context; the digest just no longer waits in front of the GPU."""
-    global _pool
     theta, eta, pr = _checked(theta, eta, pr)
-    if _cache and _cache[0][2] == _where(data) and _cache[0][0][1:] == (theta.shape, eta.shape, pr.shape):
-        if _pool is None:
-            from concurrent.futures import ThreadPoolExecutor
-            _pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="mmsbm-digest")
-        digest = _pool.submit(data_key, data)
+    if (_cache and _cache[0][2] == _where(data) and _cache[0][0][1:] == (theta.shape, eta.shape, pr.shape)
+            and _cache[0][1].device == device()):
+        digest = _digest_pool().submit(data_key, data)
         key0, ctx = _cache[0][0], _cache[0][1]
         ctx.set_params(theta, eta, pr)
         out = op(ctx)

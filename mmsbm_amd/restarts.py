@@ -19,11 +19,21 @@ from __future__ import annotations
 
 import os
 
-import numpy as np
-import torch
-import torch.distributed as dist
+# RCCL's intra-node transport (and torch's sharing of device tensors between processes) hands device memory from one
+# process to another through hipIpcGetMemHandle / hipIpcOpenMemHandle.  On hosts whose driver only supports dmabuf IPC
+# -- the MI355X pool this was built on -- the HSA runtime's legacy IPC mode fails there (`hipIpcGetMemHandle: invalid
+# argument`); HSA_ENABLE_IPC_MODE_LEGACY=0 selects the dmabuf path.  Measured (scripts/ipc_mode_probe.py, one GPU, a
+# device buffer opened by a spawned child): works with the variable at 0, fails with it unset.  The runtime reads it
+# when it starts, i.e. at the process's FIRST HIP call, so the default goes in here -- at import, before torch or the
+# library can have made one -- for every rank whatever launched it (torchrun, the driver, a scheduler).  A value the
+# caller has set is left alone.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
-from . import _lib
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from . import _lib  # noqa: E402
 
 
 def shard_restarts(sampling, rank, world):
@@ -39,6 +49,7 @@ def init_from_env(backend=None, force_init=False, timeout=None):
     group's rendezvous and collectives; None keeps torch's default, so that a dead rank or mismatched
     collectives surface after minutes, not half an hour (bench.py passes a long one: its rank 0 times the CPU
     baseline before it joins)."""
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # (see the top of this module: before the first HIP call)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -72,6 +83,51 @@ def barrier(device=None):
         dist.barrier(device_ids=[device.index])
     else:
         dist.barrier()
+
+
+def distinct_device_error(records, world, share_gpu=False):
+    """None when the ``world`` ranks sit on ``world`` different GPUs, else what is wrong, as a string.
+
+    ``records``: one dict per rank with "hostname" and "pci_bus_id" (bench.gather_ranks).  A launcher that leaves
+    LOCAL_RANK unset puts every rank on GPU 0: the job still runs, returns 0 and reports a plausible number -- for
+    ONE GPU's worth of hardware.  ``share_gpu`` (a rehearsal on a one-GPU box) is the only legitimate case."""
+    if share_gpu:
+        return None
+    if len(records) != world:
+        return f"{len(records)} rank record(s) for a world of {world}"
+    seen = {}
+    for r in records:
+        seen.setdefault((r.get("hostname"), r.get("pci_bus_id")), []).append(r.get("rank"))
+    if len(seen) == world:
+        return None
+    shared = "; ".join(f"{host} {bus}: ranks {ranks}" for (host, bus), ranks in seen.items() if len(ranks) > 1)
+    return (f"{world} ranks on {len(seen)} distinct GPU(s) ({shared}) -- is LOCAL_RANK set by the launcher? "
+            "(--share-gpu allows it for a rehearsal)")
+
+
+def require_distinct_devices(local, device=None, share_gpu=False):
+    """Every rank of the process group on its own GPU, or SystemExit on EVERY rank: one all_gather of the ranks'
+    (hostname, PCI bus id), padded to fixed-size byte tensors.  Call it before the first restart starts."""
+    if not _grouped():
+        return
+    import socket
+    rank, world = dist.get_rank(), dist.get_world_size()
+    mine = f"{socket.gethostname()}|{_lib.device_identity(local)['pci_bus_id']}".encode()[:255]
+    coll = _collective_device(device)
+    buf = torch.zeros(256, dtype=torch.uint8)
+    buf[:len(mine)] = torch.frombuffer(bytearray(mine), dtype=torch.uint8)
+    buf = buf.to(coll)
+    parts = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(parts, buf)
+    recs = []
+    for r, p in enumerate(parts):
+        host, _, bus = bytes(p.cpu().numpy().tobytes()).rstrip(b"\0").decode().partition("|")
+        recs.append({"rank": r, "hostname": host, "pci_bus_id": bus})
+    err = distinct_device_error(recs, world, share_gpu)
+    if err:
+        dist.destroy_process_group()
+        raise SystemExit(f"mmsbm_amd.restarts: {err}")
+    return recs
 
 
 def check_single_hip_runtime():

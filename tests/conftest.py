@@ -10,6 +10,15 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# Launch log (mmsbm_amd/csrc/launch.hpp): on for every test run, so that the -m gpu suite leaves a record of WHICH kernel
+# instantiations it launched, how often and under which test -- scripts/kernel_coverage.py diffs it against the compiled
+# set (profiles/r6_kernel_coverage.csv).  The library reads the variable when it is loaded, so it is set here, before any
+# test module imports it; child processes the tests start inherit it and append to the same file.  Host code only;
+# without a GPU nothing is launched and no file appears.  MMSBM_HIP_LAUNCH_LOG= (empty) switches it off.
+os.environ.setdefault("MMSBM_HIP_LAUNCH_LOG", os.path.join(ROOT, "gpurun_out", "launch_log.tsv"))
+if os.environ["MMSBM_HIP_LAUNCH_LOG"]:
+    os.makedirs(os.path.dirname(os.path.abspath(os.environ["MMSBM_HIP_LAUNCH_LOG"])), exist_ok=True)
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
@@ -21,6 +30,14 @@ def pytest_configure(config):
         ensure_library()
     except Exception as exc:  # noqa: BLE001
         sys.stderr.write(f"[conftest] library not built: {exc}\n")
+
+
+@pytest.fixture(autouse=True)
+def _launch_tag(request):
+    """The running test's id, recorded with the first launch of every kernel instantiation (launch log)."""
+    os.environ["MMSBM_HIP_LAUNCH_TAG"] = request.node.nodeid
+    yield
+    os.environ["MMSBM_HIP_LAUNCH_TAG"] = "-"
 
 
 def load_golden(name):

@@ -143,3 +143,88 @@ def test_per_rank_records_travel_as_one_tensor_all_gather(tmp_path):
     for rank, p in enumerate(procs):
         out = p.communicate(timeout=240)[0]
         assert p.returncode == 0 and f"rank {rank} ok" in out, out[-2000:]
+
+
+# ---- the first real N-GPU run must not be able to lie or to trip ("What's weak" 6) ----------------------
+
+def test_distinct_device_error():
+    from mmsbm_amd import restarts
+    recs = [{"rank": r, "hostname": "node0", "pci_bus_id": "0000:%02x:00.0" % (5 + r)} for r in range(4)]
+    assert restarts.distinct_device_error(recs, 4) is None
+    same = [dict(r, pci_bus_id="0000:05:00.0") for r in recs]
+    err = restarts.distinct_device_error(same, 4)
+    assert err and "4 ranks on 1 distinct GPU(s)" in err and "LOCAL_RANK" in err and "[0, 1, 2, 3]" in err
+    assert restarts.distinct_device_error(same, 4, share_gpu=True) is None          # the rehearsal
+    two = [recs[0], recs[1], dict(recs[2], pci_bus_id=recs[1]["pci_bus_id"]), recs[3]]
+    assert "4 ranks on 3 distinct GPU(s)" in restarts.distinct_device_error(two, 4)
+    # the same bus id on two HOSTS is two GPUs
+    hosts = [dict(r, hostname=f"node{r['rank']}", pci_bus_id="0000:05:00.0") for r in recs]
+    assert restarts.distinct_device_error(hosts, 4) is None
+    assert "3 rank record(s) for a world of 4" in restarts.distinct_device_error(recs[:3], 4)
+
+
+def test_bench_refuses_ranks_without_local_rank():
+    """Under a launcher that sets WORLD_SIZE but not LOCAL_RANK every rank would take GPU 0 and the line would still
+    look plausible: bench.py stops before any rendezvous, non-zero, nothing on stdout."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("LOCAL_RANK",)}
+    env.update(WORLD_SIZE="2", RANK="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="1", MMSBM_HIP_LAUNCH_LOG="")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and r.stdout.strip() == "" and "LOCAL_RANK" in r.stderr, (r.returncode, r.stderr[-800:])
+
+
+def test_ranks_get_the_dmabuf_ipc_default_before_their_first_hip_call():
+    """HSA_ENABLE_IPC_MODE_LEGACY=0 (mmsbm_amd/restarts.py says why) is set by importing the module every multi-GPU
+    entry point imports first -- whatever launched the rank -- and a value the caller chose is kept."""
+    import subprocess
+    code = ("import os, sys; sys.path.insert(0, %r); import mmsbm_amd.restarts; "
+            "print(os.environ['HSA_ENABLE_IPC_MODE_LEGACY'])" % ROOT)
+    env = {k: v for k, v in os.environ.items() if k != "HSA_ENABLE_IPC_MODE_LEGACY"}
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip() == "0", r.stderr[-800:]
+    r = subprocess.run([sys.executable, "-c", code], env=dict(env, HSA_ENABLE_IPC_MODE_LEGACY="1"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip() == "1", r.stderr[-800:]
+
+
+DISTINCT_WORKER = """
+import os, sys
+sys.path.insert(0, {root!r})
+import torch, torch.distributed as dist
+from mmsbm_amd import restarts, _lib
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+same = {same!r}
+_lib.device_identity = lambda d: {{"pci_bus_id": "0000:05:00.0" if same else "0000:%02x:00.0" % (5 + rank)}}
+dist.init_process_group("gloo", rank=rank, world_size=world)
+try:
+    recs = restarts.require_distinct_devices(0, torch.device("cpu"))
+except SystemExit as e:
+    assert same and "2 ranks on 1 distinct GPU(s)" in str(e), e
+    assert not dist.is_initialized()          # every rank left the group together
+    print("rank", rank, "refused")
+else:
+    assert not same and [r["rank"] for r in recs] == [0, 1]
+    dist.destroy_process_group()
+    print("rank", rank, "ok")
+"""
+
+
+@pytest.mark.parametrize("same", [False, True])
+def test_two_gloo_ranks_on_one_gpu_are_refused_on_every_rank(tmp_path, same):
+    import socket
+    import subprocess
+    script = tmp_path / "distinct_worker.py"
+    script.write_text(DISTINCT_WORKER.format(root=ROOT, same=same))
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    for rank, p in enumerate(procs):
+        out = p.communicate(timeout=240)[0]
+        assert p.returncode == 0 and f"rank {rank} {'refused' if same else 'ok'}" in out, out[-2000:]

@@ -216,3 +216,23 @@ def test_slot_batches_are_sized_for_the_workers_that_share_a_gpu(fake):
     mm = host.MMSBM(2, 2, devices=[0, 1, 0], contexts_per_device=2)
     assert mm._sharers(0) == 4 and mm._sharers(1) == 2
     assert host.MMSBM(2, 2)._sharers(0) == 1
+
+
+def test_level1_worker_device_rule():
+    """Which GPU a level-1 process works on (mmsbm_amd/_lib.py: worker_device): MMSBM_HIP_DEVICE, else the
+    multiprocessing worker number round robin, else device 0.  The reference's Pool(processes=sampling)
+    (src/mmsbm.py:182-185) numbers its workers 1..sampling."""
+    from mmsbm_amd import _lib
+    wd = _lib.worker_device
+    assert wd(8, env={}, identity=()) == 0                                   # the main process
+    assert [wd(8, env={}, identity=(j,)) for j in range(1, 10)] == [0, 1, 2, 3, 4, 5, 6, 7, 0]
+    assert [wd(2, env={}, identity=(j,)) for j in range(1, 5)] == [0, 1, 0, 1]
+    assert wd(1, env={}, identity=(5,)) == 0
+    assert wd(8, env={}, identity=(2, 3)) == 2                               # a worker of a worker: its own number
+    assert wd(8, env={"MMSBM_HIP_DEVICE": "5"}, identity=(1,)) == 5
+    assert wd(8, env={"MMSBM_HIP_DEVICE": " 0 "}, identity=(4,)) == 0
+    import pytest
+    for bad in ("8", "-1", "gpu0"):
+        with pytest.raises(ValueError):
+            wd(8, env={"MMSBM_HIP_DEVICE": bad}, identity=())
+    assert wd(0, env={}, identity=(3,)) == 0                                 # no device visible: index 0, create() says no
