@@ -202,11 +202,17 @@ int mmsbm_hip_time_stage(mmsbm_hip_ctx *ctx, int stage, int reps, float *mean_us
  * 0/1/2/4/8 (lanes per triple of the table form, 0 = automatic), "predict_fast" 0/1 (prod_dist / predict through the
  * table of p_r eta_i over every (item, rating) combination -- the default where the rows are not far fewer than the
  * items -- or through the one-thread-per-row kernels), "nt_out" 0..15 (bits: non-temporal stores of the T / A rows,
- * of the theta' rows, non-temporal loads of the segments' own rows; 8: whatever the data; results are bitwise the same). */
+ * of the theta' rows, non-temporal loads of the segments' own rows; 8: whatever the data; results are bitwise the same),
+ * "a_units" 0..16 (matrix-core pair stage only: 64-pair units per workgroup of the A launch, which writes rows only and
+ * so walks the units in runs of its own length; 0 = the library's choice -- the length that fills its last round of
+ * workgroups; the rows are bitwise the same for every value). */
 int mmsbm_hip_set_option(mmsbm_hip_ctx *ctx, const char *name, double value);
 /* Reads a switch back; also the read-only "launches" (2 or 4: what the next iteration takes), "ranges_pairs" / "ranges_users" (ranges the XCD-local work
  * list of that pass uses, 1 = off), "items_pairs" / "items_users" (work items, 0 = segments as
- * they are) and "wide" (1: K, L beyond the 64-pair LDS stage -- the vector form of the pair stage is then the plain
+ * they are), "splits_pairs" / "splits_users" (segments cut into pieces), "fused_split" (bit 0 / 1: whole-segment lists of
+ * the two-launch form built for the pair / user side), "chunk_pairs" (pairs per pair-stage workgroup at most), "n_chunks"
+ * (pair-stage workgroups = slabs, padding included), "a_chunks" (workgroups of the matrix-core A launch when it walks
+ * runs of its own; 0: the T + S launch's list serves) and "wide" (1: K, L beyond the 64-pair LDS stage -- the vector form of the pair stage is then the plain
  * wide-row kernels; they run when "mfma" reads 0, the blocked matrix-core kernels when it reads 2). */
 int mmsbm_hip_get_option(const mmsbm_hip_ctx *ctx, const char *name, double *value);
 /* How em_iterate launches: 0 (default) = eager launches on the context's stream; 1 = replay

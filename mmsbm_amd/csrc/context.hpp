@@ -199,7 +199,7 @@ struct mmsbm_hip_ctx {
   DevBuf<mmsbm::Chunk> mv_chunks;
   DevBuf<mmsbm::Chunk> lik_units;  // 64-pair units for the likelihood kernel (mv_chunks may hold 256)
   DevBuf<mmsbm::Chunk> a_chunks;   // matrix-core A launch: its own runs of units (balanced_run_units, stages.hpp), when they differ from mv_chunks
-  int n_a_chunks = 0;
+  int n_a_chunks = 0, a_units = 0;   // (a_units: 64-pair units per workgroup of that launch; option "a_units")
   int n_lik_units = 0;
   DevBuf<mmsbm::WorkItem> pair_items, user_items;   // only when some segment is long
   DevBuf<mmsbm::SplitSeg> pair_splits, user_splits;

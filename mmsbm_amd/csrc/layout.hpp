@@ -296,20 +296,27 @@ constexpr int32_t kMvChunkPairs = 64;  // default: one 64-pair unit per workgrou
 
 // (Re)build the pair_block work list with `pairs` pairs per workgroup (a multiple of 64).  More
 // pairs per workgroup = fewer K x L slabs, which matters once a slab is large (big K*L).
+// Chunks (workgroups) a rating with `rating_pairs` pairs gets at `pairs` pairs per chunk, padding included.  Every
+// rating's chunk count is padded to a multiple of 8 with EMPTY chunks (q_begin == q_end): chunk j of every rating then
+// lands on the same XCD (workgroups are dealt to the 8 XCDs round-robin), and the rows of an item, which its R (item,
+// rating) pairs all gather, are served to R - 1 of them by that XCD's L2.  (Speed only: an empty chunk's workgroup
+// writes a zero slab and nothing else.)  The ONE statement of the rule: build_mv_chunks builds by it and the cost model
+// of the matrix-core A launch (mmsbm_hip.hip: balanced_run_units) counts by it.
+inline bool chunk_align_on() { return std::getenv("MMSBM_HIP_NO_CHUNK_ALIGN") == nullptr; }
+inline int64_t padded_chunk_count(int64_t rating_pairs, int32_t pairs, int32_t n_ratings, bool align) {
+  const int64_t chunks = (rating_pairs + pairs - 1) / pairs;
+  return (align && n_ratings > 1 && rating_pairs > 0) ? (chunks + kXcds - 1) / kXcds * kXcds : chunks;
+}
 inline void build_mv_chunks(Layout &L, int32_t pairs) {
-  // Every rating's chunk count is padded to a multiple of 8 with EMPTY chunks (q_begin == q_end): chunk
-  // j of every rating then lands on the same XCD (workgroups are dealt to the 8 XCDs round-robin), and
-  // the rows of an item, which its R (item, rating) pairs all gather, are served to R - 1 of them by
-  // that XCD's L2.  (Speed only: an empty chunk's workgroup writes a zero slab and nothing else.)
-  const bool align = std::getenv("MMSBM_HIP_NO_CHUNK_ALIGN") == nullptr;
+  const bool align = chunk_align_on();
   L.mv_chunks.clear();
   L.mv_chunk_off.assign(size_t(L.n_ratings) + 1, 0);
   for (int r = 0; r < L.n_ratings; ++r) {
-    const int32_t end = L.rating_off[r + 1];
-    for (int32_t q = L.rating_off[r]; q < end; q += pairs)
+    const int32_t beg = L.rating_off[r], end = L.rating_off[r + 1];
+    for (int32_t q = beg; q < end; q += pairs)
       L.mv_chunks.push_back(Chunk{r, q, std::min<int32_t>(q + pairs, end), 0});
-    if (align && L.n_ratings > 1 && end > L.rating_off[r])
-      while ((L.mv_chunks.size() - size_t(L.mv_chunk_off[r])) % size_t(kXcds)) L.mv_chunks.push_back(Chunk{r, end, end, 0});
+    const int64_t want = int64_t(L.mv_chunk_off[r]) + padded_chunk_count(end - beg, pairs, L.n_ratings, align);
+    while (int64_t(L.mv_chunks.size()) < want) L.mv_chunks.push_back(Chunk{r, end, end, 0});
     L.mv_chunk_off[r + 1] = int32_t(L.mv_chunks.size());
   }
 }
@@ -370,7 +377,7 @@ inline SegPieces segment_pieces(const std::vector<int32_t> &off, const WorkList 
 inline bool build_mv_chunks_capped(Layout &L, const SegPieces &sp, int32_t pairs, int32_t cap_items) {
   for (int32_t q = 0; q < L.n_pairs; ++q)
     if (sp.first[size_t(q) + 1] - sp.first[size_t(q)] > cap_items) return false;
-  const bool align = std::getenv("MMSBM_HIP_NO_CHUNK_ALIGN") == nullptr;
+  const bool align = chunk_align_on();
   L.mv_chunks.clear();
   L.mv_chunk_off.assign(size_t(L.n_ratings) + 1, 0);
   for (int r = 0; r < L.n_ratings; ++r) {

@@ -147,21 +147,43 @@ namespace {
 // resident at a time: the launch lasts rounds x (units + a prologue of ~0.6 unit-times: the tile into LDS, the item ids,
 // the first rows' latency -- measured at C5, EXPERIMENTS.md), and rounds is an INTEGER (with 768 slots C5's 15,616 units in
 // runs of 8 are 1,952 workgroups = 2.54 rounds, paid as 3 = 24 unit-times; in runs of 11 they are 1.9 rounds, paid as 2 = 22).
-// Every rating's run count is rounded up to a multiple of 8 as in build_mv_chunks.
+// Workgroups are counted by the rule the run list is built by (layout.hpp: padded_chunk_count).
 inline int balanced_run_units(const std::vector<int32_t> &rating_off, int slots, int lo, int hi) {
   int best = hi;
   double best_cost = 1e300;
+  const bool align = mmsbm::chunk_align_on();
+  const int n_ratings = static_cast<int>(rating_off.size()) - 1;
   for (int u = hi; u >= lo; --u) {
     long long wgs = 0;
-    for (size_t r = 0; r + 1 < rating_off.size(); ++r) {
-      const long long units = (rating_off[r + 1] - rating_off[r] + kUnitPairs - 1) / kUnitPairs;
-      const long long runs = (units + u - 1) / u;
-      wgs += rating_off.size() > 2 ? (runs + 7) / 8 * 8 : runs;
-    }
+    for (int r = 0; r < n_ratings; ++r)
+      wgs += mmsbm::padded_chunk_count(rating_off[static_cast<size_t>(r) + 1] - rating_off[static_cast<size_t>(r)],
+                                       u * kUnitPairs, n_ratings, align);
     const double cost = static_cast<double>((wgs + slots - 1) / std::max(slots, 1)) * (u + 0.6);
     if (cost < best_cost * 0.97) { best_cost = cost; best = u; }   // (longer runs win ties: fewer prologues)
   }
   return best;
+}
+
+// The A launch of the matrix-core pair stage writes rows only -- nothing ties its workgroups to the T + S launch's
+// slabs -- so it walks the same units in runs of its own length: `units` 64-pair units per workgroup, or (0) as many as
+// make its last round of workgroups (nearly) full (balanced_run_units; C5: runs of 11 units where the T + S launch takes
+// 8).  Same rows, bit for bit.  n_a_chunks = 0: the T + S launch's own list serves.
+void build_a_runs(mmsbm_hip_ctx *c, int units) {
+  c->n_a_chunks = 0;
+  c->a_chunks.release();
+  if (!c->mfma || c->n_pairs <= 0) return;
+  const int now = c->mv_chunk_pairs / kUnitPairs, most = kMfmaChunkPairs / kUnitPairs;
+  int a_units = units > 0 ? std::min(units, most)
+                          : balanced_run_units(c->lay.rating_off, mfma_a_blocks_per_cu(c) * c->n_cus, std::max(2, now / 2),
+                                               std::min(2 * now, most));
+  c->a_units = a_units;
+  if (a_units == now) return;
+  mmsbm::Layout tmp;   // (only the fields build_mv_chunks reads and writes)
+  tmp.n_ratings = c->lay.n_ratings; tmp.rating_off = c->lay.rating_off;
+  mmsbm::build_mv_chunks(tmp, a_units * kUnitPairs);
+  c->a_chunks.upload(tmp.mv_chunks, c->stream);
+  HIP_CHECK(hipStreamSynchronize(c->stream));   // (`tmp` is a local)
+  c->n_a_chunks = static_cast<int>(tmp.mv_chunks.size());
 }
 
 // ---- small problems: the iteration in two launches (fused_small.hpp) -------------------------------------
@@ -792,24 +814,7 @@ int mmsbm_hip_create(int device, int64_t n_obs, int32_t n_users, int32_t n_items
       HIP_CHECK(hipStreamSynchronize(s));  // `grid` is a local
     }
     c->mv_chunks.upload(c->lay.mv_chunks, s);
-    // The A launch of the matrix-core pair stage writes rows only -- nothing ties its workgroups to the T + S launch's
-    // slabs -- so it walks the same units in runs of its own length, chosen so that its last round of workgroups is
-    // (nearly) full (balanced_run_units; C5: runs of 11 units where the T + S launch takes 8).  Same rows, bit for bit.
-    std::vector<mmsbm::Chunk> a_runs;
-    if (c->mfma && c->n_pairs > 0) {
-      const int per_cu = mfma_a_blocks_per_cu(c.get());
-      const int now = c->mv_chunk_pairs / kUnitPairs;
-      int a_units = balanced_run_units(c->lay.rating_off, per_cu * c->n_cus, std::max(2, now / 2), std::min(2 * now, kMfmaChunkPairs / kUnitPairs));
-      if (const char *e = std::getenv("MMSBM_HIP_A_UNITS")) a_units = std::min(std::max(1, std::atoi(e)), kMfmaChunkPairs / kUnitPairs);  // (tests)
-      if (a_units != now) {
-        mmsbm::Layout tmp;   // (only the fields build_mv_chunks reads and writes)
-        tmp.n_ratings = c->lay.n_ratings; tmp.rating_off = c->lay.rating_off;
-        mmsbm::build_mv_chunks(tmp, a_units * kUnitPairs);
-        a_runs = tmp.mv_chunks;
-        c->a_chunks.upload(a_runs, s);
-        c->n_a_chunks = static_cast<int>(a_runs.size());
-      }
-    }
+    build_a_runs(c.get(), 0);
     c->lik_units.upload(units64, s);
     c->mv_chunk_off.upload(c->lay.mv_chunk_off, s);
     c->pair_items.upload(c->lay.pair_work.items, s);
@@ -1408,6 +1413,11 @@ int mmsbm_hip_set_option(mmsbm_hip_ctx *ctx, const char *name, double value) {
       ctx->nt_out = static_cast<int>(value);
     } else if (key == "predict_fast") {  // 0: prod_dist / predict through the per-row kernels (R K L multiply-adds per row)
       ctx->predict_fast = value != 0.0;
+    } else if (key == "a_units") {  // 64-pair units per workgroup of the matrix-core A launch; 0: the library's own balance
+      if (value < 0 || value > kMfmaChunkPairs / kUnitPairs) throw std::invalid_argument("a_units: 0 .. 16");
+      use_device(ctx);
+      HIP_CHECK(hipStreamSynchronize(ctx->stream));
+      build_a_runs(ctx, static_cast<int>(value));
     } else if (key == "mfma") {  // the pair stage on the matrix cores: 0 off, 1 on (one-block form if K, L <= 64,
                                  // else the blocked form), 2 the blocked form whatever the shape
       ctx->mfma = value == 1.0 && mfma_possible(ctx);
@@ -1437,6 +1447,7 @@ int mmsbm_hip_get_option(const mmsbm_hip_ctx *ctx, const char *name, double *val
     else if (key == "ranges_users") *value = ctx->ranges_users;   // ranges per pass (1 = off)
     else if (key == "chunk_pairs") *value = ctx->mv_chunk_pairs;   // read-only: pairs per pair-stage workgroup at most
     else if (key == "n_chunks") *value = ctx->n_chunks;            // read-only: pair-stage workgroups (= slabs), padding included
+    else if (key == "a_units") *value = ctx->a_units;     // 64-pair units per workgroup of the matrix-core A launch (0: not on the matrix cores)
     else if (key == "a_chunks") *value = ctx->n_a_chunks;   // read-only: workgroups of the matrix-core A launch when it walks runs of its own (0: the T + S launch's)
     else if (key == "items_pairs") *value = static_cast<double>(ctx->lay.pair_work.items.size());
     else if (key == "items_users") *value = static_cast<double>(ctx->lay.user_work.items.size());

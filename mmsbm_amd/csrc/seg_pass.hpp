@@ -319,15 +319,12 @@ __device__ __forceinline__ void seg_combine_small(const CombineArgs &ca, const C
 }
 
 template <int G, int VEC>
-__global__ __launch_bounds__(kBlock) void seg_combine_kernel(CombineArgs ca, CombineArgs cb, int blocks_a, int dp) {
-  seg_combine_big<G, VEC>(ca, cb, static_cast<int>(blockIdx.x), blocks_a, dp);
-}
-template <int G, int VEC>
 __global__ __launch_bounds__(kBlock) void seg_combine_small_kernel(CombineArgs ca, CombineArgs cb, int blocks_a, int dp) {
   seg_combine_small<G, VEC>(ca, cb, static_cast<int>(blockIdx.x), blocks_a, dp);
 }
-// Both kinds in one launch (small problems, where a launch costs more than what it does): blocks [0, n_small) take the
-// splits of few pieces, a group of lanes each; the rest take one split of many pieces each.
+// Splits of many pieces -- and, in the same launch (a launch costs more than what it does here), the splits of few
+// pieces if there are any: blocks [0, n_small) take those, a group of lanes each; the rest take one split of many pieces
+// each.
 template <int G, int VEC>
 __global__ __launch_bounds__(kBlock) void seg_combine_both_kernel(CombineArgs sa, CombineArgs sb, int small_a, int n_small,
                                                                   CombineArgs ba, CombineArgs bb, int big_a, int dp) {

@@ -44,10 +44,15 @@ void stage_dense_valu(mmsbm_hip_ctx *c) {  // T = P^T C  and the K x L slabs for
   if (!big_tile) {
     if (big_wg) PB_GO(1, false, kPairBlockMax, 2, false); else PB_GO(1, false, kBlock, 2, false);
   } else {
+    // (four slots per thread: only where 512 threads are too few for the tile's slots, (K/4)(L/4) > 1,024 -- such a tile
+    // does not fit the LDS beside the rows, and a 256-thread launch (L <= 24) runs out of LDS for its K rows first)
     switch (c->pb_nacc) {
       case 1: PB_BIG(1); break;
       case 2: PB_BIG(2); break;
-      default: PB_BIG(4); break;
+      default:
+        if (c->tl_t || !big_wg) throw ApiError(MMSBM_E_INTERNAL, "pair_block (T + S): four slots per thread with the tile in LDS or 256 threads");
+        PB_GO(4, false, kPairBlockMax, 4, true);
+        break;
     }
   }
 #undef PB_BIG

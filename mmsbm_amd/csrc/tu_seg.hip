@@ -61,9 +61,13 @@ void stage_seg(mmsbm_hip_ctx *c, bool commit, bool with_pairs, bool with_users, 
 #define SEG_GO(G, V, B) LAUNCH_IN(ls, (seg_pass_kernel<G, V, B>), slot_grid(c, bp + bu), kBlock, 0, st, sp, su, bp, c->kp)
     if (c->seg_batch == 8 && c->code_k <= 4) {  // (eight row gathers in flight per group: small problems; not with
                                                   // 8 or 16 doubles per lane and row: that is 128 - 256 registers)
-#define CALL(G, V) SEG_GO(G, V, 8)
-      DISPATCH_GV(c->code_k, CALL);
-#undef CALL
+      switch (c->code_k) {
+        case 0: SEG_GO(4, 4, 8); break;
+        case 1: SEG_GO(8, 4, 8); break;
+        case 2: SEG_GO(16, 4, 8); break;
+        case 3: SEG_GO(32, 4, 8); break;
+        default: SEG_GO(64, 4, 8); break;
+      }
     } else {
 #define CALL(G, V) SEG_GO(G, V, 4)
       DISPATCH_GV(c->code_k, CALL);
@@ -84,17 +88,13 @@ void stage_seg(mmsbm_hip_ctx *c, bool commit, bool with_pairs, bool with_users, 
   const CombineArgs cub{c->user_splits.ptr + wu.n_small, su.parts, c->user_off.ptr, su.fixed, su.out, nsu_b, su.mode, su.bs_parts};
   const int ba = (nsp_s + per - 1) / per, bb = (nsu_s + per - 1) / per;
   const size_t lds = static_cast<size_t>(per) * c->kp * sizeof(double);
-  if (nsp_s + nsu_s > 0 && nsp_b + nsu_b > 0) {  // both kinds: one launch
+  if (nsp_b + nsu_b > 0) {  // some split has many pieces: one launch for both kinds (the small ones' blocks first, if any)
 #define CALL(G, V) \
   LAUNCH((seg_combine_both_kernel<G, V>), slot_grid(c, ba + bb + nsp_b + nsu_b), kBlock, lds, st, cps, cus, ba, ba + bb, cpb, cub, nsp_b, c->kp)
     DISPATCH_GV(c->code_k, CALL);
 #undef CALL
   } else if (nsp_s + nsu_s > 0) {
 #define CALL(G, V) LAUNCH((seg_combine_small_kernel<G, V>), slot_grid(c, ba + bb), kBlock, 0, st, cps, cus, ba, c->kp)
-    DISPATCH_GV(c->code_k, CALL);
-#undef CALL
-  } else if (nsp_b + nsu_b > 0) {
-#define CALL(G, V) LAUNCH((seg_combine_kernel<G, V>), slot_grid(c, nsp_b + nsu_b), kBlock, lds, st, cpb, cub, nsp_b, c->kp)
     DISPATCH_GV(c->code_k, CALL);
 #undef CALL
   }

@@ -141,18 +141,19 @@ def test_c5_shape_with_the_chunk_sizes_full_size_c5_runs(hip, c5_shape, chunk, m
 
 def test_the_a_launch_walks_runs_of_its_own_and_gives_the_same_rows(hip, c5_shape, monkeypatch):
     """The matrix-core A launch writes rows only, so it walks the units in runs of its own length, chosen so that its last
-    round of workgroups is (nearly) full (stages.hpp: balanced_run_units; C5: 11 units where the T + S launch takes 8).
+    round of workgroups is (nearly) full (mmsbm_hip.hip: balanced_run_units; C5: 11 units where the T + S launch takes 8).
     A rows do not depend on which workgroup computes them: theta / eta / p after three iterations are BITWISE the same
     for runs of 1, 3 and 16 units (ragged last runs, empty padding runs) as for the T + S launch's own 4-unit chunks --
     and every entry agrees with the dense oracle as in the tests above."""
     train, case = c5_shape
     outs = {}
     for units in (4, 1, 3, 16):
-        monkeypatch.setenv("MMSBM_HIP_A_UNITS", str(units))
         mm = hip.MMSBM(case["k"], case["l"], iterations=3, seed=case["seed"])
         mm._prepare_objects(train)
         ctx = mm._ctx(0)
         assert ctx.get_option("mfma") == 1.0 and ctx.get_option("chunk_pairs") == 256
+        ctx.set_option("a_units", units)
+        assert ctx.get_option("a_units") == units
         # 1,200 pairs per rating = 19 units: ceil(19 / units) runs, padded to a multiple of 8 per rating (0: the T + S launch's list)
         runs = -(-19 // units)
         assert ctx.get_option("a_chunks") == (0 if units == 4 else 10 * (-(-runs // 8) * 8))
