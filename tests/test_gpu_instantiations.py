@@ -78,10 +78,11 @@ def check_step_and_loop(em, data, theta, eta, pr, d_u, d_i, iters=2, checker=orc
 
 
 # ---- the triple passes with four rows in flight (more than 300,000 ratings) at the row widths the big configs skip ----
-@pytest.mark.parametrize("n,k,l,kernel", [(450_000, 16, 16, "seg_pass_kernel<4,4,4>"), (301_000, 100, 4, "seg_pass_kernel<32,4,4>"),
+@pytest.mark.parametrize("n,k,l,kernel", [(600_000, 16, 16, "seg_pass_kernel<4,4,4>"), (301_000, 100, 4, "seg_pass_kernel<32,4,4>"),
                                           (301_000, 200, 4, "seg_pass_kernel<64,4,4>")])
 def test_triple_passes_four_rows_in_flight(hip, n, k, l, kernel):
-    # (rows of up to 16 groups: the four-launch form takes over from the two-launch one at ratings x (K + L) > 14M)
+    # (rows of up to 16 groups: the four-launch form takes over from the two-launch one at ratings x (K + L) > 14M -- 18M for data
+    # with cut segments, which 37 ratings per pair are)
     data, (n_u, n_i, n_r) = uniform(n, 30_000, 3_000, 4, seed=k)
     d_u, d_i = orc.degrees(data, n_u, n_i)
     theta, eta, pr = orc.init_params(5, n_u, n_i, n_r, k, l, d_u, d_i)
