@@ -5,7 +5,7 @@
 set -u
 i=0
 for flags in "$@"; do
-  hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared $flags -o /tmp/libab$i.so mmsbm_amd/csrc/mmsbm_hip.hip &
+  hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared $flags -o /tmp/libab$i.so mmsbm_amd/csrc/unity.hip &
   i=$((i+1))
   [ $((i % 6)) -eq 0 ] && wait
 done

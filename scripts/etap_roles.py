@@ -1,4 +1,7 @@
 import os, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _diag import use_diagnostic_build
+use_diagnostic_build("MMSBM_ABLATE")   # the stage bits 8+ (phase ablation) exist in this build only
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mmsbm_amd import MMSBM
 from mmsbm_amd.synthetic import CONFIGS, synthetic_triples

@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # Registers / occupancy / LDS of every kernel, from the compiler's resource-usage remarks.
 # usage: scripts/kernel_resources.sh [source.hip]
-src=${1:-mmsbm_amd/csrc/mmsbm_hip.hip}
+src=${1:-mmsbm_amd/csrc/unity.hip}   # all translation units as one (the product compiles them side by side)
 /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared \
   -Rpass-analysis=kernel-resource-usage -o /dev/null "$src" 2>&1 |
 awk '/Function Name:/ {name=$(NF-1)} / VGPRs:/ {v=$(NF-1)} /TotalSGPRs:/ {s=$(NF-1)} /ScratchSize/ {sc=$(NF-1)}

@@ -1,7 +1,7 @@
 """Where the workgroups of a pair-stage launch spend their time (diagnostic build with -DMMSBM_STAMPS:
 thread 0 of every workgroup records the 100 MHz wall clock at its phase borders).
 
-    hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared -DMMSBM_STAMPS -o /tmp/libstamps.so mmsbm_amd/csrc/mmsbm_hip.hip
+    hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared -DMMSBM_STAMPS -o /tmp/libstamps.so mmsbm_amd/csrc/unity.hip
     MMSBM_HIP_LIBRARY=/tmp/libstamps.so python scripts/phase_stamps.py c3 1     # stage 1 = T+S, 3 = A
 """
 import ctypes as C, os, sys

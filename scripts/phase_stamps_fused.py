@@ -1,7 +1,7 @@
 """Where the workgroups of pairs_fused_kernel spend their time (diagnostic build with -DMMSBM_STAMPS, see
 scripts/phase_stamps.py).
 
-    hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared -DMMSBM_STAMPS -o /tmp/libstamps.so mmsbm_amd/csrc/mmsbm_hip.hip
+    hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared -DMMSBM_STAMPS -o /tmp/libstamps.so mmsbm_amd/csrc/unity.hip
     MMSBM_HIP_LIBRARY=/tmp/libstamps.so python scripts/phase_stamps_fused.py c2
 """
 import ctypes as C, os, sys

