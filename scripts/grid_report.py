@@ -61,9 +61,9 @@ def fmt(x, nd=1):
 
 
 def table(rows, head):
-    md = ["| row | it/s (timed region) | it/s steady | µs / iteration | algorithmic GB/s | % of 8.0 TB/s | % of 6.29 TB/s | "
+    md = ["| row | it/s (timed region) | it/s (median of 5 × ≥ 50 iterations) | it/s steady | µs / iteration | algorithmic GB/s | % of 8.0 TB/s | % of 6.29 TB/s | "
           "dominant kernel: µs, counter traffic GB/s | fp64 VALU % | CPU it/s (cores; port / reference) | pair stage | build id |",
-          "|---|---|---|---|---|---|---|---|---|---|---|---|"]
+          "|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
     for key, label, line in rows:
         it = line["iteration"]
         st = line.get("steady_state") or {}
@@ -73,14 +73,14 @@ def table(rows, head):
         rate = st.get("value") or line["value"]
         gbps = it["algorithmic_read_bytes"] * rate / 1e9
         cpu_txt = "n/a" if not cpu else (f"{cpu['value']:.3g} ({cpu['cores']}; {cpu.get('port_over_reference', 'n/a')})")
-        md.append(f"| {label} | {fmt(line['value'], 0)} | {fmt(st.get('value'), 0)} | {fmt(1e6 / rate, 2)} | {fmt(gbps, 0)} | "
+        md.append(f"| {label} | {fmt(line['value'], 0)} | {fmt((line.get('median_of_5') or {}).get('value'), 0)} | {fmt(st.get('value'), 0)} | {fmt(1e6 / rate, 2)} | {fmt(gbps, 0)} | "
                   f"{100 * gbps / 8000:.1f} | {100 * gbps / 6290:.1f} | {rf['kernel']}: {fmt(rf['avg_launch_us'], 1)}, {fmt(traffic, 0)} | "
                   f"{100 * it['fp64_valu']['frac_of_peak']:.1f} | {cpu_txt} | {line['config']['pair_stage'].split(' (')[0]} | "
                   f"`{line['library']['build_id']}` |")
         if line.get("batched_restarts"):
             b = line["batched_restarts"]
             gb = it["algorithmic_read_bytes"] * b["value"] / 1e9
-            md.append(f"| &nbsp;&nbsp;↳ {b['slots']} restarts per launch (restart-iterations/s, HIP events) | | {fmt(b['value'], 0)} | "
+            md.append(f"| &nbsp;&nbsp;↳ {b['slots']} restarts per launch (restart-iterations/s, HIP events) | | | {fmt(b['value'], 0)} | "
                       f"{fmt(b['us_per_restart_iteration'], 2)} | {fmt(gb, 0)} | {100 * gb / 8000:.1f} | {100 * gb / 6290:.1f} | | | | | |")
     return head + "\n\n" + "\n".join(md) + "\n"
 
@@ -106,7 +106,8 @@ def main():
             f"{done[0][2]['ranks'][0]['device_name']} (one GPU; every row is one run of `bench.py`, the commands are in "
             f"`{args.tag}_grid.json`).  Sources `{sid}`; libraries that ran: {', '.join('`' + i + '`' for i in ids)}"
             f"{'' if ids == [sid] else ' -- NOT the sources in the tree: rerun'}.  float64 throughout; the bound is HBM "
-            "bandwidth (SURVEY 8(d): B_read = N(12+8K+8L) + 8KLR per iteration); `it/s steady` = 200-1,000 iterations "
+            "bandwidth (SURVEY 8(d): B_read = N(12+8K+8L) + 8KLR per iteration); `median of 5` = SURVEY 8(d)'s protocol (>= 50 "
+            "iterations per repeat after warm-up, HIP events, median of 5 repeats); `it/s steady` = 200-1,000 iterations "
             "timed with HIP events after the timed region (the columns to its right use it when present).")
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     with open(os.path.join(ROOT, "profiles", f"{args.tag}_grid.json"), "w") as fh:
