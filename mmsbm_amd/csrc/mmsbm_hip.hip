@@ -73,19 +73,26 @@ bool g_launch_log_on = std::getenv("MMSBM_HIP_LAUNCH_LOG") != nullptr && std::ge
 
 namespace {
 struct LaunchLog {
-  struct Rec { long long count = 0; std::string tag; };
+  struct Rec { long long count = 0; std::string name, tag; };
   std::mutex mu;
-  std::map<const void *, Rec> seen;   // host-side kernel handle -> launches since the last flush, tag of the first one
+  std::map<const void *, Rec> seen;   // host-side kernel handle -> launches since the last flush, name, tag of the first one
   void note(const void *fn) {
     std::lock_guard<std::mutex> lock(mu);
     Rec &r = seen[fn];
-    if (r.count++ == 0 && r.tag.empty()) {
+    if (r.count++ == 0 && r.name.empty()) {
+      // (the name is asked for HERE, with the runtime alive and the kernel about to be launched -- not at exit, when
+      // the runtime may already be gone)
+      const char *name = hipKernelNameRefByPtr(fn, nullptr);
+      char buf[64];
+      std::snprintf(buf, sizeof buf, "%p", fn);
+      r.name = (name && name[0]) ? name : buf;
       const char *t = std::getenv("MMSBM_HIP_LAUNCH_TAG");
       r.tag = t ? t : "-";
     }
   }
   // one line per kernel: pid <tab> launches <tab> mangled name <tab> tag; appended in ONE write, so that the lines of
-  // several processes sharing the file do not interleave.  Counts restart from zero, names and tags are kept.
+  // several processes sharing the file do not interleave.  Counts restart from zero, names and tags are kept.  No HIP
+  // call in here: it also runs when the library is unloaded.
   void flush() {
     std::lock_guard<std::mutex> lock(mu);
     const char *path = std::getenv("MMSBM_HIP_LAUNCH_LOG");
@@ -93,11 +100,8 @@ struct LaunchLog {
     std::string out;
     for (auto &kv : seen) {
       if (kv.second.count == 0) continue;
-      const char *name = hipKernelNameRefByPtr(kv.first, nullptr);
-      char buf[64];
-      std::snprintf(buf, sizeof buf, "%p", kv.first);
       out += std::to_string(static_cast<long long>(getpid())) + "\t" + std::to_string(kv.second.count) + "\t" +
-             (name && name[0] ? name : buf) + "\t" + kv.second.tag + "\n";
+             kv.second.name + "\t" + kv.second.tag + "\n";
       kv.second.count = 0;
     }
     if (out.empty()) return;

@@ -105,7 +105,7 @@ __device__ __forceinline__ void seg_body(const SegArgs &a, int unit, int dp, int
   }
 
   if (!act) return;
-  if (part >= 0) {  // a piece of a long segment: raw partial sum, finished by seg_combine_kernel
+  if (part >= 0) {  // a piece of a long segment: raw partial sum, finished by the combine kernels below
     store_vec<VEC>(a.parts + sidx * a.bs_parts + static_cast<size_t>(part) * dp + lane_off, acc);
     return;
   }
