@@ -19,7 +19,6 @@ serves / its mean duration from HIP events on the library's stream; the `rocprof
 `cpu_baseline` is the numpy oracle (the reference's dense dataflow) timed on this host.
 """
 import argparse
-import hashlib
 import json
 import os
 import socket

@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 ROWS = [
     # key, label, bench.py arguments
     ("c1", "C1: 100 ratings, K=2, L=4", ["--config", "c1", "--steps", "1000", "--warmup", "50"]),
-    ("c2", "C2: 100k ratings, K=L=10", ["--config", "c2", "--steps", "1000", "--warmup", "50"]),
+    ("c2", "C2: 100k ratings, K=L=10", ["--config", "c2", "--steps", "1000", "--warmup", "50", "--cpu-iters", "20"]),
     ("c3", "C3: 1M ratings, K=L=20 (headline; the driver's 20 steps)", ["--config", "c3", "--steps", "20", "--warmup", "5"]),
     ("c3long", "C3, 1,000 steps", ["--config", "c3", "--steps", "1000", "--warmup", "50", "--no-cpu-baseline"]),
     ("c3x8", "C3, 8 restarts as slots of one context", ["--config", "c3", "--steps", "200", "--warmup", "20",
@@ -61,9 +61,9 @@ def fmt(x, nd=1):
 
 
 def table(rows, head):
-    md = ["| row | it/s (timed region) | it/s (median of 5 × ≥ 50 iterations) | it/s steady | µs / iteration | algorithmic GB/s | % of 8.0 TB/s | % of 6.29 TB/s | "
-          "dominant kernel: µs, counter traffic GB/s | fp64 VALU % | CPU it/s (cores; port / reference) | pair stage | build id |",
-          "|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
+    md = ["| row | GPUs | it/s (timed region) | it/s (median of 5 × ≥ 50 iterations) | it/s steady | µs / iteration | algorithmic GB/s | % of 8.0 TB/s | % of 6.29 TB/s | "
+          "dominant kernel: µs, counter traffic GB/s | fp64 VALU % | CPU it/s (cores; port / reference) | speed-up | pair stage | build id |",
+          "|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
     for key, label, line in rows:
         it = line["iteration"]
         st = line.get("steady_state") or {}
@@ -72,16 +72,17 @@ def table(rows, head):
         traffic = None if rf.get("traffic") is None else rf["traffic"] / (rf["avg_launch_us"] * 1e-6) / 1e9
         rate = st.get("value") or line["value"]
         gbps = it["algorithmic_read_bytes"] * rate / 1e9
-        cpu_txt = "n/a" if not cpu else (f"{cpu['value']:.3g} ({cpu['cores']}; {cpu.get('port_over_reference', 'n/a')})")
-        md.append(f"| {label} | {fmt(line['value'], 0)} | {fmt((line.get('median_of_5') or {}).get('value'), 0)} | {fmt(st.get('value'), 0)} | {fmt(1e6 / rate, 2)} | {fmt(gbps, 0)} | "
+        por = cpu.get("port_over_reference") if cpu else None
+        cpu_txt = "n/a" if not cpu else f"{cpu['value']:.3g} ({cpu['cores']}; {'n/a' if por is None else format(por, '.3f')})"
+        md.append(f"| {label} | {line['n_gpus']} | {fmt(line['value'], 0)} | {fmt((line.get('median_of_5') or {}).get('value'), 0)} | {fmt(st.get('value'), 0)} | {fmt(1e6 / rate, 2)} | {fmt(gbps, 0)} | "
                   f"{100 * gbps / 8000:.1f} | {100 * gbps / 6290:.1f} | {rf['kernel']}: {fmt(rf['avg_launch_us'], 1)}, {fmt(traffic, 0)} | "
-                  f"{100 * it['fp64_valu']['frac_of_peak']:.1f} | {cpu_txt} | {line['config']['pair_stage'].split(' (')[0]} | "
+                  f"{100 * it['fp64_valu']['frac_of_peak']:.1f} | {cpu_txt} | {fmt(line.get('gpu_over_cpu'), 0)} | {line['config']['pair_stage'].split(' (')[0]} | "
                   f"`{line['library']['build_id']}` |")
         if line.get("batched_restarts"):
             b = line["batched_restarts"]
             gb = it["algorithmic_read_bytes"] * b["value"] / 1e9
-            md.append(f"| &nbsp;&nbsp;↳ {b['slots']} restarts per launch (restart-iterations/s, HIP events) | | | {fmt(b['value'], 0)} | "
-                      f"{fmt(b['us_per_restart_iteration'], 2)} | {fmt(gb, 0)} | {100 * gb / 8000:.1f} | {100 * gb / 6290:.1f} | | | | | |")
+            md.append(f"| &nbsp;&nbsp;↳ {b['slots']} restarts per launch (restart-iterations/s, HIP events) | 1 | | | {fmt(b['value'], 0)} | "
+                      f"{fmt(b['us_per_restart_iteration'], 2)} | {fmt(gb, 0)} | {100 * gb / 8000:.1f} | {100 * gb / 6290:.1f} | | | | | | |")
     return head + "\n\n" + "\n".join(md) + "\n"
 
 
@@ -108,7 +109,9 @@ def main():
             f"{'' if ids == [sid] else ' -- NOT the sources in the tree: rerun'}.  float64 throughout; the bound is HBM "
             "bandwidth (SURVEY 8(d): B_read = N(12+8K+8L) + 8KLR per iteration); `median of 5` = SURVEY 8(d)'s protocol (>= 50 "
             "iterations per repeat after warm-up, HIP events, median of 5 repeats); `it/s steady` = 200-1,000 iterations "
-            "timed with HIP events after the timed region (the columns to its right use it when present).")
+            "timed with HIP events after the timed region (the columns to its right use it when present); CPU = the numpy "
+            "restatement of the reference's dense dataflow on this host (C5: its first 60,000 rows scaled by rows -- the "
+            "reference's own dataflow is infeasible there, omega = 200 GB); speed-up = timed-region it/s / CPU it/s.")
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     with open(os.path.join(ROOT, "profiles", f"{args.tag}_grid.json"), "w") as fh:
         json.dump({"tag": args.tag, "source_id": sid, "rows": [{"key": k, "label": lb, "line": ln} for k, lb, ln in done]},
