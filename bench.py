@@ -274,6 +274,12 @@ def batched_rate(model, train, device, slots, iters):
             "value": slots * iters / (ms * 1e-3), "unit": "restart-iterations/s on one GPU (HIP events)"}
 
 
+def _config_groups(config):
+    from mmsbm_amd.synthetic import CONFIGS
+    k, l = CONFIGS[config][4:6]
+    return (k,) if k == l else ()
+
+
 def roofline_object(args, ctx, prof, n, k, l):
     """The dominant kernel against the HBM roofline, SURVEY 8(d)-based."""
     dom = max(prof, key=lambda nm: prof[nm][0] * prof[nm][1])
@@ -309,7 +315,8 @@ def roofline_object(args, ctx, prof, n, k, l):
                           "HBM: the resident set (%.0f MB) exceeds the 256 MiB Infinity Cache" % (resident / 1e6),
            "traffic": None, "traffic_source": None}
     pmc_path = os.path.join(ROOT, "profiles", "pmc_summary.json")
-    same_command = getattr(args, "groups", 0) in (0, k) and getattr(args, "mfma", -1) < 0   # (the profiles are of the configs themselves)
+    # (the profiles are of the configs themselves: not of a K = L override, not of a forced pair-stage form)
+    same_command = getattr(args, "mfma", -1) < 0 and getattr(args, "groups", 0) in (0,) + _config_groups(args.config)
     if os.path.exists(pmc_path) and same_command:  # rocprofv3 passes of this same command (scripts/profile_round.sh)
         with open(pmc_path) as fh:
             pmc = json.load(fh)

@@ -37,7 +37,7 @@ ROWS = [
     ("c3k24", "C3 size, K=L=24", ["--config", "c3", "--groups", "24", "--steps", "1000", "--warmup", "50", "--no-cpu-baseline"]),
     ("c3k32", "C3 size, K=L=32", ["--config", "c3", "--groups", "32", "--steps", "1000", "--warmup", "50", "--no-cpu-baseline"]),
     ("c5", "C5: 10M ratings, K=L=50, pair stage on the matrix cores", ["--config", "c5", "--steps", "100", "--warmup", "10",
-                                                                       "--steady-steps", "200", "--mfma", "1"]),
+                                                                       "--steady-steps", "200"]),
     ("c5valu", "C5, pair stage on the vector ALUs (mfma = 0)", ["--config", "c5", "--steps", "100", "--warmup", "10",
                                                                  "--steady-steps", "200", "--mfma", "0", "--no-cpu-baseline"]),
 ]
@@ -102,6 +102,15 @@ def main():
         print(f"[grid] {key}: {label}", flush=True)     # (a progress line per row: the GPU box kills silent commands)
         done.append((key, label, run_row(cmd, args.timeout)))
     sid = source_id()
+    path = os.path.join(ROOT, "profiles", f"{args.tag}_grid.json")
+    if args.rows and os.path.exists(path):      # some rows again: the others are kept if they are of the same sources
+        with open(path) as fh:
+            old = json.load(fh)
+        if old.get("source_id") == sid:
+            fresh = {k: (k, lb, ln) for k, lb, ln in done}
+            kept = {r["key"]: (r["key"], r["label"], r["line"]) for r in old["rows"]}
+            kept.update(fresh)
+            done = [kept[r[0]] for r in ROWS if r[0] in kept]
     ids = sorted({line["library"]["build_id"] for _, _, line in done})
     head = (f"# Synthetic-grid report `{args.tag}`\n\nGenerated by `python scripts/grid_report.py {args.tag}` on "
             f"{done[0][2]['ranks'][0]['device_name']} (one GPU; every row is one run of `bench.py`, the commands are in "
@@ -113,7 +122,7 @@ def main():
             "restatement of the reference's dense dataflow on this host (C5: its first 60,000 rows scaled by rows -- the "
             "reference's own dataflow is infeasible there, omega = 200 GB); speed-up = timed-region it/s / CPU it/s.")
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
-    with open(os.path.join(ROOT, "profiles", f"{args.tag}_grid.json"), "w") as fh:
+    with open(path, "w") as fh:
         json.dump({"tag": args.tag, "source_id": sid, "rows": [{"key": k, "label": lb, "line": ln} for k, lb, ln in done]},
                   fh, indent=1)
     with open(os.path.join(ROOT, "profiles", f"{args.tag}_grid.md"), "w") as fh:
