@@ -1,6 +1,6 @@
 #!/usr/bin/env bash
 # Memory-path counters of the iteration's kernels (TLB, L1 stalls, fabric request sizes, DRAM share).
-# usage (on the GPU box through gpurun): scripts/pmc_mem.sh <tag> <config>
+# usage (on the GPU box through gpurun): scripts/pmc_mem.sh <tag> <config> [extra bench.py arguments, e.g. "--groups 16"]
 # Every pass runs under its own `timeout`: a counter set the hardware cannot collect in one pass makes rocprofv3 abort
 # inside rocprofiler_create_counter_config at the FIRST dispatch of the process ("error code 38: Request exceeds the
 # capabilities of the hardware to collect"), and its signal handler then waits for that dispatch for ever -- this is
@@ -9,10 +9,11 @@
 set -u
 tag=${1:-mem}
 config=${2:-c3}
+extra=${3:-}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-short="python3 $root/bench.py --config $config --steps 20 --warmup 2 --no-cpu-baseline --profile-iters 2 --steady-steps 0 --no-collective-at-1"
+short="python3 $root/bench.py --config $config --steps 20 --warmup 2 --no-cpu-baseline --profile-iters 2 --steady-steps 0 --no-collective-at-1 $extra"
 i=0
 for set in "TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_REQUEST_sum TCP_PENDING_STALL_CYCLES_sum" \
            "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_DRAM_sum TCC_REQ_sum" \

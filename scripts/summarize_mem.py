@@ -32,8 +32,12 @@ with open(out, "w", newline="") as fh:
             d["fabric_read_bytes (TCC_EA0_RDREQ x 128 B; 32-B requests: TCC_EA0_RDREQ_32B)"] = c["TCC_EA0_RDREQ_sum"] * 128 - c.get("TCC_EA0_RDREQ_32B_sum", 0) * 96
         if c.get("TCC_CYCLE_sum") and c.get("TCC_EA0_RDREQ_LEVEL_sum"):
             d["fabric_reads_in_flight_per_l2_channel (RDREQ_LEVEL / TCC_CYCLE x 16 channels x 8 XCDs)"] = c["TCC_EA0_RDREQ_LEVEL_sum"] / c["TCC_CYCLE_sum"]
+        if c.get("TCC_CYCLE_sum") and c.get("TCC_BUSY_sum") is not None:
+            d["l2_busy_fraction (TCC_BUSY / TCC_CYCLE)"] = c["TCC_BUSY_sum"] / c["TCC_CYCLE_sum"]
+        if c.get("TCC_REQ_sum") and c.get("TCC_CYCLE_sum"):
+            d["l2_requests_per_channel_cycle (TCC_REQ / TCC_CYCLE)"] = c["TCC_REQ_sum"] / c["TCC_CYCLE_sum"]
         if c.get("TCP_UTCL1_REQUEST_sum"):
             d["utcl1_miss_rate"] = c.get("TCP_UTCL1_TRANSLATION_MISS_sum", 0) / c["TCP_UTCL1_REQUEST_sum"]
         for k, v in d.items():
             w.writerow([nm, "derived: " + k, f"{v:.6g}", ""])
-print(open(out).read())
+print(open(out).read()) if "-q" not in sys.argv else print(out)
